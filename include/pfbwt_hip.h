@@ -1,0 +1,124 @@
+/*
+ * include/pfbwt_hip.h -- C ABI of libpfbwt_hip.so, the MI355X (gfx950) engine for the hot path of
+ * alshai/pfbwt-f: prefix-free parse, BWT of the parse, dictionary suffix sort and BWT/SA emission.
+ *
+ * Plain pointers and sizes only (no C++/torch types), so the reference's host code can bind it:
+ * INTEGRATION.md shows the replacement bodies for include/pfparser.hpp and include/pfbwt.hpp.
+ * Every entry point names the reference interface it stands in for (file:line under the
+ * reference tree).  All entry points return PFP_OK (0) or a negative pfp_status; none calls exit().
+ *
+ * uint_t width: the reference fixes `uint_t` at compile time (-DM64, gsa/gsacak.h:44-58).  Here it
+ * is a per-context flag: arrays documented as "U-wide" hold uint32_t without PFP_FLAG_U64 and
+ * uint64_t with it.
+ *
+ * Threading: one pfp_ctx per host thread (the reference gives each std::thread its own PfParser,
+ * src/merge_pfp.cpp:97-104).  A context owns one HIP stream and one device workspace.
+ */
+#ifndef PFBWT_HIP_H
+#define PFBWT_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pfp_ctx pfp_ctx;
+
+typedef enum pfp_status {
+    PFP_OK = 0,
+    PFP_E_ARG = -1,          /* bad argument (w > 32: pfparser.hpp:371-376; p == 0; NULL) */
+    PFP_E_INVALID_CHAR = -2, /* hash.hpp:31 "error, invalid character"; see pfp_error_detail */
+    PFP_E_TOO_LARGE = -3,    /* input needs 64-bit device indices (pfparser.hpp:326-331, 393-404) */
+    PFP_E_NOMEM = -4,        /* device workspace exhausted; pfp_workspace_needed() says how much */
+    PFP_E_HIP = -5,          /* HIP runtime error; pfp_error_detail gives the hipError_t */
+    PFP_E_ONE_WORD = -6,     /* pfparser.hpp:390-392 "only one dict word total" */
+    PFP_E_STATE = -7,        /* call order violated (e.g. pfp_parse_bwt before pfp_parse_finalize) */
+    PFP_E_CORRUPT = -8       /* loaded parse files are inconsistent (pfbwt.hpp:139 "something went wrong!") */
+} pfp_status;
+
+/* pfp_create flags */
+#define PFP_FLAG_U64           1u /* uint_t = uint64_t (pfbwt-f64), else uint32_t (pfbwt-f) */
+#define PFP_FLAG_NON_ACGT_TO_A 2u /* PfParserParams::non_acgt_to_a, pfparser.hpp:342-344 */
+#define PFP_FLAG_SAI           4u /* PfParserParams::get_sai: keep sai/bwsai (needed for -s / -r) */
+
+/* sizes reported after the parse; names as in SURVEY.md section 8 */
+typedef struct pfp_parse_sizes {
+    uint64_t n;      /* PfParser::get_n(): text length incl. the w 'A's after each sequence */
+    uint64_t m;      /* get_parse_size(): phrases in the parse */
+    uint64_t dwords; /* distinct phrases */
+    uint64_t dsize;  /* bytes of the .dict image */
+} pfp_parse_sizes;
+
+typedef struct pfp_bwt_sizes {
+    uint64_t nout;   /* n + 1 outputs */
+    uint64_t r;      /* number of BWT runs (src/pfbwt-f.cpp:304-305) */
+    uint64_t easy_cases, hard_cases; /* pfbwt.hpp:188 statistics (single-word / multi-word groups) */
+} pfp_bwt_sizes;
+
+/* ---- context --------------------------------------------------------------------------------- */
+/* PfParser(PfParserParams) pfparser.hpp:82-84 + PrefixFreeBWT ctor pfbwt.hpp:64-81 (w only).
+ * device = HIP device ordinal; workspace_bytes = device arena size, 0 = sized on demand. */
+pfp_ctx *pfp_create(int w, uint64_t p, unsigned flags, int device, uint64_t workspace_bytes, int *status);
+void pfp_destroy(pfp_ctx *ctx);
+const char *pfp_strerror(int status);
+/* for PFP_E_INVALID_CHAR: text position and byte; for PFP_E_HIP: *ch = hipError_t */
+int pfp_error_detail(pfp_ctx *ctx, uint64_t *pos, int *ch);
+/* bytes of device workspace the last PFP_E_NOMEM call would have needed (estimate) */
+uint64_t pfp_workspace_needed(pfp_ctx *ctx);
+
+/* ---- stage 1: parse -------------------------------------------------------------------------- */
+/* PfParser::add_fasta inner loop, pfparser.hpp:335-352: append raw sequence bytes (host memory).
+ * end_of_seq != 0 closes the record: the w 'A's of :335-337 are appended.  Case folding, the
+ * optional non-ACGT->A mapping and the validity check of hash.hpp:30-31 happen on the device. */
+int pfp_parse_feed(pfp_ctx *ctx, const uint8_t *bases, uint64_t len, int end_of_seq);
+/* same, but the bytes are already in device memory (one record, pad appended by the library) */
+int pfp_parse_feed_device(pfp_ctx *ctx, const void *d_bases, uint64_t len, int end_of_seq);
+/* PfParser::finalize pfparser.hpp:484-517 (+ process_phrase :595-601 for every phrase): trigger scan,
+ * phrase de-duplication, dictionary sort, ranks, occ, last, sai.  Results stay on the device. */
+int pfp_parse_finalize(pfp_ctx *ctx, pfp_parse_sizes *out);
+/* save_parser pfbwt_io.hpp:234-249 getters: copy results to caller-owned host buffers (NULL skips).
+ * dict: dsize bytes (.dict image); occ: dwords U-wide; parse: m uint32 (1-based ranks);
+ * last: m bytes; sai: m U-wide (only with PFP_FLAG_SAI). */
+int pfp_parse_get(pfp_ctx *ctx, uint8_t *dict, void *occ, uint32_t *parse, uint8_t *last, void *sai);
+/* PfParser::bwt_of_parse pfparser.hpp:379-467 (sacak_int :425 included) */
+int pfp_parse_bwt(pfp_ctx *ctx);
+/* the three vectors handed to OutFn at pfparser.hpp:466: bwlast m+1 bytes, ilist / bwsai m+1 U-wide */
+int pfp_parse_bwt_get(pfp_ctx *ctx, uint8_t *bwlast, void *ilist, void *bwsai);
+
+/* ---- stage 2: BWT / SA ------------------------------------------------------------------------- */
+/* PrefixFreeBWT ctor pfbwt.hpp:64-81, for --pfbwt-only: upload .dict .occ .bwlast .ilist [.bwsai]
+ * images (host memory).  Not needed when pfp_parse_finalize + pfp_parse_bwt ran in this context.
+ * n_hint: the value of the .n file (src/pfbwt-f.cpp:282-285), sizes the workspace; 0 = unknown. */
+int pfp_bwt_load(pfp_ctx *ctx, const uint8_t *dict, uint64_t dsize, const void *occ, uint64_t dwords,
+                 const uint8_t *bwlast, const void *ilist, const void *bwsai, uint64_t nrows, uint64_t n_hint);
+/* PrefixFreeBWT::generate_bwt_lcp pfbwt.hpp:96-194 (sort_dict_suffixes :206-223 = gsacak included)
+ * fused with the CLI's out_fn src/pfbwt-f.cpp:298-328: BWT bytes, SA (row 0 := n), run samples. */
+int pfp_bwt_build(pfp_ctx *ctx, int want_sa, int want_rssa, pfp_bwt_sizes *out);
+/* copy results to host (NULL skips): bwt nout bytes; sa nout U-wide; ssa/esa 2*r U-wide each */
+int pfp_bwt_get(pfp_ctx *ctx, uint8_t *bwt, void *sa, void *ssa, void *esa);
+/* device pointers of the same results (valid until the next pfp_* call that rebuilds them) */
+int pfp_bwt_device_ptrs(pfp_ctx *ctx, const void **d_bwt, const void **d_sa, const void **d_ssa, const void **d_esa);
+
+/* ---- drop-ins for the suffix-sorting C ABI, gsa/gsacak.h:76-103 ------------------------------- */
+/* int sacak_int(int_text *s, uint_t *SA, uint_t n, uint_t k): s[n-1]==0, symbols < k.  Returns the
+ * number of refinement rounds (>= 1; the reference returns its recursion depth) or -1 on error. */
+int pfp_sacak_int_u32(const uint32_t *s, uint32_t *SA, uint32_t n, uint32_t k);
+int pfp_sacak_int_u64(const uint32_t *s, uint64_t *SA, uint64_t n, uint64_t k);
+
+/* ---- instrumentation ---------------------------------------------------------------------------- */
+/* per-kernel timing with hipEvents on the context's stream (off by default) */
+int pfp_profile_enable(pfp_ctx *ctx, int on);
+int pfp_profile_reset(pfp_ctx *ctx);
+/* idx-th record: kernel name, launches, total ms, algorithmic bytes; returns 0 or PFP_E_ARG past the end */
+int pfp_profile_get(pfp_ctx *ctx, int idx, const char **name, uint64_t *launches, double *ms, double *bytes);
+/* wall-clock milliseconds of the last call of each stage (host timer around a stream sync):
+ * [0] parse_finalize [1] parse_bwt [2] bwt_build */
+int pfp_stage_ms(pfp_ctx *ctx, double out[3]);
+/* library build info: "hip-gfx950" for the product library */
+const char *pfp_backend(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,176 @@
+// pfbwt-f_amd/csrc/common.h -- context, device arena, launch + profiling helpers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <chrono>
+#include <vector>
+#include "../../include/pfbwt_hip.h"
+
+namespace pfp {
+
+typedef uint32_t idx_t;           // device index type of this build: texts / dictionaries < 2^32
+
+constexpr int BLOCK = 256;        // 4 wave64 per workgroup
+constexpr int WAVE = 64;
+
+// Reference constants, include/utils.h:8-10
+constexpr uint8_t Dollar = 2, EndOfWord = 1, EndOfDict = 0;
+
+// ---- kernel ids for the profile table ----------------------------------------------------------
+enum KernelId {
+    K_TRIGGER_SCAN, K_PHRASE_ENDS, K_PHRASE_HASH, K_PHRASE_HASH_LONG, K_DEDUP_HEADS, K_DEDUP_LONG,
+    K_DICT_BUILD, K_RADIX_HIST, K_RADIX_SCATTER, K_SCAN_REDUCE, K_SCAN_SPINE, K_SCAN_APPLY,
+    K_SS_INIT_KEYS, K_SS_HEADS, K_SS_MAKE_KEYS, K_SS_WRITE_RANK, K_SS_FLAG_ACTIVE, K_COMPACT,
+    K_WORD_RANK, K_PARSE_RANKS, K_DICT_SORTED, K_PBWT_ROWS, K_EMIT_COUNT, K_EMIT, K_RUNS, K_SAMPLES, K_MISC,
+    K_COUNT_
+};
+static const char *const kernel_names[K_COUNT_] = {
+    "trigger_scan", "phrase_ends", "phrase_hash", "phrase_hash_long", "dedup_heads", "dedup_long",
+    "dict_build", "radix_hist", "radix_scatter", "scan_reduce", "scan_spine", "scan_apply",
+    "ss_init_keys", "ss_heads", "ss_make_keys", "ss_write_rank", "ss_flag_active", "compact",
+    "word_rank", "parse_ranks", "dict_sorted", "pbwt_rows", "emit_count", "emit", "runs", "samples", "misc"};
+
+struct ProfRec { uint64_t launches = 0; double ms = 0, bytes = 0; };
+
+// Two-ended bump allocator over one hipMalloc'd slab: results of a stage live at the low end,
+// scratch at the high end (released with mark/release).
+struct Arena {
+    char *base = nullptr;
+    size_t cap = 0, lo = 0, hi = 0, want = 0;
+    bool failed = false;
+    void reset() { lo = 0; hi = cap; failed = false; }
+    void *alloc_lo(size_t bytes)
+    {
+        size_t a = (lo + 255) & ~(size_t)255;
+        if (a + bytes > hi) { failed = true; want += bytes; return nullptr; }
+        lo = a + bytes; return base + a;
+    }
+    void *alloc_hi(size_t bytes)
+    {
+        size_t b = (bytes + 255) & ~(size_t)255;
+        if (b > hi || hi - b < lo) { failed = true; want += bytes; return nullptr; }
+        hi -= b; return base + hi;
+    }
+    size_t mark_hi() const { return hi; }
+    void release_hi(size_t m) { hi = m; }
+    size_t mark_lo() const { return lo; }
+    void release_lo(size_t m) { lo = m; }
+};
+
+} // namespace pfp
+
+struct pfp_ctx {
+    int w = 10; uint64_t p = 100; unsigned flags = 0; int device = 0;
+    hipStream_t stream = nullptr;
+    pfp::Arena arena;
+    size_t arena_request = 0;
+    // error detail
+    uint64_t err_pos = 0; int err_ch = 0;
+    // --- text staging (device): tb = 16 guard bytes (tb[15] = Dollar) + X + w Dollars + slack
+    uint8_t *tb = nullptr; size_t tb_cap = 0; uint64_t n = 0; bool text_in_arena = false;
+    // --- parse results (device, arena low end)
+    int stage = 0;             // 0 feeding, 1 parsed, 2 parse-bwt done
+    uint64_t m = 0, dwords = 0, dsize = 0;
+    uint32_t *d_ye = nullptr;       // m: Y-coordinate of each phrase's last byte (= sai)
+    uint32_t *d_pid = nullptr;      // m: phrase -> dictionary word id (D' order)
+    uint32_t *d_parse = nullptr;    // m: 1-based ranks
+    uint8_t *d_last = nullptr;      // m
+    uint8_t *d_dict = nullptr;      // D': dictionary in word-id order (dsize bytes)
+    uint32_t *d_ws = nullptr;       // dwords+1 word starts in D'
+    uint32_t *d_wordid = nullptr;   // dsize: word id of each D' offset
+    uint32_t *d_wrank = nullptr;    // dwords: word id -> 0-based rank (nullptr: identity)
+    uint32_t *d_occ = nullptr;      // dwords, by rank
+    uint8_t *d_sdict = nullptr;     // sorted .dict image (dsize), by rank
+    uint32_t *d_gsa = nullptr;      // dsize: suffix array of D'
+    uint32_t *d_grank = nullptr;    // dsize: class-head slot of each D' offset
+    bool gsa_valid = false;
+    // --- parse-BWT results
+    uint64_t nrows = 0;
+    uint8_t *d_bwlast = nullptr; uint32_t *d_ilist = nullptr; uint32_t *d_bwsai = nullptr;
+    // --- BWT results
+    uint64_t nout = 0, runs = 0, easy = 0, hard = 0;
+    uint8_t *d_bwt = nullptr; void *d_sa = nullptr; void *d_ssa = nullptr; void *d_esa = nullptr;
+    bool have_sa = false, have_rssa = false;
+    size_t lo_after_parse = 0, lo_after_pbwt = 0;
+    // --- instrumentation
+    bool prof_on = false;
+    pfp::ProfRec prof[pfp::K_COUNT_];
+    struct PendingEv { hipEvent_t a, b; int id; double bytes; };
+    std::vector<PendingEv> pending;
+    std::vector<hipEvent_t> ev_pool;
+    double stage_ms[3] = {0, 0, 0};
+    int hip_err = 0;
+    uint64_t hash_seed = 0x9E3779B97F4A7C15ULL;
+};
+
+namespace pfp {
+
+inline hipEvent_t ev_get(pfp_ctx *c)
+{
+    if (!c->ev_pool.empty()) { hipEvent_t e = c->ev_pool.back(); c->ev_pool.pop_back(); return e; }
+    hipEvent_t e; (void)hipEventCreate(&e); return e;
+}
+inline void prof_collect(pfp_ctx *c)
+{
+    if (c->pending.empty()) return;
+    (void)hipStreamSynchronize(c->stream);
+    for (auto &pe : c->pending) {
+        float ms = 0; (void)hipEventElapsedTime(&ms, pe.a, pe.b);
+        c->prof[pe.id].launches++; c->prof[pe.id].ms += ms; c->prof[pe.id].bytes += pe.bytes;
+        c->ev_pool.push_back(pe.a); c->ev_pool.push_back(pe.b);
+    }
+    c->pending.clear();
+}
+struct ProfScope {
+    pfp_ctx *c; int id; double bytes; hipEvent_t a = nullptr;
+    ProfScope(pfp_ctx *c_, int id_, double bytes_) : c(c_), id(id_), bytes(bytes_)
+    {
+        if (c->prof_on) { a = ev_get(c); (void)hipEventRecord(a, c->stream); }
+    }
+    ~ProfScope()
+    {
+        if (c->prof_on) {
+            hipEvent_t b = ev_get(c); (void)hipEventRecord(b, c->stream);
+            c->pending.push_back({a, b, id, bytes});
+            if (c->pending.size() > 4096) prof_collect(c);
+        }
+    }
+};
+
+// LAUNCH(ctx, kernel-id, algorithmic bytes, kernel, grid, args...)
+#define PFP_LAUNCH(ctx, id, bytes, kernel, grid, ...)                                             \
+    do {                                                                                          \
+        pfp::ProfScope ps_((ctx), (id), (double)(bytes));                                         \
+        hipLaunchKernelGGL(kernel, dim3((unsigned)(grid)), dim3(pfp::BLOCK), 0, (ctx)->stream, __VA_ARGS__); \
+    } while (0)
+
+#define PFP_HIP(ctx, expr)                                                                        \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) { (ctx)->hip_err = (int)e_; (ctx)->err_ch = (int)e_;                \
+            fprintf(stderr, "[pfbwt_hip] %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return PFP_E_HIP; }                                                                   \
+    } while (0)
+
+#define PFP_TRY(expr) do { int rc_ = (expr); if (rc_ != PFP_OK) return rc_; } while (0)
+
+// typed arena allocation; on exhaustion the enclosing function returns PFP_E_NOMEM
+#define PFP_ALLOC_HI(ctx, ptr, T, count)                                                          \
+    do { (ptr) = (T *)(ctx)->arena.alloc_hi(sizeof(T) * (size_t)((count) ? (count) : 1));         \
+         if (!(ptr)) return PFP_E_NOMEM; } while (0)
+#define PFP_ALLOC_LO(ctx, ptr, T, count)                                                          \
+    do { (ptr) = (T *)(ctx)->arena.alloc_lo(sizeof(T) * (size_t)((count) ? (count) : 1));         \
+         if (!(ptr)) return PFP_E_NOMEM; } while (0)
+
+inline unsigned nblocks(uint64_t items, uint64_t per_block) { return (unsigned)((items + per_block - 1) / per_block); }
+inline int bits_for(uint64_t maxval) { int b = 1; while (b < 64 && (maxval >> b)) ++b; return b; }
+
+struct HostTimer {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    double ms() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
+} // namespace pfp

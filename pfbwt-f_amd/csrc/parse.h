@@ -1,0 +1,299 @@
+// pfbwt-f_amd/csrc/parse.h -- stage 1 on the device: trigger scan, phrase ends, phrase
+// fingerprints, de-duplication, dictionary build.
+//
+// Replaces (reference file:line): WangHash::update include/hash.hpp:29-35, wang_hash :12-21, the
+// per-base loop of PfParser::add_fasta include/pfparser.hpp:335-352, process_phrase :595-601 and the
+// std::map dictionary :69-70.  Text layout in HBM: `tb` = 16 guard bytes + X + w Dollars; Y = tb+15
+// is the "decorated text" (Y[0] = Dollar, Y[1+i] = X[i], Y[n+1..n+w] = Dollar): phrase j is the byte
+// range Y[ys_j .. ye_j] with ys_0 = 0, ys_j = ye_{j-1} - w + 1, so the Dollar of the first phrase and
+// the w Dollars of the last one (pfparser.hpp:315-318, 484-489) need no special cases.
+#pragma once
+#include "prims.h"
+
+namespace pfp {
+
+// include/hash.hpp:12-21
+__device__ __forceinline__ uint64_t wang_hash(uint64_t key)
+{
+    key = (~key) + (key << 21);
+    key = key ^ (key >> 24);
+    key = (key + (key << 3)) + (key << 8);
+    key = key ^ (key >> 14);
+    key = (key + (key << 2)) + (key << 4);
+    key = key ^ (key >> 28);
+    key = key + (key << 31);
+    return key;
+}
+
+// toupper + optional non-ACGT->A (pfparser.hpp:337-344); idempotent by construction
+__device__ __forceinline__ uint32_t norm_base(uint32_t c, bool ntoa)
+{
+    if (c >= 'a' && c <= 'z') c -= 32;
+    if (ntoa && !(c == 'A' || c == 'C' || c == 'G' || c == 'T')) c = 'A';
+    return c;
+}
+// seq_nt4_ntoa_table, src/utils.c:139-161 (after toupper): A,N->0 C->1 G->2 T,'-'->3 else 5
+__device__ __forceinline__ uint32_t ntoa_code(uint32_t c)
+{
+    return (c == 'A' || c == 'N') ? 0u : (c == 'C') ? 1u : (c == 'G') ? 2u : (c == 'T' || c == '-') ? 3u : 5u;
+}
+
+__device__ __forceinline__ uint32_t pack16(const uint4 &q, bool ntoa, uint32_t *bad /*bitmask of invalid bytes*/, uint4 *normed)
+{
+    uint32_t wds[4] = {q.x, q.y, q.z, q.w}, out[4], pk = 0, badm = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint32_t o = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            uint32_t c = norm_base((wds[i] >> (8 * b)) & 0xff, ntoa);
+            uint32_t code = ntoa_code(c);
+            if (code > 3) { badm |= 1u << (i * 4 + b); code = 0; }
+            pk = (pk << 2) | code;
+            o |= c << (8 * b);
+        }
+        out[i] = o;
+    }
+    *bad = badm;
+    if (normed) *normed = make_uint4(out[0], out[1], out[2], out[3]);
+    return pk;
+}
+
+// One thread = 16 consecutive bases (one 16-byte load).  Writes the normalised bytes back, one
+// 16-bit trigger mask per thread and the trigger count of the workgroup.
+// X must be 16-byte aligned with capacity rounded up to the grid; positions >= n are ignored.
+__global__ __launch_bounds__(BLOCK) void k_trigger_scan(uint8_t *X, uint64_t n, int w, uint64_t p, uint64_t kmask, int ntoa,
+                                                        uint16_t *mask16, uint32_t *blockcnt, unsigned long long *err_pos)
+{
+    __shared__ uint32_t pk[BLOCK + 2];
+    __shared__ uint32_t red[4];
+    const uint64_t t = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const uint64_t base = t * 16;
+    uint4 q = make_uint4(0, 0, 0, 0), nq;
+    uint32_t bad = 0;
+    if (base < n) q = *reinterpret_cast<const uint4 *>(X + base);
+    const uint32_t mine = pack16(q, ntoa != 0, &bad, &nq);
+    if (base < n) {
+        const uint32_t live = (n - base >= 16) ? 0xffffu : ((1u << (unsigned)(n - base)) - 1u);
+        if (live != 0xffffu) { // keep bytes beyond n untouched
+            uint32_t a[4] = {q.x, q.y, q.z, q.w}, b[4] = {nq.x, nq.y, nq.z, nq.w};
+            for (int i = 0; i < 16; ++i) if (!((live >> i) & 1)) { b[i >> 2] = (b[i >> 2] & ~(0xffu << (8 * (i & 3)))) | (a[i >> 2] & (0xffu << (8 * (i & 3)))); }
+            nq = make_uint4(b[0], b[1], b[2], b[3]);
+        }
+        *reinterpret_cast<uint4 *>(X + base) = nq;
+        bad &= live;
+        if (bad) atomicMin(err_pos, (unsigned long long)(base + (uint64_t)(__ffs((int)bad) - 1)));
+    }
+    pk[threadIdx.x + 2] = mine;
+    if (threadIdx.x < 2) { // halo: the 32 bases in front of the workgroup's first base
+        const uint64_t first = (uint64_t)blockIdx.x * BLOCK; // in units of 16 bases
+        uint32_t hv = 0;
+        if (first + threadIdx.x >= 2) {
+            uint32_t hb;
+            uint4 hq = *reinterpret_cast<const uint4 *>(X + (first + threadIdx.x - 2) * 16);
+            hv = pack16(hq, ntoa != 0, &hb, nullptr);
+        }
+        pk[threadIdx.x] = hv;
+    }
+    __syncthreads();
+    uint64_t kmer = ((uint64_t)pk[threadIdx.x] << 32) | pk[threadIdx.x + 1];
+    uint32_t trig = 0;
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+        kmer = (kmer << 2) | ((mine >> (30 - 2 * b)) & 3u);       // hash.hpp:32
+        const uint64_t pos = base + b;
+        const uint64_t h = wang_hash(kmer & kmask);
+        // pfparser.hpp:347: pos_ > w  <=>  pos >= w (pos_ = pos + 1 at the test)
+        if (pos < n && pos >= (uint64_t)w && (h % p) == 0) trig |= 1u << b;
+    }
+    mask16[t] = (uint16_t)trig;
+    uint32_t tot;
+    (void)block_excl_sum((uint32_t)__popc(trig), red, &tot);
+    if (threadIdx.x == 0) blockcnt[blockIdx.x] = tot;
+}
+
+// ye[j] = (trigger position e_j) + 1 for every trigger, in text order
+__global__ __launch_bounds__(BLOCK) void k_phrase_ends(const uint16_t *mask16, const uint32_t *blockoff, uint32_t *ye)
+{
+    __shared__ uint32_t red[4];
+    const uint64_t t = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    uint32_t m = mask16[t], tot;
+    uint32_t o = blockoff[blockIdx.x] + block_excl_sum((uint32_t)__popc(m), red, &tot);
+    while (m) { int b = __ffs((int)m) - 1; m &= m - 1; ye[o++] = (uint32_t)(t * 16 + b + 1); }
+}
+
+// ---- phrase fingerprints: polynomial hash modulo the Mersenne prime 2^61-1 ---------------------
+constexpr uint64_t P61 = (1ULL << 61) - 1;
+__host__ __device__ __forceinline__ uint64_t mulmod61(uint64_t a, uint64_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint64_t hi = __umul64hi(a, b);
+#else
+    const uint64_t hi = (uint64_t)(((unsigned __int128)a * b) >> 64);
+#endif
+    const uint64_t lo = a * b;
+    uint64_t r = (lo & P61) + ((lo >> 61) | (hi << 3));
+    r = (r & P61) + (r >> 61);
+    return r >= P61 ? r - P61 : r;
+}
+__host__ __device__ __forceinline__ uint64_t addmod61(uint64_t a, uint64_t b) { uint64_t r = a + b; return r >= P61 ? r - P61 : r; }
+__host__ __device__ __forceinline__ uint64_t powmod61(uint64_t b, uint64_t e)
+{
+    uint64_t r = 1;
+    while (e) { if (e & 1) r = mulmod61(r, b); b = mulmod61(b, b); e >>= 1; }
+    return r;
+}
+
+__device__ __forceinline__ void phrase_span(const uint32_t *ye, uint64_t j, int w, uint32_t *ys, uint32_t *len)
+{
+    const uint32_t s = j ? ye[j - 1] - (uint32_t)w + 1u : 0u;
+    *ys = s; *len = ye[j] - s + 1u;
+}
+
+constexpr uint32_t LONG_PHRASE = 2048; // phrases longer than this go to the workgroup-per-phrase kernels
+
+// one thread per phrase
+__global__ __launch_bounds__(BLOCK) void k_phrase_hash(const uint8_t *Y, const uint32_t *ye, uint64_t m, int w, uint64_t B,
+                                                       uint64_t *keys, uint32_t *vals, uint32_t *longlist, uint32_t *nlong)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (j >= m) return;
+    uint32_t ys, len; phrase_span(ye, j, w, &ys, &len);
+    vals[j] = (uint32_t)j;
+    if (len > LONG_PHRASE) { longlist[atomicAdd(nlong, 1u)] = (uint32_t)j; keys[j] = 0; return; }
+    uint64_t h = 0;
+    const uint8_t *s = Y + ys;
+    for (uint32_t i = 0; i < len; ++i) h = addmod61(mulmod61(h, B), s[i]);
+    keys[j] = addmod61(mulmod61(h, B), len % P61);
+}
+
+// one workgroup per long phrase: every thread hashes one chunk, thread 0 folds the chunks
+__global__ __launch_bounds__(BLOCK) void k_phrase_hash_long(const uint8_t *Y, const uint32_t *ye, int w, uint64_t B,
+                                                            const uint32_t *longlist, uint64_t *keys)
+{
+    __shared__ uint64_t part[BLOCK];
+    const uint32_t j = longlist[blockIdx.x];
+    uint32_t ys, len; phrase_span(ye, j, w, &ys, &len);
+    const uint32_t chunk = (len + BLOCK - 1) / BLOCK;
+    const uint32_t a = threadIdx.x * chunk, b = (a + chunk < len) ? a + chunk : len;
+    uint64_t h = 0;
+    for (uint32_t i = a; i < b; ++i) h = addmod61(mulmod61(h, B), Y[ys + i]);
+    part[threadIdx.x] = h;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint64_t Bc = powmod61(B, chunk);
+        uint64_t acc = 0;
+        for (uint32_t t = 0; t < BLOCK; ++t) {
+            const uint32_t ta = t * chunk; if (ta >= len) break;
+            const uint32_t tl = (ta + chunk < len ? ta + chunk : len) - ta;
+            acc = addmod61(mulmod61(acc, tl == chunk ? Bc : powmod61(B, tl)), part[t]);
+        }
+        keys[j] = addmod61(mulmod61(acc, B), len % P61);
+    }
+}
+
+// After sorting (key, j): head[i] = 1 where a new distinct phrase starts.  Equal fingerprints are
+// verified byte-for-byte against the predecessor; a mismatch (fingerprint collision) raises *collide.
+__global__ __launch_bounds__(BLOCK) void k_dedup_heads(const uint8_t *Y, const uint32_t *ye, int w, const uint64_t *keys, const uint32_t *vals,
+                                                       uint64_t m, uint32_t *head, uint32_t *longpairs, uint32_t *nlongpairs, uint32_t *collide)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= m) return;
+    if (i == 0 || keys[i] != keys[i - 1]) { head[i] = 1; return; }
+    uint32_t sa_, la, sb, lb;
+    phrase_span(ye, vals[i - 1], w, &sa_, &la);
+    phrase_span(ye, vals[i], w, &sb, &lb);
+    if (la != lb) { head[i] = 1; atomicAdd(collide, 1u); return; }
+    if (la > LONG_PHRASE) { head[i] = 0; longpairs[atomicAdd(nlongpairs, 1u)] = (uint32_t)i; return; }
+    const uint8_t *a = Y + sa_, *b = Y + sb;
+    uint32_t diff = 0;
+    for (uint32_t k = 0; k < la; ++k) diff |= (uint32_t)(a[k] ^ b[k]);
+    head[i] = 0;
+    if (diff) { head[i] = 1; atomicAdd(collide, 1u); }
+}
+__global__ __launch_bounds__(BLOCK) void k_dedup_long(const uint8_t *Y, const uint32_t *ye, int w, const uint32_t *vals,
+                                                      const uint32_t *longpairs, uint32_t *collide)
+{
+    const uint32_t i = longpairs[blockIdx.x];
+    uint32_t sa_, la, sb, lb;
+    phrase_span(ye, vals[i - 1], w, &sa_, &la);
+    phrase_span(ye, vals[i], w, &sb, &lb);
+    uint32_t diff = 0;
+    for (uint32_t k = threadIdx.x; k < la; k += BLOCK) diff |= (uint32_t)(Y[sa_ + k] ^ Y[sb + k]);
+    if (diff) atomicAdd(collide, 1u);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_dedup_ids(const uint32_t *head, uint32_t *ex, uint64_t m)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < m) ex[i] = ex[i] + head[i] - 1u;
+}
+// per sorted slot i: id[i] = (inclusive scan of head) - 1 is already in `ids`.  Scatter the word table.
+__global__ __launch_bounds__(BLOCK) void k_dedup_scatter(const uint32_t *vals, const uint32_t *head, const uint32_t *ids, uint64_t m,
+                                                         uint32_t *pid, uint32_t *rep, uint32_t *headpos)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= m) return;
+    const uint32_t id = ids[i];
+    pid[vals[i]] = id;
+    if (head[i]) { rep[id] = vals[i]; headpos[id] = (uint32_t)i; }
+}
+// wlen1[id] = phrase length + 1 (EndOfWord); occ'[id] = class size
+__global__ __launch_bounds__(BLOCK) void k_word_lengths(const uint32_t *ye, int w, const uint32_t *rep, const uint32_t *headpos, uint64_t dwords, uint64_t m,
+                                                        uint32_t *wlen1, uint32_t *occw)
+{
+    const uint64_t id = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (id >= dwords) return;
+    uint32_t ys, len; phrase_span(ye, rep[id], w, &ys, &len);
+    wlen1[id] = len + 1;
+    occw[id] = (id + 1 < dwords ? headpos[id + 1] : (uint32_t)m) - headpos[id];
+}
+
+__device__ __forceinline__ uint32_t upper_bound_u32(const uint32_t *a, uint32_t n, uint32_t x)
+{   // first index with a[idx] > x
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) { uint32_t mid = lo + ((hi - lo) >> 1); if (a[mid] <= x) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+// D' : words in id order, each followed by EndOfWord, then EndOfDict.  One thread = 16 output bytes.
+// srcstart[id] = Y offset of the word's first byte (or offset into another dictionary image).
+__global__ __launch_bounds__(BLOCK) void k_dict_build(const uint8_t *src, const uint32_t *srcstart, const uint32_t *ws, uint32_t dwords, uint64_t dsize,
+                                                      uint8_t *dict, uint32_t *wordid)
+{
+    const uint64_t x0 = ((uint64_t)blockIdx.x * BLOCK + threadIdx.x) * 16;
+    if (x0 >= dsize) return;
+    uint32_t id = upper_bound_u32(ws, dwords + 1, (uint32_t)x0) - 1; // ws[id] <= x0
+    for (uint64_t x = x0; x < x0 + 16 && x < dsize; ++x) {
+        while (id < dwords && x >= ws[id + 1]) ++id;
+        uint8_t c;
+        if (id >= dwords) c = EndOfDict;
+        else { const uint32_t off = (uint32_t)x - ws[id]; c = (x + 1 == ws[id + 1]) ? EndOfWord : src[srcstart[id] + off]; }
+        dict[x] = c;
+        if (wordid) wordid[x] = id;
+    }
+}
+__global__ __launch_bounds__(BLOCK) void k_rep_starts(const uint32_t *ye, int w, const uint32_t *rep, uint64_t dwords, uint32_t *srcstart)
+{
+    const uint64_t id = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (id >= dwords) return;
+    uint32_t ys, len; phrase_span(ye, rep[id], w, &ys, &len);
+    srcstart[id] = ys;
+}
+// last[j] = Y[ye[j] - w]   (pfparser.hpp:599)
+__global__ __launch_bounds__(BLOCK) void k_last_chars(const uint8_t *Y, const uint32_t *ye, uint64_t m, int w, uint8_t *last)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (j < m) last[j] = Y[ye[j] - (uint32_t)w];
+}
+__global__ __launch_bounds__(BLOCK) void k_fill_u8(uint8_t *p, uint64_t n, uint8_t v)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+__global__ __launch_bounds__(BLOCK) void k_set_u32(uint32_t *p, uint64_t idx, uint32_t v)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) p[idx] = v;
+}
+
+} // namespace pfp

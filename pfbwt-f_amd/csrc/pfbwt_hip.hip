@@ -1,0 +1,569 @@
+// pfbwt-f_amd/csrc/pfbwt_hip.hip -- the C ABI of include/pfbwt_hip.h: host orchestration of the
+// gfx950 kernels in parse.h / sufsort.h / emit.h / prims.h.  Built by hipcc into
+// pfbwt-f_amd/lib/libpfbwt_hip.so.  There is no CPU fallback in this library.
+#include "common.h"
+#include "prims.h"
+#include "parse.h"
+#include "sufsort.h"
+#include "emit.h"
+
+using namespace pfp;
+
+#ifndef PFP_BACKEND_NAME
+#define PFP_BACKEND_NAME "hip-gfx950"
+#endif
+
+// -------------------------------------------------------------------------------------------------
+static int ensure_arena(pfp_ctx *c, uint64_t n_hint)
+{
+    size_t want = c->arena_request ? c->arena_request : (size_t)(96ULL * n_hint + (64ULL << 20));
+    if (c->arena.base && c->arena.cap >= want) return PFP_OK;
+    if (c->arena.base) { PFP_HIP(c, hipStreamSynchronize(c->stream)); PFP_HIP(c, hipFree(c->arena.base)); c->arena.base = nullptr; c->arena.cap = 0; }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) { c->arena.want = want; (void)hipGetLastError(); return PFP_E_NOMEM; }
+    c->arena.base = (char *)p; c->arena.cap = want; c->arena.reset();
+    return PFP_OK;
+}
+
+static int ensure_text(pfp_ctx *c, uint64_t need_n)
+{
+    // capacity: 16 guard bytes + text rounded up to whole trigger-scan tiles + w Dollars + slack
+    size_t need = 16 + (((size_t)need_n + 4095) / 4096) * 4096 + 4096 + 64;
+    if (c->tb && c->tb_cap >= need) return PFP_OK;
+    size_t cap = c->tb_cap ? c->tb_cap : (size_t)1 << 20;
+    while (cap < need) cap *= 2;
+    uint8_t *nb = nullptr;
+    hipError_t e = hipMalloc((void **)&nb, cap);
+    if (e != hipSuccess) { (void)hipGetLastError(); return PFP_E_NOMEM; }
+    if (c->tb) {
+        PFP_HIP(c, hipMemcpyAsync(nb, c->tb, 16 + (size_t)c->n, hipMemcpyDeviceToDevice, c->stream));
+        PFP_HIP(c, hipStreamSynchronize(c->stream));
+        PFP_HIP(c, hipFree(c->tb));
+    }
+    c->tb = nb; c->tb_cap = cap;
+    return PFP_OK;
+}
+
+static void reset_results(pfp_ctx *c)
+{
+    c->stage = 0; c->n = 0; c->m = c->dwords = c->dsize = 0; c->nrows = 0; c->nout = c->runs = 0;
+    c->gsa_valid = false; c->d_wrank = nullptr; c->d_bwt = nullptr; c->d_sa = c->d_ssa = c->d_esa = nullptr;
+    c->d_bwlast = nullptr; c->d_ilist = nullptr; c->d_bwsai = nullptr;
+    c->arena.reset();
+}
+
+extern "C" {
+
+const char *pfp_backend(void) { return PFP_BACKEND_NAME; }
+
+const char *pfp_strerror(int s)
+{
+    switch (s) {
+    case PFP_OK: return "ok";
+    case PFP_E_ARG: return "invalid argument";
+    case PFP_E_INVALID_CHAR: return "error, invalid character";
+    case PFP_E_TOO_LARGE: return "input too long for 32-bit device indices";
+    case PFP_E_NOMEM: return "device workspace exhausted";
+    case PFP_E_HIP: return "HIP runtime error";
+    case PFP_E_ONE_WORD: return "error: only one dict word total. Re-run with a smaller p modulus";
+    case PFP_E_STATE: return "call order violated";
+    case PFP_E_CORRUPT: return "something went wrong!";
+    default: return "unknown status";
+    }
+}
+
+pfp_ctx *pfp_create(int w, uint64_t p, unsigned flags, int device, uint64_t workspace_bytes, int *status)
+{
+    int st = PFP_OK;
+    pfp_ctx *c = nullptr;
+    if (w < 1 || w > 32 || p == 0) st = PFP_E_ARG;           // check_w, pfparser.hpp:371-376
+    else {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) st = PFP_E_HIP;
+        else if (hipSetDevice(device) != hipSuccess) st = PFP_E_HIP;
+        else {
+            c = new pfp_ctx();
+            c->w = w; c->p = p; c->flags = flags; c->device = device; c->arena_request = (size_t)workspace_bytes;
+            if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; c = nullptr; st = PFP_E_HIP; }
+        }
+    }
+    if (status) *status = st;
+    return c;
+}
+
+void pfp_destroy(pfp_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    prof_collect(c);
+    for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->tb) (void)hipFree(c->tb);
+    if (c->arena.base) (void)hipFree(c->arena.base);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int pfp_error_detail(pfp_ctx *c, uint64_t *pos, int *ch)
+{
+    if (!c) return PFP_E_ARG;
+    if (pos) *pos = c->err_pos;
+    if (ch) *ch = c->err_ch;
+    return PFP_OK;
+}
+uint64_t pfp_workspace_needed(pfp_ctx *c) { return c ? (uint64_t)(c->arena.cap + c->arena.want) : 0; }
+
+int pfp_profile_enable(pfp_ctx *c, int on) { if (!c) return PFP_E_ARG; prof_collect(c); c->prof_on = on != 0; return PFP_OK; }
+int pfp_profile_reset(pfp_ctx *c) { if (!c) return PFP_E_ARG; prof_collect(c); for (auto &r : c->prof) r = ProfRec(); return PFP_OK; }
+int pfp_profile_get(pfp_ctx *c, int idx, const char **name, uint64_t *launches, double *ms, double *bytes)
+{
+    if (!c || idx < 0 || idx >= K_COUNT_) return PFP_E_ARG;
+    prof_collect(c);
+    if (name) *name = kernel_names[idx];
+    if (launches) *launches = c->prof[idx].launches;
+    if (ms) *ms = c->prof[idx].ms;
+    if (bytes) *bytes = c->prof[idx].bytes;
+    return PFP_OK;
+}
+int pfp_stage_ms(pfp_ctx *c, double out[3]) { if (!c || !out) return PFP_E_ARG; for (int i = 0; i < 3; ++i) out[i] = c->stage_ms[i]; return PFP_OK; }
+
+// ---- stage 1: feeding ---------------------------------------------------------------------------
+static int feed_common(pfp_ctx *c, const void *src, uint64_t len, int end_of_seq, hipMemcpyKind kind)
+{
+    if (!c || (!src && len)) return PFP_E_ARG;
+    PFP_HIP(c, hipSetDevice(c->device));
+    if (c->stage != 0) reset_results(c);
+    const uint64_t add = len + (end_of_seq ? (uint64_t)c->w : 0);
+    if (c->n + add + (uint64_t)c->w + 64 >= 0xFFFFFFFFULL) return PFP_E_TOO_LARGE;   // pfparser.hpp:326-331
+    PFP_TRY(ensure_text(c, c->n + add + (uint64_t)c->w));
+    if (len) PFP_HIP(c, hipMemcpyAsync(c->tb + 16 + c->n, src, (size_t)len, kind, c->stream));
+    c->n += len;
+    if (end_of_seq) {   // the w 'A's of pfparser.hpp:335-337
+        PFP_HIP(c, hipMemsetAsync(c->tb + 16 + c->n, 'A', (size_t)c->w, c->stream));
+        c->n += (uint64_t)c->w;
+    }
+    if (kind == hipMemcpyHostToDevice) PFP_HIP(c, hipStreamSynchronize(c->stream)); // caller may reuse its buffer
+    return PFP_OK;
+}
+int pfp_parse_feed(pfp_ctx *c, const uint8_t *bases, uint64_t len, int end_of_seq) { return feed_common(c, bases, len, end_of_seq, hipMemcpyHostToDevice); }
+int pfp_parse_feed_device(pfp_ctx *c, const void *d_bases, uint64_t len, int end_of_seq) { return feed_common(c, d_bases, len, end_of_seq, hipMemcpyDeviceToDevice); }
+
+// ---- dictionary suffix sort (shared by the parse and the --pfbwt-only path) ---------------------
+static int sort_dict_suffixes(pfp_ctx *c)
+{
+    const uint64_t N = c->dsize;
+    const size_t mk = c->arena.mark_hi();
+    uint64_t *k0, *k1; uint32_t *v0, *v1;
+    PFP_ALLOC_LO(c, c->d_gsa, uint32_t, N);
+    PFP_ALLOC_LO(c, c->d_grank, uint32_t, N);
+    PFP_ALLOC_HI(c, k0, uint64_t, N); PFP_ALLOC_HI(c, k1, uint64_t, N);
+    PFP_ALLOC_HI(c, v0, uint32_t, N); PFP_ALLOC_HI(c, v1, uint32_t, N);
+    PFP_LAUNCH(c, K_SS_INIT_KEYS, N * 13, k_dict_init_keys, nblocks(N, DK_TILE), (const uint8_t *)c->d_dict, N, k0, v0);
+    BitRange full = {0, 64};
+    int rounds = 0;
+    PFP_TRY(suffix_sort_doubling(c, N, k0, v0, k1, v1, &full, 1, DK_CHARS, c->d_ws, c->d_wordid, c->d_gsa, c->d_grank, &rounds));
+    c->arena.release_hi(mk);
+    c->gsa_valid = true;
+    return PFP_OK;
+}
+
+int pfp_parse_finalize(pfp_ctx *c, pfp_parse_sizes *out)
+{
+    if (!c) return PFP_E_ARG;
+    if (c->stage != 0) return PFP_E_STATE;
+    if (c->n == 0) return PFP_E_ARG;
+    PFP_HIP(c, hipSetDevice(c->device));
+    HostTimer timer;
+    const uint64_t n = c->n; const int w = c->w;
+    PFP_TRY(ensure_arena(c, n));
+    c->arena.reset();
+    uint8_t *X = c->tb + 16; const uint8_t *Y = c->tb + 15;
+    // Dollar in front, w Dollars behind (pfparser.hpp:315-318, 484-489)
+    PFP_HIP(c, hipMemsetAsync(c->tb, Dollar, 16, c->stream));
+    PFP_HIP(c, hipMemsetAsync(X + n, Dollar, (size_t)w, c->stream));
+    const size_t mk = c->arena.mark_hi();
+
+    // 1. trigger scan
+    const unsigned gts = nblocks(n, 16 * BLOCK);
+    uint16_t *mask16; uint32_t *blockcnt, *d_u32; unsigned long long *d_err;
+    PFP_ALLOC_HI(c, mask16, uint16_t, (size_t)gts * BLOCK);
+    PFP_ALLOC_HI(c, blockcnt, uint32_t, gts);
+    PFP_ALLOC_HI(c, d_u32, uint32_t, 8);
+    PFP_ALLOC_HI(c, d_err, unsigned long long, 1);
+    PFP_HIP(c, hipMemsetAsync(d_err, 0xff, 8, c->stream));
+    PFP_HIP(c, hipMemsetAsync(d_u32, 0, 32, c->stream));
+    const uint64_t kmask = (w == 32) ? 0ULL : ((1ULL << (2 * w)) - 1ULL);   // hash.hpp:26 (w == 32: observed x86 value)
+    PFP_LAUNCH(c, K_TRIGGER_SCAN, n * 2 + n / 8, k_trigger_scan, gts, X, n, w, c->p, kmask, (int)((c->flags & PFP_FLAG_NON_ACGT_TO_A) != 0), mask16, blockcnt, d_err);
+    PFP_TRY((device_scan<uint32_t, 0>(c, blockcnt, blockcnt, gts, d_u32)));
+    uint32_t ntrig = 0; unsigned long long herr = 0;
+    PFP_HIP(c, hipMemcpyAsync(&herr, d_err, 8, hipMemcpyDeviceToHost, c->stream));
+    PFP_TRY(d2h_u32(c, d_u32, &ntrig));
+    if (herr != ~0ULL) {   // hash.hpp:31
+        uint8_t ch = 0;
+        PFP_HIP(c, hipMemcpy(&ch, X + herr, 1, hipMemcpyDeviceToHost));
+        c->err_pos = herr; c->err_ch = ch;
+        return PFP_E_INVALID_CHAR;
+    }
+    const uint64_t m = (uint64_t)ntrig + 1;
+    c->m = m;
+    PFP_ALLOC_LO(c, c->d_ye, uint32_t, m);
+    PFP_LAUNCH(c, K_PHRASE_ENDS, n / 8 + m * 4, k_phrase_ends, gts, (const uint16_t *)mask16, (const uint32_t *)blockcnt, c->d_ye);
+    PFP_LAUNCH(c, K_MISC, 4, k_set_u32, 1, c->d_ye, m - 1, (uint32_t)(n + (uint64_t)w));
+
+    // 2. fingerprints, sort, verified de-duplication
+    uint64_t *hk0, *hk1; uint32_t *hv0, *hv1, *longlist, *head, *ex, *longpairs;
+    PFP_ALLOC_HI(c, hk0, uint64_t, m); PFP_ALLOC_HI(c, hk1, uint64_t, m);
+    PFP_ALLOC_HI(c, hv0, uint32_t, m); PFP_ALLOC_HI(c, hv1, uint32_t, m);
+    const uint64_t maxlong = (n + w + 1) / LONG_PHRASE + 2;
+    PFP_ALLOC_HI(c, longlist, uint32_t, maxlong);
+    PFP_ALLOC_HI(c, longpairs, uint32_t, maxlong);
+    PFP_ALLOC_HI(c, head, uint32_t, m);
+    PFP_ALLOC_HI(c, ex, uint32_t, m);
+    uint64_t *sk = nullptr; uint32_t *sv = nullptr;
+    const unsigned gm = nblocks(m, BLOCK);
+    for (int attempt = 0;; ++attempt) {
+        if (attempt == 8) return PFP_E_CORRUPT;
+        // multiplier in [2^32, P61): a fresh one per attempt
+        uint64_t B = (c->hash_seed + 0x9E3779B97F4A7C15ULL * (uint64_t)(attempt + 1));
+        B ^= B >> 31; B *= 0xD6E8FEB86659FD93ULL; B ^= B >> 29;
+        B = (B % (P61 - (1ULL << 32))) + (1ULL << 32);
+        PFP_HIP(c, hipMemsetAsync(d_u32, 0, 32, c->stream));
+        PFP_LAUNCH(c, K_PHRASE_HASH, n + m * 12, k_phrase_hash, gm, Y, (const uint32_t *)c->d_ye, m, w, B, hk0, hv0, longlist, d_u32 + 1);
+        uint32_t nlong = 0; PFP_TRY(d2h_u32(c, d_u32 + 1, &nlong));
+        if (nlong) PFP_LAUNCH(c, K_PHRASE_HASH_LONG, 0, k_phrase_hash_long, nlong, Y, (const uint32_t *)c->d_ye, w, B, (const uint32_t *)longlist, hk0);
+        BitRange full = {0, 64};
+        PFP_TRY(radix_sort_pairs<uint64_t>(c, hk0, hv0, hk1, hv1, m, &full, 1, &sk, &sv));
+        PFP_LAUNCH(c, K_DEDUP_HEADS, n + m * 16, k_dedup_heads, gm, Y, (const uint32_t *)c->d_ye, w, (const uint64_t *)sk, (const uint32_t *)sv, m, head, longpairs, d_u32 + 2, d_u32 + 3);
+        uint32_t nlp = 0; PFP_TRY(d2h_u32(c, d_u32 + 2, &nlp));
+        if (nlp) PFP_LAUNCH(c, K_DEDUP_LONG, 0, k_dedup_long, nlp, Y, (const uint32_t *)c->d_ye, w, (const uint32_t *)sv, (const uint32_t *)longpairs, d_u32 + 3);
+        uint32_t collide = 0; PFP_TRY(d2h_u32(c, d_u32 + 3, &collide));
+        if (!collide) break;
+    }
+    PFP_TRY((device_scan<uint32_t, 0>(c, head, ex, m, d_u32 + 4)));
+    uint32_t dw32 = 0; PFP_TRY(d2h_u32(c, d_u32 + 4, &dw32));
+    const uint64_t dwords = dw32; c->dwords = dwords;
+    uint32_t *rep, *headpos, *wlen1, *occw, *srcstart;
+    PFP_ALLOC_LO(c, c->d_pid, uint32_t, m);
+    PFP_ALLOC_HI(c, rep, uint32_t, dwords); PFP_ALLOC_HI(c, headpos, uint32_t, dwords);
+    PFP_ALLOC_HI(c, wlen1, uint32_t, dwords); PFP_ALLOC_HI(c, occw, uint32_t, dwords); PFP_ALLOC_HI(c, srcstart, uint32_t, dwords);
+    // ids[i] = ex[i] + head[i] - 1 (0-based id of the distinct phrase, in fingerprint order)
+    PFP_LAUNCH(c, K_MISC, m * 12, k_dedup_ids, gm, (const uint32_t *)head, ex, m);
+    PFP_LAUNCH(c, K_MISC, m * 20, k_dedup_scatter, gm, (const uint32_t *)sv, (const uint32_t *)head, (const uint32_t *)ex, m, c->d_pid, rep, headpos);
+    const unsigned gd = nblocks(dwords, BLOCK);
+    PFP_LAUNCH(c, K_MISC, dwords * 16, k_word_lengths, gd, (const uint32_t *)c->d_ye, w, (const uint32_t *)rep, (const uint32_t *)headpos, dwords, m, wlen1, occw);
+    PFP_ALLOC_LO(c, c->d_ws, uint32_t, dwords + 1);
+    PFP_TRY((device_scan<uint32_t, 0>(c, wlen1, c->d_ws, dwords, c->d_ws + dwords)));
+    uint32_t dsm1 = 0; PFP_TRY(d2h_u32(c, c->d_ws + dwords, &dsm1));
+    const uint64_t dsize = (uint64_t)dsm1 + 1; c->dsize = dsize;
+    if (dsize + 64 >= 0xFFFFFFFFULL) return PFP_E_TOO_LARGE;
+    PFP_ALLOC_LO(c, c->d_dict, uint8_t, dsize + 16);
+    PFP_ALLOC_LO(c, c->d_wordid, uint32_t, dsize);
+    PFP_LAUNCH(c, K_MISC, dwords * 12, k_rep_starts, gd, (const uint32_t *)c->d_ye, w, (const uint32_t *)rep, dwords, srcstart);
+    PFP_LAUNCH(c, K_DICT_BUILD, dsize * 6, k_dict_build, nblocks(dsize, 16 * BLOCK), Y, (const uint32_t *)srcstart, (const uint32_t *)c->d_ws, (uint32_t)dwords, dsize, c->d_dict, c->d_wordid);
+
+    // 3. suffix sort of the dictionary: gives word ranks now and the emission order later
+    PFP_TRY(sort_dict_suffixes(c));
+
+    // 4. ranks, occ, last, sorted .dict image
+    uint32_t *flag, *pos, *idofrank, *len1;
+    PFP_ALLOC_HI(c, flag, uint32_t, dsize); PFP_ALLOC_HI(c, pos, uint32_t, dsize);
+    PFP_ALLOC_HI(c, idofrank, uint32_t, dwords); PFP_ALLOC_HI(c, len1, uint32_t, dwords + 1);
+    PFP_ALLOC_LO(c, c->d_wrank, uint32_t, dwords);
+    PFP_ALLOC_LO(c, c->d_occ, uint32_t, dwords);
+    PFP_ALLOC_LO(c, c->d_parse, uint32_t, m + 1);
+    PFP_ALLOC_LO(c, c->d_last, uint8_t, m);
+    PFP_ALLOC_LO(c, c->d_sdict, uint8_t, dsize + 16);
+    const unsigned gds = nblocks(dsize, BLOCK);
+    PFP_LAUNCH(c, K_WORD_RANK, dsize * 12, k_wordstart_flags, gds, (const uint32_t *)c->d_gsa, (const uint32_t *)c->d_wordid, (const uint32_t *)c->d_ws, (uint32_t)dwords, dsize, flag);
+    PFP_TRY((device_scan<uint32_t, 0>(c, flag, pos, dsize, nullptr)));
+    PFP_LAUNCH(c, K_WORD_RANK, dsize * 12, k_word_rank, gds, (const uint32_t *)c->d_gsa, (const uint32_t *)c->d_wordid, (const uint32_t *)flag, (const uint32_t *)pos, dsize,
+               (const uint32_t *)occw, c->d_wrank, idofrank, c->d_occ);
+    PFP_LAUNCH(c, K_PARSE_RANKS, m * 12, k_parse_ranks, gm, (const uint32_t *)c->d_pid, (const uint32_t *)c->d_wrank, m, c->d_parse);
+    PFP_LAUNCH(c, K_MISC, m * 6, k_last_chars, gm, Y, (const uint32_t *)c->d_ye, m, w, c->d_last);
+    PFP_LAUNCH(c, K_DICT_SORTED, dwords * 12, k_sorted_lengths, gd, (const uint32_t *)c->d_ws, (const uint32_t *)idofrank, dwords, len1, srcstart);
+    PFP_TRY((device_scan<uint32_t, 0>(c, len1, len1, dwords, len1 + dwords)));
+    PFP_LAUNCH(c, K_DICT_SORTED, dsize * 2, k_dict_build, nblocks(dsize, 16 * BLOCK), (const uint8_t *)c->d_dict, (const uint32_t *)srcstart, (const uint32_t *)len1, (uint32_t)dwords, dsize,
+               c->d_sdict, (uint32_t *)nullptr);
+    PFP_HIP(c, hipStreamSynchronize(c->stream));
+    c->arena.release_hi(mk);
+    c->stage = 1;
+    c->lo_after_parse = c->arena.mark_lo();
+    c->stage_ms[0] = timer.ms();
+    if (out) { out->n = n; out->m = m; out->dwords = dwords; out->dsize = dsize; }
+    return PFP_OK;
+}
+
+// widen / copy helpers for the U-wide getters
+static int get_u32_as(pfp_ctx *c, const uint32_t *d, uint64_t cnt, void *dst, bool u64)
+{
+    if (!dst || !cnt) return PFP_OK;
+    if (!u64) { PFP_HIP(c, hipMemcpy(dst, d, cnt * 4, hipMemcpyDeviceToHost)); return PFP_OK; }
+    std::vector<uint32_t> tmp((size_t)cnt);
+    PFP_HIP(c, hipMemcpy(tmp.data(), d, cnt * 4, hipMemcpyDeviceToHost));
+    uint64_t *o = (uint64_t *)dst;
+    for (uint64_t i = 0; i < cnt; ++i) o[i] = tmp[(size_t)i];
+    return PFP_OK;
+}
+
+int pfp_parse_get(pfp_ctx *c, uint8_t *dict, void *occ, uint32_t *parse, uint8_t *last, void *sai)
+{
+    if (!c) return PFP_E_ARG;
+    if (c->stage < 1 || !c->d_sdict) return PFP_E_STATE;
+    PFP_HIP(c, hipSetDevice(c->device));
+    PFP_HIP(c, hipStreamSynchronize(c->stream));
+    const bool u64 = (c->flags & PFP_FLAG_U64) != 0;
+    if (dict) PFP_HIP(c, hipMemcpy(dict, c->d_sdict, c->dsize, hipMemcpyDeviceToHost));
+    PFP_TRY(get_u32_as(c, c->d_occ, c->dwords, occ, u64));
+    if (parse) PFP_HIP(c, hipMemcpy(parse, c->d_parse, c->m * 4, hipMemcpyDeviceToHost));
+    if (last) PFP_HIP(c, hipMemcpy(last, c->d_last, c->m, hipMemcpyDeviceToHost));
+    PFP_TRY(get_u32_as(c, c->d_ye, c->m, sai, u64));   // sai[j] = pos_ at process_phrase = ye[j]  (pfparser.hpp:600)
+    return PFP_OK;
+}
+
+// suffix array of S[0..N) (S[N-1] == 0 unique smallest), integer alphabet with values <= maxsym
+static int sort_int_suffixes(pfp_ctx *c, const uint32_t *dS, uint64_t N, uint64_t maxsym, uint32_t *SA, uint32_t *rank, int *rounds)
+{
+    const size_t mk = c->arena.mark_hi();
+    uint64_t *k0, *k1; uint32_t *v0, *v1;
+    PFP_ALLOC_HI(c, k0, uint64_t, N); PFP_ALLOC_HI(c, k1, uint64_t, N);
+    PFP_ALLOC_HI(c, v0, uint32_t, N); PFP_ALLOC_HI(c, v1, uint32_t, N);
+    PFP_LAUNCH(c, K_SS_INIT_KEYS, N * 16, k_int_init_keys, nblocks(N, BLOCK), dS, N, k0, v0);
+    const int sb = bits_for(maxsym);
+    BitRange rr[2] = {{0, sb}, {32, 32 + sb}};
+    PFP_TRY(suffix_sort_doubling(c, N, k0, v0, k1, v1, rr, 2, 2, nullptr, nullptr, SA, rank, rounds));
+    c->arena.release_hi(mk);
+    return PFP_OK;
+}
+
+int pfp_parse_bwt(pfp_ctx *c)
+{
+    if (!c) return PFP_E_ARG;
+    if (c->stage < 1 || !c->d_parse) return PFP_E_STATE;
+    if (c->m < 2) return PFP_E_ONE_WORD;                        // pfparser.hpp:390-392
+    PFP_HIP(c, hipSetDevice(c->device));
+    HostTimer timer;
+    c->arena.release_lo(c->lo_after_parse);
+    const uint64_t m = c->m, N = m + 1;
+    const size_t mk = c->arena.mark_hi();
+    PFP_LAUNCH(c, K_MISC, 4, k_set_u32, 1, c->d_parse, m, 0u);  // :407-410 (d_parse has m+1 slots)
+    uint32_t *SAP, *rk, *W, *rowid, *W2, *rowid2;
+    PFP_ALLOC_LO(c, c->d_bwlast, uint8_t, N);
+    PFP_ALLOC_LO(c, c->d_ilist, uint32_t, N);
+    const bool sai = (c->flags & PFP_FLAG_SAI) != 0;
+    if (sai) PFP_ALLOC_LO(c, c->d_bwsai, uint32_t, N); else c->d_bwsai = nullptr;
+    PFP_ALLOC_HI(c, SAP, uint32_t, N); PFP_ALLOC_HI(c, rk, uint32_t, N);
+    PFP_ALLOC_HI(c, W, uint32_t, N); PFP_ALLOC_HI(c, rowid, uint32_t, N);
+    PFP_ALLOC_HI(c, W2, uint32_t, N); PFP_ALLOC_HI(c, rowid2, uint32_t, N);
+    int rounds = 0;
+    PFP_TRY(sort_int_suffixes(c, c->d_parse, N, c->dwords, SAP, rk, &rounds));   // sacak_int, :425
+    PFP_LAUNCH(c, K_PBWT_ROWS, N * 24, k_pbwt_rows, nblocks(N, BLOCK), (const uint32_t *)SAP, (const uint32_t *)c->d_parse, (const uint8_t *)c->d_last,
+               (const uint32_t *)c->d_ye, m, c->d_bwlast, c->d_bwsai, W, rowid);
+    // ilist: rows grouped by word, ascending inside a word (:452-462) = stable sort of row ids by word
+    BitRange wr = {0, bits_for(c->dwords)};
+    uint32_t *sw, *sr;
+    PFP_TRY(radix_sort_pairs<uint32_t>(c, W, rowid, W2, rowid2, N, &wr, 1, &sw, &sr));
+    PFP_HIP(c, hipMemcpyAsync(c->d_ilist, sr, N * 4, hipMemcpyDeviceToDevice, c->stream));
+    PFP_HIP(c, hipStreamSynchronize(c->stream));
+    c->arena.release_hi(mk);
+    c->nrows = N; c->stage = 2;
+    c->lo_after_pbwt = c->arena.mark_lo();
+    c->stage_ms[1] = timer.ms();
+    return PFP_OK;
+}
+
+int pfp_parse_bwt_get(pfp_ctx *c, uint8_t *bwlast, void *ilist, void *bwsai)
+{
+    if (!c) return PFP_E_ARG;
+    if (c->stage < 2) return PFP_E_STATE;
+    PFP_HIP(c, hipSetDevice(c->device));
+    const bool u64 = (c->flags & PFP_FLAG_U64) != 0;
+    if (bwlast) PFP_HIP(c, hipMemcpy(bwlast, c->d_bwlast, c->nrows, hipMemcpyDeviceToHost));
+    PFP_TRY(get_u32_as(c, c->d_ilist, c->nrows, ilist, u64));
+    if (bwsai) { if (!c->d_bwsai) return PFP_E_STATE; PFP_TRY(get_u32_as(c, c->d_bwsai, c->nrows, bwsai, u64)); }
+    return PFP_OK;
+}
+
+// ---- stage 2 --------------------------------------------------------------------------------------
+static int upload_u32_from(pfp_ctx *c, const void *src, uint64_t cnt, bool u64, uint32_t *d)
+{
+    if (!u64) { PFP_HIP(c, hipMemcpy(d, src, cnt * 4, hipMemcpyHostToDevice)); return PFP_OK; }
+    std::vector<uint32_t> tmp((size_t)cnt);
+    const uint64_t *s = (const uint64_t *)src;
+    for (uint64_t i = 0; i < cnt; ++i) { if (s[i] > 0xFFFFFFFFULL) return PFP_E_TOO_LARGE; tmp[(size_t)i] = (uint32_t)s[i]; }
+    PFP_HIP(c, hipMemcpy(d, tmp.data(), cnt * 4, hipMemcpyHostToDevice));
+    return PFP_OK;
+}
+
+int pfp_bwt_load(pfp_ctx *c, const uint8_t *dict, uint64_t dsize, const void *occ, uint64_t dwords,
+                 const uint8_t *bwlast, const void *ilist, const void *bwsai, uint64_t nrows, uint64_t n_hint)
+{
+    if (!c || !dict || !occ || !bwlast || !ilist || dsize < 2 || dwords < 1 || nrows < 2) return PFP_E_ARG;
+    if (dsize + 64 >= 0xFFFFFFFFULL || nrows + 64 >= 0xFFFFFFFFULL) return PFP_E_TOO_LARGE;
+    PFP_HIP(c, hipSetDevice(c->device));
+    reset_results(c);
+    // n (the .n file, src/pfbwt-f.cpp:282-285) sizes the outputs; without it assume n <= 4 * dsize
+    PFP_TRY(ensure_arena(c, (n_hint ? n_hint : 4 * dsize) + dsize + nrows));
+    c->arena.reset();
+    const bool u64 = (c->flags & PFP_FLAG_U64) != 0;
+    c->dsize = dsize; c->dwords = dwords; c->nrows = nrows; c->m = nrows - 1;
+    PFP_ALLOC_LO(c, c->d_dict, uint8_t, dsize + 16);
+    PFP_ALLOC_LO(c, c->d_wordid, uint32_t, dsize);
+    PFP_ALLOC_LO(c, c->d_ws, uint32_t, dwords + 2);
+    PFP_ALLOC_LO(c, c->d_occ, uint32_t, dwords);
+    PFP_ALLOC_LO(c, c->d_bwlast, uint8_t, nrows);
+    PFP_ALLOC_LO(c, c->d_ilist, uint32_t, nrows);
+    PFP_HIP(c, hipMemcpy(c->d_dict, dict, dsize, hipMemcpyHostToDevice));
+    PFP_HIP(c, hipMemcpy(c->d_bwlast, bwlast, nrows, hipMemcpyHostToDevice));
+    PFP_TRY(upload_u32_from(c, occ, dwords, u64, c->d_occ));
+    PFP_TRY(upload_u32_from(c, ilist, nrows, u64, c->d_ilist));
+    if (bwsai) { PFP_ALLOC_LO(c, c->d_bwsai, uint32_t, nrows); PFP_TRY(upload_u32_from(c, bwsai, nrows, u64, c->d_bwsai)); }
+    // word index of every dictionary offset = number of EndOfWord bytes before it (dict_idx.rank, pfbwt.hpp:83-85)
+    const size_t mk = c->arena.mark_hi();
+    uint32_t *flag, *d_cnt;
+    PFP_ALLOC_HI(c, flag, uint32_t, dsize); PFP_ALLOC_HI(c, d_cnt, uint32_t, 1);
+    PFP_LAUNCH(c, K_MISC, dsize * 5, k_eow_flags, nblocks(dsize, BLOCK), (const uint8_t *)c->d_dict, dsize, flag);
+    PFP_TRY((device_scan<uint32_t, 0>(c, flag, c->d_wordid, dsize, d_cnt)));
+    uint32_t nw = 0; PFP_TRY(d2h_u32(c, d_cnt, &nw));
+    if (nw != dwords) return PFP_E_CORRUPT;
+    PFP_LAUNCH(c, K_MISC, dsize * 5, k_ws_from_flags, nblocks(dsize, BLOCK), (const uint8_t *)c->d_dict, dsize, (const uint32_t *)c->d_wordid, c->d_ws);
+    PFP_HIP(c, hipStreamSynchronize(c->stream));
+    c->arena.release_hi(mk);
+    c->d_wrank = nullptr; c->gsa_valid = false; c->stage = 2; c->n = 0;
+    c->lo_after_pbwt = c->arena.mark_lo();
+    return PFP_OK;
+}
+
+extern "C++" {
+template <typename SAT> static int emit_and_sample(pfp_ctx *c, const EmitArgs &ea, bool want_sa, bool want_rssa)
+{
+    const uint64_t nout = ea.nout;
+    const bool any_sa = want_sa || want_rssa;
+    PFP_ALLOC_LO(c, c->d_bwt, uint8_t, nout);
+    SAT *sa = nullptr;
+    if (any_sa) { PFP_ALLOC_LO(c, sa, SAT, nout); }
+    c->d_sa = sa;
+    PFP_LAUNCH(c, K_EMIT, nout * (1 + (any_sa ? sizeof(SAT) : 0)) + c->nrows * 9 + c->dsize * 9, (k_emit<SAT>), nblocks(nout, BLOCK), ea, c->d_bwt, sa);
+    // runs
+    uint32_t *flag, *ridx, *d_cnt;
+    PFP_ALLOC_HI(c, flag, uint32_t, nout); PFP_ALLOC_HI(c, ridx, uint32_t, nout); PFP_ALLOC_HI(c, d_cnt, uint32_t, 1);
+    PFP_LAUNCH(c, K_RUNS, nout * 5, k_run_flags, nblocks(nout, BLOCK), (const uint8_t *)c->d_bwt, nout, flag);
+    PFP_TRY((device_scan<uint32_t, 0>(c, flag, ridx, nout, d_cnt)));
+    uint32_t r = 0; PFP_TRY(d2h_u32(c, d_cnt, &r));
+    c->runs = r;
+    c->d_ssa = c->d_esa = nullptr;
+    if (want_rssa) {
+        SAT *ssa, *esa;
+        PFP_ALLOC_LO(c, ssa, SAT, 2 * (uint64_t)r); PFP_ALLOC_LO(c, esa, SAT, 2 * (uint64_t)r);
+        PFP_LAUNCH(c, K_SAMPLES, nout * 8 + (uint64_t)r * 4 * sizeof(SAT), (k_samples<SAT>), nblocks(nout, BLOCK), (const uint32_t *)flag, (const uint32_t *)ridx, (const SAT *)sa, nout, (uint64_t)r, ssa, esa);
+        c->d_ssa = ssa; c->d_esa = esa;
+    }
+    return PFP_OK;
+}
+} // extern "C++"
+
+int pfp_bwt_build(pfp_ctx *c, int want_sa, int want_rssa, pfp_bwt_sizes *out)
+{
+    if (!c) return PFP_E_ARG;
+    if (c->stage < 2) return PFP_E_STATE;
+    if ((want_sa || want_rssa) && !c->d_bwsai) return PFP_E_STATE;
+    PFP_HIP(c, hipSetDevice(c->device));
+    HostTimer timer;
+    c->arena.release_lo(c->lo_after_pbwt);
+    const size_t mk = c->arena.mark_hi();
+    if (!c->gsa_valid) { PFP_TRY(sort_dict_suffixes(c)); c->lo_after_pbwt = c->arena.mark_lo(); }   // gsacak, pfbwt.hpp:211
+    const uint64_t dsize = c->dsize, dwords = c->dwords;
+    uint32_t *F, *cnt, *EB, *d_tot, *mr;
+    PFP_ALLOC_HI(c, F, uint32_t, dwords + 1);
+    PFP_ALLOC_HI(c, cnt, uint32_t, dsize); PFP_ALLOC_HI(c, EB, uint32_t, dsize); PFP_ALLOC_HI(c, mr, uint32_t, dsize);
+    PFP_ALLOC_HI(c, d_tot, uint32_t, 4);
+    // F[r] = 1 + sum_{r' < r} occ[r']  (ilist[0] is the EOS row; pfbwt.hpp:259-268)
+    PFP_TRY((device_scan<uint32_t, 0>(c, c->d_occ, F, dwords, nullptr)));
+    PFP_LAUNCH(c, K_MISC, dwords * 8, k_u32_add_store, nblocks(dwords, BLOCK), (const uint32_t *)F, dwords, 1u, F);
+    EmitArgs ea;
+    ea.D = c->d_dict; ea.dsize = dsize; ea.dwords = (uint32_t)dwords; ea.w = c->w;
+    ea.SA = c->d_gsa; ea.grank = c->d_grank; ea.wordid = c->d_wordid; ea.ws = c->d_ws; ea.wrank = c->d_wrank;
+    ea.occ = c->d_occ; ea.F = F; ea.ilist = c->d_ilist; ea.bwsai = c->d_bwsai; ea.bwlast = c->d_bwlast;
+    ea.EB = EB; ea.nout = 0; ea.n = 0;
+    PFP_LAUNCH(c, K_EMIT_COUNT, dsize * 16, k_emit_count, nblocks(dsize, BLOCK), ea, cnt);
+    PFP_TRY((device_scan<uint32_t, 0>(c, cnt, EB, dsize, d_tot)));
+    PFP_LAUNCH(c, K_MISC, dsize * 16, k_multi_rows, nblocks(dsize, BLOCK), ea, (const uint32_t *)cnt, mr);
+    PFP_TRY((device_scan<uint32_t, 0>(c, mr, mr, dsize, d_tot + 1)));
+    uint32_t tot = 0, hardrows = 0;
+    PFP_HIP(c, hipMemcpyAsync(&hardrows, d_tot + 1, 4, hipMemcpyDeviceToHost, c->stream));
+    PFP_TRY(d2h_u32(c, d_tot, &tot));
+    const uint64_t nout = tot;
+    if (nout < 2) return PFP_E_CORRUPT;
+    if (c->n && nout != c->n + 1) return PFP_E_CORRUPT;         // emission must produce exactly n+1 rows
+    if (!c->n) c->n = nout - 1;
+    ea.nout = nout; ea.n = c->n;
+    c->nout = nout; c->hard = hardrows; c->easy = nout - hardrows;
+    c->have_sa = want_sa != 0; c->have_rssa = want_rssa != 0;
+    int rc;
+    if (c->flags & PFP_FLAG_U64) rc = emit_and_sample<uint64_t>(c, ea, want_sa != 0, want_rssa != 0);
+    else rc = emit_and_sample<uint32_t>(c, ea, want_sa != 0, want_rssa != 0);
+    if (rc != PFP_OK) return rc;
+    PFP_HIP(c, hipStreamSynchronize(c->stream));
+    c->arena.release_hi(mk);
+    c->stage = 3;
+    c->stage_ms[2] = timer.ms();
+    if (out) { out->nout = nout; out->r = c->runs; out->easy_cases = c->easy; out->hard_cases = c->hard; }
+    return PFP_OK;
+}
+
+int pfp_bwt_get(pfp_ctx *c, uint8_t *bwt, void *sa, void *ssa, void *esa)
+{
+    if (!c) return PFP_E_ARG;
+    if (c->stage < 3) return PFP_E_STATE;
+    PFP_HIP(c, hipSetDevice(c->device));
+    const size_t U = (c->flags & PFP_FLAG_U64) ? 8 : 4;
+    if (bwt) PFP_HIP(c, hipMemcpy(bwt, c->d_bwt, c->nout, hipMemcpyDeviceToHost));
+    if (sa) { if (!c->d_sa) return PFP_E_STATE; PFP_HIP(c, hipMemcpy(sa, c->d_sa, c->nout * U, hipMemcpyDeviceToHost)); }
+    if (ssa) { if (!c->d_ssa) return PFP_E_STATE; PFP_HIP(c, hipMemcpy(ssa, c->d_ssa, c->runs * 2 * U, hipMemcpyDeviceToHost)); }
+    if (esa) { if (!c->d_esa) return PFP_E_STATE; PFP_HIP(c, hipMemcpy(esa, c->d_esa, c->runs * 2 * U, hipMemcpyDeviceToHost)); }
+    return PFP_OK;
+}
+
+int pfp_bwt_device_ptrs(pfp_ctx *c, const void **d_bwt, const void **d_sa, const void **d_ssa, const void **d_esa)
+{
+    if (!c) return PFP_E_ARG;
+    if (c->stage < 3) return PFP_E_STATE;
+    if (d_bwt) *d_bwt = c->d_bwt;
+    if (d_sa) *d_sa = c->d_sa;
+    if (d_ssa) *d_ssa = c->d_ssa;
+    if (d_esa) *d_esa = c->d_esa;
+    return PFP_OK;
+}
+
+// ---- gsa/gsacak.h:76-103 drop-ins ------------------------------------------------------------------
+static int sacak_int_impl(const uint32_t *s, void *SA, uint64_t n, uint64_t k, bool u64)
+{
+    if (!s || !SA || n == 0) return -1;
+    if (n + 64 >= 0xFFFFFFFFULL) return -1;
+    int st = 0;
+    pfp_ctx *c = pfp_create(10, 100, 0, 0, (uint64_t)(80 * n + (32ULL << 20)), &st);
+    if (!c) return -1;
+    int rounds = -1;
+    do {
+        if (ensure_arena(c, n) != PFP_OK) break;
+        uint32_t *dS = (uint32_t *)c->arena.alloc_lo(n * 4), *dSA = (uint32_t *)c->arena.alloc_lo(n * 4), *dR = (uint32_t *)c->arena.alloc_lo(n * 4);
+        if (!dS || !dSA || !dR) break;
+        if (hipMemcpy(dS, s, n * 4, hipMemcpyHostToDevice) != hipSuccess) break;
+        int r = 0;
+        if (sort_int_suffixes(c, dS, n, k ? k - 1 : 0, dSA, dR, &r) != PFP_OK) break;
+        if (hipStreamSynchronize(c->stream) != hipSuccess) break;
+        if (!u64) { if (hipMemcpy(SA, dSA, n * 4, hipMemcpyDeviceToHost) != hipSuccess) break; }
+        else {
+            std::vector<uint32_t> tmp((size_t)n);
+            if (hipMemcpy(tmp.data(), dSA, n * 4, hipMemcpyDeviceToHost) != hipSuccess) break;
+            for (uint64_t i = 0; i < n; ++i) ((uint64_t *)SA)[i] = tmp[(size_t)i];
+        }
+        rounds = r;
+    } while (0);
+    pfp_destroy(c);
+    return rounds;
+}
+int pfp_sacak_int_u32(const uint32_t *s, uint32_t *SA, uint32_t n, uint32_t k) { return sacak_int_impl(s, SA, n, k, false); }
+int pfp_sacak_int_u64(const uint32_t *s, uint64_t *SA, uint64_t n, uint64_t k) { return sacak_int_impl(s, SA, n, k, true); }
+
+} // extern "C"

@@ -1,0 +1,276 @@
+// pfbwt-f_amd/csrc/prims.h -- device-wide primitives written for wave64 / 256-thread workgroups:
+// exclusive/inclusive scans, LSD radix sort of (key, u32 value) pairs, stream compaction.
+// No counterpart in the reference (it is sequential C/C++); these are the building blocks the
+// suffix sorters and the emission are expressed in on the GPU.
+#pragma once
+#include "common.h"
+
+namespace pfp {
+
+// ------------------------------------------------------------------------------------------------
+// workgroup scan helpers (256 threads = 4 waves)
+template <typename T> __device__ __forceinline__ T wave_incl_sum(T v)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { T y = __shfl_up(v, d); if (lane >= d) v += y; }
+    return v;
+}
+template <typename T> __device__ __forceinline__ T wave_incl_max(T v)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { T y = __shfl_up(v, d); if (lane >= d && y > v) v = y; }
+    return v;
+}
+
+// exclusive sum over the 256 threads of the block; *total = block sum. lds: >= 4 entries.
+template <typename T> __device__ __forceinline__ T block_excl_sum(T v, T *lds, T *total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    T inc = wave_incl_sum(v);
+    if (lane == 63) lds[wave] = inc;
+    __syncthreads();
+    T base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < BLOCK / WAVE; ++i) { T s = lds[i]; if (i < wave) base += s; tot += s; }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+template <typename T> __device__ __forceinline__ T block_incl_max(T v, T *lds, T *total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    T inc = wave_incl_max(v);
+    if (lane == 63) lds[wave] = inc;
+    __syncthreads();
+    T base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < BLOCK / WAVE; ++i) { T s = lds[i]; if (i < wave && s > base) base = s; if (s > tot) tot = s; }
+    __syncthreads();
+    *total = tot;
+    return inc > base ? inc : base;
+}
+
+// ------------------------------------------------------------------------------------------------
+// device-wide scan: OP 0 = exclusive sum, OP 1 = inclusive max.  Tile = 256 threads x SCAN_ITEMS.
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_TILE = BLOCK * SCAN_ITEMS;
+
+template <typename T, int OP> __global__ __launch_bounds__(BLOCK) void k_scan_reduce(const T *in, uint64_t n, T *partial)
+{
+    __shared__ T lds[4];
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
+    T acc = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        uint64_t i = base + k;
+        T v = i < n ? in[i] : (T)0;
+        if (OP == 0) acc += v; else acc = v > acc ? v : acc;
+    }
+    T tot;
+    if (OP == 0) (void)block_excl_sum(acc, lds, &tot); else (void)block_incl_max(acc, lds, &tot);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+// single workgroup: scans `cnt` partials in place (exclusive for both ops: carry-in of each tile)
+template <typename T, int OP> __global__ __launch_bounds__(BLOCK) void k_scan_spine(T *partial, uint64_t cnt, T *grand_total)
+{
+    __shared__ T lds[4];
+    T carry = 0;
+    for (uint64_t base = 0; base < cnt; base += SCAN_TILE) {
+        T v[SCAN_ITEMS]; T acc = 0;
+        const uint64_t b = base + (uint64_t)threadIdx.x * SCAN_ITEMS;
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; ++k) {
+            v[k] = (b + k) < cnt ? partial[b + k] : (T)0;
+            if (OP == 0) acc += v[k]; else acc = v[k] > acc ? v[k] : acc;
+        }
+        T tot, pre;
+        if (OP == 0) pre = block_excl_sum(acc, lds, &tot);
+        else { // exclusive max = inclusive max of the previous thread
+            T inc = block_incl_max(acc, lds, &tot);
+            // derive exclusive: max over threads < me.  Recompute with a shifted value.
+            T sh = __shfl_up(inc, 1);
+            __shared__ T wl[4];
+            if ((threadIdx.x & 63) == 63) wl[threadIdx.x >> 6] = inc;
+            __syncthreads();
+            pre = (threadIdx.x & 63) ? sh : ((threadIdx.x >> 6) ? wl[(threadIdx.x >> 6) - 1] : (T)0);
+            __syncthreads();
+        }
+        T run = OP == 0 ? carry + pre : (carry > pre ? carry : pre);
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; ++k) {
+            if ((b + k) < cnt) partial[b + k] = run;
+            if (OP == 0) run += v[k]; else run = v[k] > run ? v[k] : run;
+        }
+        if (OP == 0) carry += tot; else carry = tot > carry ? tot : carry;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && grand_total) *grand_total = carry;
+}
+
+template <typename T, int OP> __global__ __launch_bounds__(BLOCK) void k_scan_apply(const T *in, T *out, uint64_t n, const T *partial)
+{
+    __shared__ T lds[4];
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
+    T v[SCAN_ITEMS]; T acc = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        uint64_t i = base + k;
+        v[k] = i < n ? in[i] : (T)0;
+        if (OP == 0) acc += v[k]; else acc = v[k] > acc ? v[k] : acc;
+    }
+    T tot;
+    const T carry = partial[blockIdx.x];
+    if (OP == 0) {
+        T run = carry + block_excl_sum(acc, lds, &tot);
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; ++k) { uint64_t i = base + k; if (i < n) out[i] = run; run += v[k]; }
+    } else {
+        // inclusive max: need the max over all previous threads (exclusive) as the running start
+        T inc = block_incl_max(acc, lds, &tot);
+        __shared__ T wl[4];
+        T sh = __shfl_up(inc, 1);
+        if ((threadIdx.x & 63) == 63) wl[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        T pre = (threadIdx.x & 63) ? sh : ((threadIdx.x >> 6) ? wl[(threadIdx.x >> 6) - 1] : (T)0);
+        T run = carry > pre ? carry : pre;
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; ++k) { uint64_t i = base + k; run = v[k] > run ? v[k] : run; if (i < n) out[i] = run; }
+    }
+}
+
+// out may alias in.  d_total (device, optional) receives the grand total.  Scratch from arena hi.
+template <typename T, int OP> inline int device_scan(pfp_ctx *c, const T *in, T *out, uint64_t n, T *d_total)
+{
+    if (n == 0) { if (d_total) PFP_HIP(c, hipMemsetAsync(d_total, 0, sizeof(T), c->stream)); return PFP_OK; }
+    const size_t mk = c->arena.mark_hi();
+    const unsigned nb = nblocks(n, SCAN_TILE);
+    T *partial; PFP_ALLOC_HI(c, partial, T, nb);
+    PFP_LAUNCH(c, K_SCAN_REDUCE, n * sizeof(T), (k_scan_reduce<T, OP>), nb, in, n, partial);
+    PFP_LAUNCH(c, K_SCAN_SPINE, nb * sizeof(T) * 2, (k_scan_spine<T, OP>), 1, partial, (uint64_t)nb, d_total);
+    PFP_LAUNCH(c, K_SCAN_APPLY, n * sizeof(T) * 2, (k_scan_apply<T, OP>), nb, in, out, n, (const T *)partial);
+    c->arena.release_hi(mk);
+    return PFP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LSD radix sort, 8-bit digits, stable.  Tile = 4 waves x 16 rounds x 64 lanes = 4096 pairs; every
+// wave owns a contiguous 1024-pair slice so that order inside the tile is wave-major.
+constexpr int RS_ITEMS = 16;
+constexpr int RS_TILE = BLOCK * RS_ITEMS;
+constexpr int RS_RADIX = 256;
+
+template <typename K> __global__ __launch_bounds__(BLOCK) void k_radix_hist(const K *keys, uint64_t n, int shift, uint32_t *hist, unsigned nb)
+{
+    __shared__ uint32_t h[RS_RADIX];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t base = (uint64_t)blockIdx.x * RS_TILE + (uint64_t)(threadIdx.x >> 6) * (RS_ITEMS * WAVE) + (threadIdx.x & 63);
+#pragma unroll
+    for (int it = 0; it < RS_ITEMS; ++it) {
+        uint64_t i = base + (uint64_t)it * WAVE;
+        if (i < n) atomicAdd(&h[(unsigned)(keys[i] >> shift) & (RS_RADIX - 1)], 1u);
+    }
+    __syncthreads();
+    hist[(uint64_t)threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];
+}
+
+template <typename K> __global__ __launch_bounds__(BLOCK) void k_radix_scatter(const K *keys, const uint32_t *vals, K *okeys, uint32_t *ovals,
+                                                                             uint64_t n, int shift, const uint32_t *gbase, unsigned nb)
+{
+    __shared__ uint32_t wh[BLOCK / WAVE][RS_RADIX];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    K k[RS_ITEMS]; uint32_t v[RS_ITEMS];
+    const uint64_t base = (uint64_t)blockIdx.x * RS_TILE + (uint64_t)wave * (RS_ITEMS * WAVE) + lane;
+#pragma unroll
+    for (int w = 0; w < BLOCK / WAVE; ++w) wh[w][threadIdx.x] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < RS_ITEMS; ++it) {
+        uint64_t i = base + (uint64_t)it * WAVE;
+        if (i < n) { k[it] = keys[i]; v[it] = vals[i]; atomicAdd(&wh[wave][(unsigned)(k[it] >> shift) & (RS_RADIX - 1)], 1u); }
+        else { k[it] = 0; v[it] = 0; }
+    }
+    __syncthreads();
+    {   // thread d turns the four per-wave counts of digit d into global write cursors
+        uint32_t run = gbase[(uint64_t)threadIdx.x * nb + blockIdx.x];
+#pragma unroll
+        for (int w = 0; w < BLOCK / WAVE; ++w) { uint32_t cnt = wh[w][threadIdx.x]; wh[w][threadIdx.x] = run; run += cnt; }
+    }
+    __syncthreads();
+    const unsigned long long lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;
+#pragma unroll
+    for (int it = 0; it < RS_ITEMS; ++it) {
+        const uint64_t i = base + (uint64_t)it * WAVE;
+        const bool valid = i < n;
+        const unsigned d = (unsigned)(k[it] >> shift) & (RS_RADIX - 1);
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            unsigned long long m = __ballot((d >> b) & 1);
+            peers &= ((d >> b) & 1) ? m : ~m;
+        }
+        // peers: valid lanes with my digit (garbage for invalid lanes, which are masked below)
+        const int leader = valid ? (__ffsll((long long)peers) - 1) : lane;
+        uint32_t old = 0;
+        if (valid && lane == leader) { old = wh[wave][d]; wh[wave][d] = old + (uint32_t)__popcll(peers); }
+        old = __shfl(old, leader);
+        if (valid) {
+            const uint32_t dst = old + (uint32_t)__popcll(peers & lt);
+            okeys[dst] = k[it]; ovals[dst] = v[it];
+        }
+    }
+}
+
+struct BitRange { int lo, hi; };
+
+// Sorts n pairs by the key bits in `ranges` (least significant range first).  Buffers (k0,v0) hold
+// the input; (k1,v1) are scratch of the same size.  On return *rk,*rv point at the sorted arrays.
+template <typename K> inline int radix_sort_pairs(pfp_ctx *c, K *k0, uint32_t *v0, K *k1, uint32_t *v1, uint64_t n,
+                                                  const BitRange *ranges, int nranges, K **rk, uint32_t **rv)
+{
+    *rk = k0; *rv = v0;
+    if (n <= 1) return PFP_OK;
+    const size_t mk = c->arena.mark_hi();
+    const unsigned nb = nblocks(n, RS_TILE);
+    uint32_t *hist; PFP_ALLOC_HI(c, hist, uint32_t, (size_t)RS_RADIX * nb);
+    K *src = k0, *dst = k1; uint32_t *sv = v0, *dv = v1;
+    for (int r = 0; r < nranges; ++r) {
+        for (int shift = ranges[r].lo; shift < ranges[r].hi; shift += 8) {
+            PFP_LAUNCH(c, K_RADIX_HIST, n * sizeof(K), (k_radix_hist<K>), nb, (const K *)src, n, shift, hist, nb);
+            PFP_TRY((device_scan<uint32_t, 0>(c, hist, hist, (uint64_t)RS_RADIX * nb, nullptr)));
+            PFP_LAUNCH(c, K_RADIX_SCATTER, n * 2 * (sizeof(K) + 4), (k_radix_scatter<K>), nb, (const K *)src, (const uint32_t *)sv, dst, dv, n, shift,
+                       (const uint32_t *)hist, nb);
+            K *tk = src; src = dst; dst = tk; uint32_t *tv = sv; sv = dv; dv = tv;
+        }
+    }
+    *rk = src; *rv = sv;
+    c->arena.release_hi(mk);
+    return PFP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// compaction: out[j] = in[i] for the i with flag[i] != 0, order preserved; *d_count = kept.
+__global__ __launch_bounds__(BLOCK) void k_compact_scatter(const uint32_t *in, const uint32_t *flag, const uint32_t *pos, uint64_t n, uint32_t *out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n && flag[i]) out[pos[i]] = in ? in[i] : (uint32_t)i;
+}
+// in == nullptr compacts the indices themselves.  pos_scratch: n entries.
+inline int device_compact(pfp_ctx *c, const uint32_t *in, const uint32_t *flag, uint64_t n, uint32_t *out, uint32_t *pos_scratch, uint32_t *d_count)
+{
+    PFP_TRY((device_scan<uint32_t, 0>(c, flag, pos_scratch, n, d_count)));
+    if (n) PFP_LAUNCH(c, K_COMPACT, n * 12, k_compact_scatter, nblocks(n, BLOCK), in, flag, (const uint32_t *)pos_scratch, n, out);
+    return PFP_OK;
+}
+
+inline int d2h_u32(pfp_ctx *c, const uint32_t *d, uint32_t *h)
+{
+    PFP_HIP(c, hipMemcpyAsync(h, d, 4, hipMemcpyDeviceToHost, c->stream));
+    PFP_HIP(c, hipStreamSynchronize(c->stream));
+    return PFP_OK;
+}
+
+} // namespace pfp

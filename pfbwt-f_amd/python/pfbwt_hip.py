@@ -1,0 +1,203 @@
+"""ctypes binding of libpfbwt_hip.so (include/pfbwt_hip.h) -- the MI355X engine.
+
+Thin by design: numpy arrays in/out, no algorithmic work here.  The product library is
+`pfbwt-f_amd/lib/libpfbwt_hip.so` (hipcc, gfx950).  If it is missing or cannot be loaded this module
+raises -- there is no CPU fallback.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(os.path.dirname(_HERE), "lib", "libpfbwt_hip.so")
+
+PFP_OK = 0
+FLAG_U64, FLAG_NON_ACGT_TO_A, FLAG_SAI = 1, 2, 4
+E_INVALID_CHAR, E_TOO_LARGE, E_NOMEM, E_HIP, E_ONE_WORD, E_STATE, E_CORRUPT = -2, -3, -4, -5, -6, -7, -8
+
+
+class PfpError(RuntimeError):
+    def __init__(self, status, msg, pos=None, ch=None):
+        super().__init__("pfbwt_hip: %s (status %d)" % (msg, status))
+        self.status, self.pos, self.ch = status, pos, ch
+
+
+class ParseSizes(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("m", C.c_uint64), ("dwords", C.c_uint64), ("dsize", C.c_uint64)]
+
+
+class BwtSizes(C.Structure):
+    _fields_ = [("nout", C.c_uint64), ("r", C.c_uint64), ("easy_cases", C.c_uint64), ("hard_cases", C.c_uint64)]
+
+
+_libs = {}
+
+
+def load_library(path=None):
+    path = os.path.abspath(path or DEFAULT_LIB)
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
+        raise OSError("HIP library %s not built: run `make -C pfbwt-f_amd` (hipcc --offload-arch=gfx950)" % path)
+    L = C.CDLL(path)
+    vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int
+    L.pfp_create.restype = vp
+    L.pfp_create.argtypes = [i32, u64, C.c_uint, i32, u64, C.POINTER(i32)]
+    L.pfp_destroy.argtypes = [vp]
+    L.pfp_destroy.restype = None
+    L.pfp_strerror.restype = C.c_char_p
+    L.pfp_strerror.argtypes = [i32]
+    L.pfp_backend.restype = C.c_char_p
+    L.pfp_error_detail.argtypes = [vp, C.POINTER(u64), C.POINTER(i32)]
+    L.pfp_workspace_needed.restype = u64
+    L.pfp_workspace_needed.argtypes = [vp]
+    L.pfp_parse_feed.argtypes = [vp, vp, u64, i32]
+    L.pfp_parse_feed_device.argtypes = [vp, vp, u64, i32]
+    L.pfp_parse_finalize.argtypes = [vp, C.POINTER(ParseSizes)]
+    L.pfp_parse_get.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.pfp_parse_bwt.argtypes = [vp]
+    L.pfp_parse_bwt_get.argtypes = [vp, vp, vp, vp]
+    L.pfp_bwt_load.argtypes = [vp, vp, u64, vp, u64, vp, vp, vp, u64, u64]
+    L.pfp_bwt_build.argtypes = [vp, i32, i32, C.POINTER(BwtSizes)]
+    L.pfp_bwt_get.argtypes = [vp, vp, vp, vp, vp]
+    L.pfp_bwt_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    L.pfp_sacak_int_u32.argtypes = [vp, vp, C.c_uint32, C.c_uint32]
+    L.pfp_sacak_int_u64.argtypes = [vp, vp, u64, u64]
+    L.pfp_profile_enable.argtypes = [vp, i32]
+    L.pfp_profile_reset.argtypes = [vp]
+    L.pfp_profile_get.argtypes = [vp, i32, C.POINTER(C.c_char_p), C.POINTER(u64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.pfp_stage_ms.argtypes = [vp, C.POINTER(C.c_double)]
+    _libs[path] = L
+    return L
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class PfpContext:
+    """One engine context = one HIP stream + one device workspace (include/pfbwt_hip.h)."""
+
+    def __init__(self, w=10, p=100, u64=True, non_acgt_to_a=False, sai=True, device=0, workspace_bytes=0, lib=None):
+        self.L = load_library(lib)
+        self.u64 = bool(u64)
+        self.udt = np.uint64 if u64 else np.uint32
+        flags = (FLAG_U64 if u64 else 0) | (FLAG_NON_ACGT_TO_A if non_acgt_to_a else 0) | (FLAG_SAI if sai else 0)
+        self.sai = bool(sai)
+        st = C.c_int(0)
+        self.h = self.L.pfp_create(int(w), int(p), flags, int(device), int(workspace_bytes), C.byref(st))
+        if not self.h:
+            raise PfpError(st.value, self.L.pfp_strerror(st.value).decode())
+        self.sizes = None
+        self.bsizes = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.pfp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, st):
+        if st != PFP_OK:
+            pos, ch = C.c_uint64(0), C.c_int(0)
+            self.L.pfp_error_detail(self.h, C.byref(pos), C.byref(ch))
+            raise PfpError(st, self.L.pfp_strerror(st).decode(), pos.value, ch.value)
+
+    # ---- stage 1
+    def feed(self, bases, end_of_seq=True):
+        a = np.frombuffer(bases, dtype=np.uint8) if isinstance(bases, (bytes, bytearray, memoryview)) else np.ascontiguousarray(bases, dtype=np.uint8)
+        self._check(self.L.pfp_parse_feed(self.h, _ptr(a) if a.size else None, a.size, 1 if end_of_seq else 0))
+
+    def feed_device(self, dptr, nbytes, end_of_seq=True):
+        self._check(self.L.pfp_parse_feed_device(self.h, C.c_void_p(int(dptr)), int(nbytes), 1 if end_of_seq else 0))
+
+    def finalize(self):
+        s = ParseSizes()
+        self._check(self.L.pfp_parse_finalize(self.h, C.byref(s)))
+        self.sizes = s
+        return s
+
+    def parse_get(self):
+        s = self.sizes
+        out = {"dict": np.empty(s.dsize, np.uint8), "occ": np.empty(s.dwords, self.udt), "parse": np.empty(s.m, np.uint32),
+               "last": np.empty(s.m, np.uint8), "sai": np.empty(s.m, self.udt) if self.sai else None}
+        self._check(self.L.pfp_parse_get(self.h, _ptr(out["dict"]), _ptr(out["occ"]), _ptr(out["parse"]), _ptr(out["last"]), _ptr(out["sai"])))
+        return out
+
+    def parse_bwt(self):
+        self._check(self.L.pfp_parse_bwt(self.h))
+
+    def parse_bwt_get(self):
+        nr = self.sizes.m + 1
+        out = {"bwlast": np.empty(nr, np.uint8), "ilist": np.empty(nr, self.udt), "bwsai": np.empty(nr, self.udt) if self.sai else None}
+        self._check(self.L.pfp_parse_bwt_get(self.h, _ptr(out["bwlast"]), _ptr(out["ilist"]), _ptr(out["bwsai"])))
+        return out
+
+    # ---- stage 2
+    def bwt_load(self, dict_, occ, bwlast, ilist, bwsai=None, n_hint=0):
+        d = np.ascontiguousarray(dict_, np.uint8); o = np.ascontiguousarray(occ, self.udt)
+        bl = np.ascontiguousarray(bwlast, np.uint8); il = np.ascontiguousarray(ilist, self.udt)
+        bs = None if bwsai is None else np.ascontiguousarray(bwsai, self.udt)
+        self._check(self.L.pfp_bwt_load(self.h, _ptr(d), d.size, _ptr(o), o.size, _ptr(bl), _ptr(il), _ptr(bs), bl.size, int(n_hint)))
+
+    def bwt_build(self, sa=True, rssa=False):
+        b = BwtSizes()
+        self._check(self.L.pfp_bwt_build(self.h, 1 if sa else 0, 1 if rssa else 0, C.byref(b)))
+        self.bsizes, self._want = b, (bool(sa), bool(rssa))
+        return b
+
+    def bwt_get(self):
+        b = self.bsizes
+        sa, rssa = self._want
+        out = {"bwt": np.empty(b.nout, np.uint8), "sa": np.empty(b.nout, self.udt) if (sa or rssa) else None,
+               "ssa": np.empty(2 * b.r, self.udt) if rssa else None, "esa": np.empty(2 * b.r, self.udt) if rssa else None}
+        self._check(self.L.pfp_bwt_get(self.h, _ptr(out["bwt"]), _ptr(out["sa"]), _ptr(out["ssa"]), _ptr(out["esa"])))
+        return out
+
+    def bwt_device_ptrs(self):
+        p = [C.c_void_p(0) for _ in range(4)]
+        self._check(self.L.pfp_bwt_device_ptrs(self.h, *[C.byref(x) for x in p]))
+        return [x.value for x in p]
+
+    # ---- instrumentation
+    def profile_enable(self, on=True):
+        self._check(self.L.pfp_profile_enable(self.h, 1 if on else 0))
+
+    def profile_reset(self):
+        self._check(self.L.pfp_profile_reset(self.h))
+
+    def profile(self):
+        rows, i = [], 0
+        while True:
+            name, n, ms, by = C.c_char_p(), C.c_uint64(), C.c_double(), C.c_double()
+            if self.L.pfp_profile_get(self.h, i, C.byref(name), C.byref(n), C.byref(ms), C.byref(by)) != PFP_OK:
+                break
+            if n.value:
+                rows.append({"kernel": name.value.decode(), "launches": n.value, "ms": ms.value, "bytes": by.value})
+            i += 1
+        return rows
+
+    def stage_ms(self):
+        a = (C.c_double * 3)()
+        self._check(self.L.pfp_stage_ms(self.h, a))
+        return {"parse_finalize": a[0], "parse_bwt": a[1], "bwt_build": a[2]}
+
+    def backend(self):
+        return self.L.pfp_backend().decode()
+
+
+def sacak_int(s, k, u64=False, lib=None):
+    """Drop-in for sacak_int (gsa/gsacak.h:88): suffix array of an integer string ending in a unique 0."""
+    L = load_library(lib)
+    s = np.ascontiguousarray(s, np.uint32)
+    SA = np.empty(s.size, np.uint64 if u64 else np.uint32)
+    fn = L.pfp_sacak_int_u64 if u64 else L.pfp_sacak_int_u32
+    r = fn(_ptr(s), _ptr(SA), s.size, int(k))
+    if r < 0:
+        raise PfpError(r, "sacak_int failed")
+    return SA, r

@@ -1,0 +1,212 @@
+/*
+ * tests/emu/hip/hip_runtime.h -- TEST-ONLY debugging harness, NOT a backend and NOT product code.
+ *
+ * A tiny fiber-based interpreter of the HIP execution model, good enough to run the kernels of
+ * pfbwt-f_amd/csrc/ *.hip on the CPU of the build container (which has no GPU) at toy sizes, so that
+ * indexing / synchronisation mistakes are found before spending GPU minutes.  It is injected with
+ * `g++ -I tests/emu` when building tests/emu/build/libpfbwt_emu.so; the product library
+ * (pfbwt-f_amd/lib/libpfbwt_hip.so, built by hipcc for gfx950) never sees this file, the python
+ * package never loads the emu library, and no parity claim rests on it.
+ *
+ * Model: one workgroup at a time; each work-item is a ucontext fiber; __syncthreads() and the wave64
+ * cross-lane builtins are rendezvous points.  A kernel that would deadlock on the GPU (divergent
+ * barrier) aborts here with a message.
+ */
+#ifndef PFBWT_EMU_HIP_RUNTIME_H
+#define PFBWT_EMU_HIP_RUNTIME_H
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <chrono>
+#include <ucontext.h>
+#include <vector>
+#include <functional>
+
+#define __global__
+#define __device__
+#define __host__
+#define __shared__ static
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __restrict__ __restrict
+#define __constant__ static
+
+struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
+struct uint2 { unsigned x, y; };
+struct uint4 { unsigned x, y, z, w; };
+static inline uint4 make_uint4(unsigned a, unsigned b, unsigned c, unsigned d) { uint4 r = {a, b, c, d}; return r; }
+static inline uint2 make_uint2(unsigned a, unsigned b) { uint2 r = {a, b}; return r; }
+
+typedef int hipError_t;
+typedef struct emu_stream_s *hipStream_t;
+typedef struct emu_event_s { double t; } *hipEvent_t;
+enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1 };
+enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
+#define hipStreamNonBlocking 1
+#define hipHostMallocDefault 0
+
+namespace emu {
+struct State {
+    dim3 tid, bid, bdim, gdim;
+    int cur = -1;               // running fiber
+    int nthreads = 0;
+    ucontext_t sched;
+    std::vector<ucontext_t> ctx;
+    std::vector<char *> stacks;
+    std::vector<int> st;        // 0 ready, 1 at block barrier, 2 done, 3 at wave rendezvous
+    std::vector<uint64_t> lane_val;
+    std::vector<int> lane_pred;
+    std::function<void()> body;
+};
+inline State &S() { static State s; return s; }
+
+inline void yield_to_sched() { State &s = S(); int me = s.cur; swapcontext(&s.ctx[me], &s.sched); }
+inline void fiber_main() { State &s = S(); s.body(); s.st[s.cur] = 2; swapcontext(&s.ctx[s.cur], &s.sched); }
+
+inline void set_tid(int t) { State &s = S(); s.cur = t; s.tid.x = t % s.bdim.x; s.tid.y = (t / s.bdim.x) % s.bdim.y; s.tid.z = t / (s.bdim.x * s.bdim.y); }
+
+inline void run_block()
+{
+    State &s = S();
+    const size_t STK = 256 * 1024;
+    int T = s.nthreads;
+    if ((int)s.ctx.size() < T) { s.ctx.resize(T); s.st.resize(T); s.lane_val.resize(T); s.lane_pred.resize(T); }
+    while ((int)s.stacks.size() < T) s.stacks.push_back((char *)malloc(STK));
+    for (int t = 0; t < T; ++t) {
+        getcontext(&s.ctx[t]);
+        s.ctx[t].uc_stack.ss_sp = s.stacks[t]; s.ctx[t].uc_stack.ss_size = STK; s.ctx[t].uc_link = &s.sched;
+        makecontext(&s.ctx[t], (void (*)())fiber_main, 0);
+        s.st[t] = 0;
+    }
+    for (;;) {
+        bool progress = false; int done = 0;
+        for (int t = 0; t < T; ++t) {
+            if (s.st[t] == 0) { set_tid(t); swapcontext(&s.sched, &s.ctx[t]); progress = true; }
+        }
+        // block barrier release
+        int at_bar = 0; done = 0;
+        for (int t = 0; t < T; ++t) { at_bar += s.st[t] == 1; done += s.st[t] == 2; }
+        if (done == T) break;
+        if (at_bar && at_bar + done == T) { for (int t = 0; t < T; ++t) if (s.st[t] == 1) s.st[t] = 0; progress = true; }
+        // wave rendezvous release
+        for (int w0 = 0; w0 < T; w0 += 64) {
+            int w1 = w0 + 64 < T ? w0 + 64 : T, at = 0, dn = 0;
+            for (int t = w0; t < w1; ++t) { at += s.st[t] == 3; dn += s.st[t] == 2; }
+            if (at && at + dn == w1 - w0) { for (int t = w0; t < w1; ++t) if (s.st[t] == 3) s.st[t] = 4; progress = true; }
+        }
+        // state 4 = wave released: all lanes may now read peers' deposits; flip to ready
+        for (int t = 0; t < T; ++t) if (s.st[t] == 4) s.st[t] = 0;
+        if (!progress) {
+            fprintf(stderr, "[emu] deadlock in block (%u,%u): states:", s.bid.x, s.bid.y);
+            for (int t = 0; t < T && t < 64; ++t) fprintf(stderr, " %d", s.st[t]);
+            fprintf(stderr, "\n"); abort();
+        }
+    }
+}
+
+inline void block_barrier() { State &s = S(); s.st[s.cur] = 1; yield_to_sched(); }
+inline void wave_sync() { State &s = S(); s.st[s.cur] = 3; yield_to_sched(); }
+
+template <typename F> inline void launch(dim3 grid, dim3 block, F f)
+{
+    State &s = S();
+    s.gdim = grid; s.bdim = block; s.nthreads = (int)(block.x * block.y * block.z);
+    s.body = f;
+    for (unsigned bz = 0; bz < grid.z; ++bz) for (unsigned by = 0; by < grid.y; ++by) for (unsigned bx = 0; bx < grid.x; ++bx) {
+        s.bid = dim3(bx, by, bz);
+        run_block();
+    }
+}
+inline int lane() { return S().cur & 63; }
+inline int wave_base() { return S().cur & ~63; }
+inline int wave_end() { State &s = S(); int e = wave_base() + 64; return e < s.nthreads ? e : s.nthreads; }
+} // namespace emu
+
+#define threadIdx (emu::S().tid)
+#define blockIdx (emu::S().bid)
+#define blockDim (emu::S().bdim)
+#define gridDim (emu::S().gdim)
+#define warpSize 64
+
+static inline void __syncthreads() { emu::block_barrier(); }
+static inline void __threadfence() {}
+static inline void __threadfence_block() {}
+
+// ---- wave64 cross-lane: every live lane of the wave must call (no divergence) -------------
+static inline unsigned long long __ballot(int pred)
+{
+    emu::State &s = emu::S(); int me = s.cur;
+    s.lane_pred[me] = pred ? 1 : 0; emu::wave_sync();
+    unsigned long long m = 0; int b = emu::wave_base(), e = emu::wave_end();
+    for (int t = b; t < e; ++t) if (s.st[t] != 2 && s.lane_pred[t]) m |= 1ULL << (t - b);
+    emu::wave_sync();
+    (void)me; return m;
+}
+static inline int __any(int p) { return __ballot(p) != 0; }
+static inline int __all(int p) { emu::State &s = emu::S(); unsigned long long live = 0; int b = emu::wave_base(), e = emu::wave_end(); unsigned long long m = __ballot(p); for (int t = b; t < e; ++t) if (s.st[t] != 2) live |= 1ULL << (t - b); return m == live; }
+template <typename T> static inline T emu_shfl_from(T v, int src)
+{
+    emu::State &s = emu::S(); int me = s.cur;
+    static_assert(sizeof(T) <= 8, "shfl payload");
+    uint64_t raw = 0; memcpy(&raw, &v, sizeof(T)); s.lane_val[me] = raw; emu::wave_sync();
+    int b = emu::wave_base(); int e = emu::wave_end();
+    uint64_t got = (src >= 0 && b + src < e) ? s.lane_val[b + src] : raw;
+    emu::wave_sync();
+    T r; memcpy(&r, &got, sizeof(T)); return r;
+}
+template <typename T> static inline T __shfl(T v, int src, int width = 64) { int l = emu::lane(); int base = l & ~(width - 1); return emu_shfl_from(v, base + (src & (width - 1))); }
+template <typename T> static inline T __shfl_up(T v, unsigned d, int width = 64) { int l = emu::lane(); int base = l & ~(width - 1); int src = l - (int)d; return emu_shfl_from(v, src < base ? l : src); }
+template <typename T> static inline T __shfl_down(T v, unsigned d, int width = 64) { int l = emu::lane(); int base = l & ~(width - 1); int src = l + (int)d; return emu_shfl_from(v, src >= base + width ? l : src); }
+template <typename T> static inline T __shfl_xor(T v, int m, int width = 64) { int l = emu::lane(); (void)width; return emu_shfl_from(v, l ^ m); }
+
+static inline int __popc(unsigned x) { return __builtin_popcount(x); }
+static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+static inline int __clz(int x) { return x ? __builtin_clz((unsigned)x) : 32; }
+static inline int __clzll(long long x) { return x ? __builtin_clzll((unsigned long long)x) : 64; }
+static inline int __ffs(int x) { return __builtin_ffs(x); }
+static inline int __ffsll(long long x) { return __builtin_ffsll(x); }
+static inline unsigned long long __umul64hi(unsigned long long a, unsigned long long b) { return (unsigned long long)(((unsigned __int128)a * b) >> 64); }
+static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((uint64_t)a * b) >> 32); }
+
+// ---- atomics (fibers are cooperative: plain RMW is atomic) --------------------------------
+template <typename T> static inline T atomicAdd(T *p, T v) { T o = *p; *p = o + v; return o; }
+template <typename T> static inline T atomicMax(T *p, T v) { T o = *p; if (v > o) *p = v; return o; }
+template <typename T> static inline T atomicMin(T *p, T v) { T o = *p; if (v < o) *p = v; return o; }
+template <typename T> static inline T atomicOr(T *p, T v) { T o = *p; *p = o | v; return o; }
+template <typename T> static inline T atomicExch(T *p, T v) { T o = *p; *p = v; return o; }
+template <typename T> static inline T atomicCAS(T *p, T c, T v) { T o = *p; if (o == c) *p = v; return o; }
+
+// ---- host runtime ---------------------------------------------------------------------------
+static inline hipError_t hipMalloc(void **p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+template <typename T> static inline hipError_t hipMalloc(T **p, size_t n) { return hipMalloc((void **)p, n); }
+static inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
+static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned = 0) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+template <typename T> static inline hipError_t hipHostMalloc(T **p, size_t n, unsigned f = 0) { return hipHostMalloc((void **)p, n, f); }
+static inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
+static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t = 0) { memmove(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemset(void *d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t = 0) { memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipStreamCreate(hipStream_t *s) { *s = 0; return hipSuccess; }
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = 0; return hipSuccess; }
+static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
+static inline hipError_t hipGetDeviceCount(int *d) { *d = 1; return hipSuccess; }
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipPeekAtLastError() { return hipSuccess; }
+static inline const char *hipGetErrorString(hipError_t) { return "emu"; }
+static inline hipError_t hipMemGetInfo(size_t *f, size_t *t) { *f = *t = (size_t)8 << 30; return hipSuccess; }
+static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = new emu_event_s{0}; return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = 0) { e->t = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t - a->t); return hipSuccess; }
+
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+    emu::launch(dim3(grid), dim3(block), [=]() { kernel(__VA_ARGS__); })
+
+#endif
