@@ -361,10 +361,12 @@ static int suff_cmp(const void *a, const void *b)
     return x < y ? -1 : (x > y);
 }
 
-int64_t orc_bwt(const uint8_t *dict, uint64_t dsize, const uint64_t *occ, uint64_t dwords,
+static int sidx_cmp(const void *a, const void *b) { sidx x = *(const sidx *)a, y = *(const sidx *)b; return x < y ? -1 : (x > y); }
+
+static int64_t orc_bwt_impl(const uint8_t *dict, uint64_t dsize, const uint64_t *occ, uint64_t dwords,
                 const uint8_t *bwlast, const uint64_t *ilist, const uint64_t *bwsai, uint64_t nrows,
                 int w, int U, uint8_t *bwt, uint64_t *sa_raw,
-                uint64_t *easy_cases, uint64_t *hard_cases)
+                uint64_t *easy_cases, uint64_t *hard_cases, uint64_t *gsa_out, uint64_t *lcp_out)
 {
     sidx *T, *gsa, *rank, *lcp;
     uint32_t *wid;        /* dict offset -> word index (role of dict_idx.rank, pfbwt.hpp:83-85) */
@@ -405,6 +407,24 @@ int64_t orc_bwt(const uint8_t *dict, uint64_t dsize, const uint64_t *occ, uint64
             } else h = 0;
         }
     }
+    /* gsacak orders byte-identical suffixes of different words by position (separator i < separator j
+     * for i < j, gsa/gsacak.c:877-912) and its LCP stops at the separator; the plain suffix sort above
+     * orders them by what follows the separator.  The emission is sensitive to WHICH member of such a
+     * group comes first (pfbwt.hpp:116 vs :129), so restore gsacak's order and LCP values here. */
+    for (i = 1; i < dsize;) {
+        uint64_t g = (uint64_t)gsa[i], sl = (dict[g] == ORC_ENDOFDICT) ? 0 : wend[wid[g]] - g, j = i + 1, x;
+        while (j < dsize && (uint64_t)lcp[j] >= sl + 1) ++j;
+        if (j - i > 1) {
+            /* insertion sort by position (groups are small) or qsort for big ones */
+            if (j - i > 32) qsort(gsa + i, (size_t)(j - i), sizeof(sidx), sidx_cmp);
+            else for (x = i + 1; x < j; ++x) { sidx v = gsa[x]; uint64_t y = x; while (y > i && gsa[y - 1] > v) { gsa[y] = gsa[y - 1]; --y; } gsa[y] = v; }
+            for (x = i + 1; x < j; ++x) lcp[x] = (sidx)sl;
+        }
+        i = j;
+    }
+    if (gsa_out) for (i = 0; i < dsize; ++i) gsa_out[i] = (uint64_t)gsa[i];
+    if (lcp_out) for (i = 0; i < dsize; ++i) lcp_out[i] = (uint64_t)lcp[i];
+    if (!bwt) { free(T); free(gsa); free(rank); free(lcp); free(wid); free(wend); free(F); return 0; }
     F[0] = 1;                                                     /* ilist[0] is the EOS row */
     for (k = 1; k <= dwords; ++k) F[k] = F[k - 1] + occ[k - 1];
 
@@ -452,6 +472,22 @@ int64_t orc_bwt(const uint8_t *dict, uint64_t dsize, const uint64_t *occ, uint64
     free(T); free(gsa); free(rank); free(lcp); free(wid); free(wend); free(F);
     free(suffs); free(chars); free(words);
     return (int64_t)pos;
+}
+
+int64_t orc_bwt(const uint8_t *dict, uint64_t dsize, const uint64_t *occ, uint64_t dwords,
+                const uint8_t *bwlast, const uint64_t *ilist, const uint64_t *bwsai, uint64_t nrows,
+                int w, int U, uint8_t *bwt, uint64_t *sa_raw, uint64_t *easy_cases, uint64_t *hard_cases)
+{
+    return orc_bwt_impl(dict, dsize, occ, dwords, bwlast, ilist, bwsai, nrows, w, U, bwt, sa_raw, easy_cases, hard_cases, NULL, NULL);
+}
+
+/* gSA + gLCP of a .dict image exactly as gsacak(s, SA, LCP, NULL, n) returns them (gsa/gsacak.c:2504-2524) */
+int orc_gsa_lcp(const uint8_t *dict, uint64_t dsize, uint64_t dwords, uint64_t *gsa, uint64_t *lcp)
+{
+    uint64_t *occ = (uint64_t *)calloc((size_t)dwords + 1, sizeof(uint64_t));
+    int64_t r = orc_bwt_impl(dict, dsize, occ, dwords, NULL, NULL, NULL, 0, 0, 8, NULL, NULL, NULL, NULL, gsa, lcp);
+    free(occ);
+    return (int)r;
 }
 
 /* src/pfbwt-f.cpp:298-320 (out_fn), 325-328 (final run end) */

@@ -73,6 +73,10 @@ int64_t orc_bwt(const uint8_t *dict, uint64_t dsize, const uint64_t *occ, uint64
                 int w, int U, uint8_t *bwt, uint64_t *sa_raw,
                 uint64_t *easy_cases, uint64_t *hard_cases);
 
+/* gSA and gLCP of a .dict image with gsacak's conventions (ties by position, LCP stops at the
+ * separator), for pinning against oracle/_ref/libgsacak*.so */
+int orc_gsa_lcp(const uint8_t *dict, uint64_t dsize, uint64_t dwords, uint64_t *gsa, uint64_t *lcp);
+
 /* src/pfbwt-f.cpp:298-320,325-328: the CLI's out_fn.  sa_out (n+1) gets row 0 := n; ssa/esa get
  * (row, sa) pairs (2*r values each; caller allocates 2*(n+1)).  U = 4 or 8 gives the wrap width of
  * the raw values.  Returns r. */

@@ -124,19 +124,32 @@ template <typename SAT> __global__ __launch_bounds__(BLOCK) void k_emit(EmitArgs
     const uint32_t g0 = a.grank[x];                            // first slot of the group of equal suffixes
     uint64_t pos = o;
     const bool multi = (i != g0) || (i + 1 < a.dsize && a.grank[a.SA[i + 1]] == g0);
+    const bool self_full = (x == a.ws[id]);
+    bool full_emits_eow = false;
     if (multi) {                                               // pfbwt.hpp:137-181: merge by ilist position
+        // gsacak puts byte-identical suffixes in dictionary-position order, i.e. by word rank.  The
+        // reference's loop starts at the FIRST member: if that one is a whole word it is emitted alone
+        // (:116-128) and the rest forms its own group; otherwise all members are merged by ilist
+        // position and a whole-word member contributes dict[gsa-1] == EndOfWord as its BWT byte (:140).
         uint64_t before = 0;
+        uint32_t first_rk = rk, first_before = 0, first_occ = a.occ[rk]; bool first_full = self_full;
         for (uint32_t s = g0; s < a.dsize; ++s) {
             const uint32_t xs = a.SA[s];
             if (a.grank[xs] != g0) break;
             if (s == i) continue;
-            const uint32_t rs = word_rank_of(a, a.wordid[xs]);
-            before += lower_bound_u32(a.ilist + a.F[rs], a.occ[rs], q);
+            const uint32_t ids = a.wordid[xs];
+            const uint32_t rs = word_rank_of(a, ids);
+            const uint32_t oc = a.occ[rs];
+            const uint32_t lb = lower_bound_u32(a.ilist + a.F[rs], oc, q);
+            before += lb;
+            if (rs < first_rk) { first_rk = rs; first_before = lb; first_occ = oc; first_full = (xs == a.ws[ids]); }
         }
-        pos = (uint64_t)a.EB[g0] + before + r;
+        const uint64_t gb = a.EB[g0];
+        if (first_full) pos = (first_rk == rk) ? gb + r : gb + first_occ + (before - first_before) + r;
+        else { pos = gb + before + r; full_emits_eow = self_full; }
     }
     uint8_t c;
-    if (x == a.ws[id]) c = a.bwlast[q];                         // whole word, pfbwt.hpp:116-128
+    if (self_full) c = full_emits_eow ? EndOfWord : a.bwlast[q];   // whole word, pfbwt.hpp:116-128
     else { c = a.D[x - 1]; if (c == Dollar && x - 1 == a.ws[id]) c = 0; }   // :132 "gsa[i]-1 ? dict[..] : 0"
     bwt[pos] = c;
     if (sa) {

@@ -1,0 +1,61 @@
+"""CPU tests of the host orchestration and kernel logic through tests/emu (a fiber interpreter of the
+HIP execution model -- a debugging harness for a container without a GPU, NOT a backend: the product
+never loads it and no parity claim rests on it; the parity tests proper are tests/test_gpu_parity.py)."""
+import os
+import subprocess
+import numpy as np
+import pytest
+from pfp_testlib import EMU_SO, ROOT, compare, engine_run, golden_case, images, oracle_run, sha
+
+
+@pytest.fixture(scope="module")
+def emu_factory():
+    subprocess.run(["make", "-C", os.path.join(ROOT, "pfbwt-f_amd"), "emu"], check=True, stdout=subprocess.DEVNULL)
+    import pfbwt_hip
+    assert pfbwt_hip.load_library(EMU_SO).pfp_backend().decode() == "cpu-emu-TEST-ONLY"
+    return lambda **kw: pfbwt_hip.PfpContext(lib=EMU_SO, **kw)
+
+
+@pytest.mark.parametrize("name,U", [("edge", 8), ("edge", 4), ("w4p7", 8), ("mult_chroms_fa", 4)])
+def test_emu_pipeline_matches_oracle_and_reference_digests(emu_factory, name, U):
+    man, recs = golden_case(name)
+    seqs = [s for _, s in recs]
+    ref = oracle_run(seqs, w=man["w"], p=man["p"], U=U)
+    res = engine_run(emu_factory, seqs, man["w"], man["p"], U)
+    assert compare(res, ref, U) == []
+    mf = man["files"]["u%d" % (U * 8)]
+    for k, img in images(res, U).items():
+        assert sha(img) == mf[k]["sha256"], k
+
+
+def test_emu_pfbwt_only_path(emu_factory):
+    """--pfbwt-only: stage 2 from the on-disk arrays alone (pfp_bwt_load)."""
+    man, recs = golden_case("w4p7")
+    ref = oracle_run([s for _, s in recs], w=man["w"], p=man["p"], U=8)
+    ctx = emu_factory(w=man["w"], p=man["p"], u64=True)
+    ctx.bwt_load(ref["dict"], ref["occ"], ref["bwlast"], ref["ilist"], ref["bwsai"], n_hint=ref["n"])
+    b = ctx.bwt_build(sa=True, rssa=True)
+    out = ctx.bwt_get()
+    ctx.close()
+    assert b.nout == ref["n"] + 1 and b.r == ref["r"]
+    for k in ("bwt", "sa", "ssa", "esa"):
+        assert np.array_equal(out[k].astype(np.uint64), ref[k]), k
+
+
+def test_emu_error_paths(emu_factory):
+    import pfbwt_hip
+    ctx = emu_factory(w=4, p=5)
+    ctx.feed(b"ACGTRACGTACGTACGTACGT")
+    with pytest.raises(pfbwt_hip.PfpError) as e:
+        ctx.finalize()
+    assert e.value.status == pfbwt_hip.E_INVALID_CHAR and e.value.pos == 4 and e.value.ch == ord("R")
+    ctx.close()
+    with pytest.raises(pfbwt_hip.PfpError):
+        emu_factory(w=33, p=100)
+    ctx = emu_factory(w=10, p=100)
+    ctx.feed(b"ACGTACGTAAAA")                     # no trigger: one phrase
+    ctx.finalize()
+    with pytest.raises(pfbwt_hip.PfpError) as e:
+        ctx.parse_bwt()
+    assert e.value.status == pfbwt_hip.E_ONE_WORD
+    ctx.close()
