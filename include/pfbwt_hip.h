@@ -109,6 +109,8 @@ int pfp_sacak_int_u64(const uint32_t *s, uint64_t *SA, uint64_t n, uint64_t k);
 /* ---- instrumentation ---------------------------------------------------------------------------- */
 /* per-kernel timing with hipEvents on the context's stream (off by default) */
 int pfp_profile_enable(pfp_ctx *ctx, int on);
+/* time only the launches of one kernel (name as reported by pfp_profile_get); keeps event overhead out of a timed run */
+int pfp_profile_select(pfp_ctx *ctx, const char *kernel_name);
 int pfp_profile_reset(pfp_ctx *ctx);
 /* idx-th record: kernel name, launches, total ms, algorithmic bytes; returns 0 or PFP_E_ARG past the end */
 int pfp_profile_get(pfp_ctx *ctx, int idx, const char **name, uint64_t *launches, double *ms, double *bytes);

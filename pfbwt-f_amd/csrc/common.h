@@ -96,7 +96,7 @@ struct pfp_ctx {
     bool have_sa = false, have_rssa = false;
     size_t lo_after_parse = 0, lo_after_pbwt = 0;
     // --- instrumentation
-    bool prof_on = false;
+    bool prof_on = false; uint64_t prof_mask = ~0ULL;
     pfp::ProfRec prof[pfp::K_COUNT_];
     struct PendingEv { hipEvent_t a, b; int id; double bytes; };
     std::vector<PendingEv> pending;
@@ -125,14 +125,15 @@ inline void prof_collect(pfp_ctx *c)
     c->pending.clear();
 }
 struct ProfScope {
-    pfp_ctx *c; int id; double bytes; hipEvent_t a = nullptr;
+    pfp_ctx *c; int id; double bytes; hipEvent_t a = nullptr; bool on = false;
     ProfScope(pfp_ctx *c_, int id_, double bytes_) : c(c_), id(id_), bytes(bytes_)
     {
-        if (c->prof_on) { a = ev_get(c); (void)hipEventRecord(a, c->stream); }
+        on = c->prof_on && ((c->prof_mask >> id) & 1ULL);
+        if (on) { a = ev_get(c); (void)hipEventRecord(a, c->stream); }
     }
     ~ProfScope()
     {
-        if (c->prof_on) {
+        if (on) {
             hipEvent_t b = ev_get(c); (void)hipEventRecord(b, c->stream);
             c->pending.push_back({a, b, id, bytes});
             if (c->pending.size() > 4096) prof_collect(c);

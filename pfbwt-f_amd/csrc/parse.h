@@ -167,29 +167,69 @@ __global__ __launch_bounds__(BLOCK) void k_phrase_hash(const uint8_t *Y, const u
     keys[j] = addmod61(mulmod61(h, B), len % P61);
 }
 
-// one workgroup per long phrase: every thread hashes one chunk, thread 0 folds the chunks
-__global__ __launch_bounds__(BLOCK) void k_phrase_hash_long(const uint8_t *Y, const uint32_t *ye, int w, uint64_t B,
-                                                            const uint32_t *longlist, uint64_t *keys)
+// ---- long phrases (e.g. a 10 Mbp run of N is ONE phrase: wang_hash(0) % 100 != 0) ----
+// A host-built chunk table spreads every long phrase over workgroups of LONG_CHUNK bytes.
+constexpr uint32_t LONG_CHUNK = 16384;
+struct LongChunk { uint32_t item; uint32_t a_off, b_off; uint32_t len; }; // item index, two Y offsets of the chunk, chunk length
+
+// spans of listed phrases: out[2k] = ys, out[2k+1] = len
+__global__ __launch_bounds__(BLOCK) void k_list_spans(const uint32_t *ye, int w, const uint32_t *list, uint32_t cnt, uint32_t *out)
+{
+    const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
+    if (k >= cnt) return;
+    uint32_t ys, len; phrase_span(ye, list[k], w, &ys, &len);
+    out[2 * k] = ys; out[2 * k + 1] = len;
+}
+// same for the two phrases of each listed sorted position i: (vals[i-1], vals[i]); out[3k..] = ys_a, ys_b, len
+__global__ __launch_bounds__(BLOCK) void k_pair_spans(const uint32_t *ye, int w, const uint32_t *vals, const uint32_t *list, uint32_t cnt, uint32_t *out)
+{
+    const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
+    if (k >= cnt) return;
+    const uint32_t i = list[k];
+    uint32_t sa_, la, sb, lb;
+    phrase_span(ye, vals[i - 1], w, &sa_, &la);
+    phrase_span(ye, vals[i], w, &sb, &lb);
+    out[3 * k] = sa_; out[3 * k + 1] = sb; out[3 * k + 2] = la;
+}
+// one workgroup per chunk: polynomial hash of Y[a_off .. a_off+len)
+__global__ __launch_bounds__(BLOCK) void k_phrase_hash_long(const uint8_t *Y, const LongChunk *chunks, uint64_t B, uint64_t *partial)
 {
     __shared__ uint64_t part[BLOCK];
-    const uint32_t j = longlist[blockIdx.x];
-    uint32_t ys, len; phrase_span(ye, j, w, &ys, &len);
-    const uint32_t chunk = (len + BLOCK - 1) / BLOCK;
-    const uint32_t a = threadIdx.x * chunk, b = (a + chunk < len) ? a + chunk : len;
+    const LongChunk ch = chunks[blockIdx.x];
+    const uint32_t sub = (ch.len + BLOCK - 1) / BLOCK;
+    const uint32_t a = threadIdx.x * sub, b = (a + sub < ch.len) ? a + sub : ch.len;
     uint64_t h = 0;
-    for (uint32_t i = a; i < b; ++i) h = addmod61(mulmod61(h, B), Y[ys + i]);
+    for (uint32_t i = a; i < b; ++i) h = addmod61(mulmod61(h, B), Y[ch.a_off + i]);
     part[threadIdx.x] = h;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const uint64_t Bc = powmod61(B, chunk);
+        const uint64_t Bc = powmod61(B, sub);
         uint64_t acc = 0;
         for (uint32_t t = 0; t < BLOCK; ++t) {
-            const uint32_t ta = t * chunk; if (ta >= len) break;
-            const uint32_t tl = (ta + chunk < len ? ta + chunk : len) - ta;
-            acc = addmod61(mulmod61(acc, tl == chunk ? Bc : powmod61(B, tl)), part[t]);
+            const uint32_t ta = t * sub; if (ta >= ch.len) break;
+            const uint32_t tl = (ta + sub < ch.len ? ta + sub : ch.len) - ta;
+            acc = addmod61(mulmod61(acc, tl == sub ? Bc : powmod61(B, tl)), part[t]);
         }
-        keys[j] = addmod61(mulmod61(acc, B), len % P61);
+        partial[blockIdx.x] = acc;
     }
+}
+// one thread per long phrase folds its chunks (consecutive in the table, first chunk index in first[])
+__global__ __launch_bounds__(BLOCK) void k_phrase_hash_fold(const LongChunk *chunks, const uint32_t *first, const uint32_t *longlist, uint32_t nlong,
+                                                            const uint32_t *spans, const uint64_t *partial, uint64_t B, uint64_t *keys)
+{
+    const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
+    if (k >= nlong) return;
+    uint64_t acc = 0;
+    for (uint32_t c = first[k]; c < first[k + 1]; ++c) acc = addmod61(mulmod61(acc, powmod61(B, chunks[c].len)), partial[c]);
+    keys[longlist[k]] = addmod61(mulmod61(acc, B), (uint64_t)spans[2 * k + 1] % P61);
+}
+// one workgroup per chunk of a long pair: byte compare
+__global__ __launch_bounds__(BLOCK) void k_dedup_long(const uint8_t *Y, const LongChunk *chunks, uint32_t *collide)
+{
+    const LongChunk ch = chunks[blockIdx.x];
+    uint32_t diff = 0;
+    for (uint32_t k = threadIdx.x; k < ch.len; k += BLOCK) diff |= (uint32_t)(Y[ch.a_off + k] ^ Y[ch.b_off + k]);
+    if (diff) atomicAdd(collide, 1u);
 }
 
 // After sorting (key, j): head[i] = 1 where a new distinct phrase starts.  Equal fingerprints are
@@ -211,18 +251,6 @@ __global__ __launch_bounds__(BLOCK) void k_dedup_heads(const uint8_t *Y, const u
     head[i] = 0;
     if (diff) { head[i] = 1; atomicAdd(collide, 1u); }
 }
-__global__ __launch_bounds__(BLOCK) void k_dedup_long(const uint8_t *Y, const uint32_t *ye, int w, const uint32_t *vals,
-                                                      const uint32_t *longpairs, uint32_t *collide)
-{
-    const uint32_t i = longpairs[blockIdx.x];
-    uint32_t sa_, la, sb, lb;
-    phrase_span(ye, vals[i - 1], w, &sa_, &la);
-    phrase_span(ye, vals[i], w, &sb, &lb);
-    uint32_t diff = 0;
-    for (uint32_t k = threadIdx.x; k < la; k += BLOCK) diff |= (uint32_t)(Y[sa_ + k] ^ Y[sb + k]);
-    if (diff) atomicAdd(collide, 1u);
-}
-
 __global__ __launch_bounds__(BLOCK) void k_dedup_ids(const uint32_t *head, uint32_t *ex, uint64_t m)
 {
     const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;

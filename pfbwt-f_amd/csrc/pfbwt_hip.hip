@@ -114,7 +114,14 @@ int pfp_error_detail(pfp_ctx *c, uint64_t *pos, int *ch)
 }
 uint64_t pfp_workspace_needed(pfp_ctx *c) { return c ? (uint64_t)(c->arena.cap + c->arena.want) : 0; }
 
-int pfp_profile_enable(pfp_ctx *c, int on) { if (!c) return PFP_E_ARG; prof_collect(c); c->prof_on = on != 0; return PFP_OK; }
+int pfp_profile_enable(pfp_ctx *c, int on) { if (!c) return PFP_E_ARG; prof_collect(c); c->prof_on = on != 0; c->prof_mask = ~0ULL; return PFP_OK; }
+int pfp_profile_select(pfp_ctx *c, const char *kernel)
+{
+    if (!c || !kernel) return PFP_E_ARG;
+    prof_collect(c);
+    for (int i = 0; i < K_COUNT_; ++i) if (!strcmp(kernel, kernel_names[i])) { c->prof_on = true; c->prof_mask = 1ULL << i; return PFP_OK; }
+    return PFP_E_ARG;
+}
 int pfp_profile_reset(pfp_ctx *c) { if (!c) return PFP_E_ARG; prof_collect(c); for (auto &r : c->prof) r = ProfRec(); return PFP_OK; }
 int pfp_profile_get(pfp_ctx *c, int idx, const char **name, uint64_t *launches, double *ms, double *bytes)
 {
@@ -165,6 +172,56 @@ static int sort_dict_suffixes(pfp_ctx *c)
     PFP_TRY(suffix_sort_doubling(c, N, k0, v0, k1, v1, &full, 1, DK_CHARS, c->d_ws, c->d_wordid, c->d_gsa, c->d_grank, &rounds));
     c->arena.release_hi(mk);
     c->gsa_valid = true;
+    return PFP_OK;
+}
+
+// ---- long phrases: host-built chunk tables (phrases longer than LONG_PHRASE are rare) ----------------
+static int hash_long_phrases(pfp_ctx *c, const uint8_t *Y, const uint32_t *d_longlist, uint32_t nlong, uint64_t B, uint64_t *keys)
+{
+    const size_t mk = c->arena.mark_hi();
+    uint32_t *d_spans; PFP_ALLOC_HI(c, d_spans, uint32_t, 2 * (size_t)nlong);
+    PFP_LAUNCH(c, K_MISC, nlong * 16, k_list_spans, nblocks(nlong, BLOCK), (const uint32_t *)c->d_ye, c->w, d_longlist, nlong, d_spans);
+    std::vector<uint32_t> spans(2 * (size_t)nlong);
+    PFP_HIP(c, hipMemcpyAsync(spans.data(), d_spans, spans.size() * 4, hipMemcpyDeviceToHost, c->stream));
+    PFP_HIP(c, hipStreamSynchronize(c->stream));
+    std::vector<LongChunk> tab; std::vector<uint32_t> first(nlong + 1);
+    for (uint32_t k = 0; k < nlong; ++k) {
+        first[k] = (uint32_t)tab.size();
+        const uint32_t ys = spans[2 * k], len = spans[2 * k + 1];
+        for (uint32_t a = 0; a < len; a += LONG_CHUNK) tab.push_back({k, ys + a, 0u, (len - a < LONG_CHUNK) ? len - a : LONG_CHUNK});
+    }
+    first[nlong] = (uint32_t)tab.size();
+    LongChunk *d_tab; uint32_t *d_first; uint64_t *d_part;
+    PFP_ALLOC_HI(c, d_tab, LongChunk, tab.size()); PFP_ALLOC_HI(c, d_first, uint32_t, first.size()); PFP_ALLOC_HI(c, d_part, uint64_t, tab.size());
+    PFP_HIP(c, hipMemcpyAsync(d_tab, tab.data(), tab.size() * sizeof(LongChunk), hipMemcpyHostToDevice, c->stream));
+    PFP_HIP(c, hipMemcpyAsync(d_first, first.data(), first.size() * 4, hipMemcpyHostToDevice, c->stream));
+    double bytes = 0; for (auto &t : tab) bytes += t.len;
+    PFP_LAUNCH(c, K_PHRASE_HASH_LONG, bytes, k_phrase_hash_long, (unsigned)tab.size(), Y, (const LongChunk *)d_tab, B, d_part);
+    PFP_LAUNCH(c, K_MISC, tab.size() * 24, k_phrase_hash_fold, nblocks(nlong, BLOCK), (const LongChunk *)d_tab, (const uint32_t *)d_first, d_longlist, nlong,
+               (const uint32_t *)d_spans, (const uint64_t *)d_part, B, keys);
+    PFP_HIP(c, hipStreamSynchronize(c->stream));   // tab / first are host vectors
+    c->arena.release_hi(mk);
+    return PFP_OK;
+}
+static int compare_long_pairs(pfp_ctx *c, const uint8_t *Y, const uint32_t *d_vals, const uint32_t *d_pairs, uint32_t np, uint32_t *d_collide)
+{
+    const size_t mk = c->arena.mark_hi();
+    uint32_t *d_spans; PFP_ALLOC_HI(c, d_spans, uint32_t, 3 * (size_t)np);
+    PFP_LAUNCH(c, K_MISC, np * 24, k_pair_spans, nblocks(np, BLOCK), (const uint32_t *)c->d_ye, c->w, d_vals, d_pairs, np, d_spans);
+    std::vector<uint32_t> spans(3 * (size_t)np);
+    PFP_HIP(c, hipMemcpyAsync(spans.data(), d_spans, spans.size() * 4, hipMemcpyDeviceToHost, c->stream));
+    PFP_HIP(c, hipStreamSynchronize(c->stream));
+    std::vector<LongChunk> tab;
+    for (uint32_t k = 0; k < np; ++k) {
+        const uint32_t sa_ = spans[3 * k], sb = spans[3 * k + 1], len = spans[3 * k + 2];
+        for (uint32_t a = 0; a < len; a += LONG_CHUNK) tab.push_back({k, sa_ + a, sb + a, (len - a < LONG_CHUNK) ? len - a : LONG_CHUNK});
+    }
+    LongChunk *d_tab; PFP_ALLOC_HI(c, d_tab, LongChunk, tab.size());
+    PFP_HIP(c, hipMemcpyAsync(d_tab, tab.data(), tab.size() * sizeof(LongChunk), hipMemcpyHostToDevice, c->stream));
+    double bytes = 0; for (auto &t : tab) bytes += 2.0 * t.len;
+    PFP_LAUNCH(c, K_DEDUP_LONG, bytes, k_dedup_long, (unsigned)tab.size(), Y, (const LongChunk *)d_tab, d_collide);
+    PFP_HIP(c, hipStreamSynchronize(c->stream));
+    c->arena.release_hi(mk);
     return PFP_OK;
 }
 
@@ -231,12 +288,12 @@ int pfp_parse_finalize(pfp_ctx *c, pfp_parse_sizes *out)
         PFP_HIP(c, hipMemsetAsync(d_u32, 0, 32, c->stream));
         PFP_LAUNCH(c, K_PHRASE_HASH, n + m * 12, k_phrase_hash, gm, Y, (const uint32_t *)c->d_ye, m, w, B, hk0, hv0, longlist, d_u32 + 1);
         uint32_t nlong = 0; PFP_TRY(d2h_u32(c, d_u32 + 1, &nlong));
-        if (nlong) PFP_LAUNCH(c, K_PHRASE_HASH_LONG, 0, k_phrase_hash_long, nlong, Y, (const uint32_t *)c->d_ye, w, B, (const uint32_t *)longlist, hk0);
+        if (nlong) PFP_TRY(hash_long_phrases(c, Y, longlist, nlong, B, hk0));
         BitRange full = {0, 64};
         PFP_TRY(radix_sort_pairs<uint64_t>(c, hk0, hv0, hk1, hv1, m, &full, 1, &sk, &sv));
         PFP_LAUNCH(c, K_DEDUP_HEADS, n + m * 16, k_dedup_heads, gm, Y, (const uint32_t *)c->d_ye, w, (const uint64_t *)sk, (const uint32_t *)sv, m, head, longpairs, d_u32 + 2, d_u32 + 3);
         uint32_t nlp = 0; PFP_TRY(d2h_u32(c, d_u32 + 2, &nlp));
-        if (nlp) PFP_LAUNCH(c, K_DEDUP_LONG, 0, k_dedup_long, nlp, Y, (const uint32_t *)c->d_ye, w, (const uint32_t *)sv, (const uint32_t *)longpairs, d_u32 + 3);
+        if (nlp) PFP_TRY(compare_long_pairs(c, Y, sv, longpairs, nlp, d_u32 + 3));
         uint32_t collide = 0; PFP_TRY(d2h_u32(c, d_u32 + 3, &collide));
         if (!collide) break;
     }

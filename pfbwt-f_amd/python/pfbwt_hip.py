@@ -65,6 +65,7 @@ def load_library(path=None):
     L.pfp_sacak_int_u64.argtypes = [vp, vp, u64, u64]
     L.pfp_profile_enable.argtypes = [vp, i32]
     L.pfp_profile_reset.argtypes = [vp]
+    L.pfp_profile_select.argtypes = [vp, C.c_char_p]
     L.pfp_profile_get.argtypes = [vp, i32, C.POINTER(C.c_char_p), C.POINTER(u64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.pfp_stage_ms.argtypes = [vp, C.POINTER(C.c_double)]
     _libs[path] = L
@@ -167,6 +168,9 @@ class PfpContext:
     # ---- instrumentation
     def profile_enable(self, on=True):
         self._check(self.L.pfp_profile_enable(self.h, 1 if on else 0))
+
+    def profile_select(self, kernel):
+        self._check(self.L.pfp_profile_select(self.h, kernel.encode()))
 
     def profile_reset(self):
         self._check(self.L.pfp_profile_reset(self.h))

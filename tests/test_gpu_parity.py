@@ -51,7 +51,7 @@ CASES = [
     (3, 50000, 3, 4, 7, (0, 0, 0, 0), 4),          # many short phrases, big multi-word groups
     (4, 60000, 2, 10, 100, (5000, 9000, 40000, 300), 4),   # N runs -> giant phrases, long LCPs
     (5, 200000, 10, 10, 100, (0, 0, 0, 0), 4),     # panel
-    (6, 100000, 2, 32, 50, (0, 0, 0, 0), 8),       # w = 32 (mask quirk of hash.hpp:26)
+    (6, 20000, 2, 32, 16, (0, 0, 0, 0), 8),        # w = 32: hash.hpp:26 mask quirk -> k-mer is always 0; p | wang_hash(0): every position triggers
     (7, 40000, 2, 1, 3, (0, 0, 0, 0), 4),          # w = 1
     (8, 4099, 1, 10, 100, (0, 0, 0, 0), 4),        # ragged size
 ]
