@@ -1,0 +1,123 @@
+// pfbwt-f_amd/host/include/pfbwtf_common.hpp -- shared bits of the host-side mirror of the reference
+// interface: uint_t / int_t / int_text (gsa/gsacak.h:44-64), special symbols and file extensions
+// (include/utils.h:8-31), die() (src/utils.c:13-17), and a FASTA/FASTQ record reader with the record
+// semantics of include/kseq.h:178-222 (gz or plain, "-" = stdin).
+#ifndef PFBWTF_COMMON_HPP
+#define PFBWTF_COMMON_HPP
+#include <cinttypes>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <zlib.h>
+#include "pfbwt_hip.h"
+
+#ifndef M64
+#define M64 0
+#endif
+#if M64
+typedef int64_t int_t;
+typedef uint64_t uint_t;
+#else
+typedef int32_t int_t;
+typedef uint32_t uint_t;
+#endif
+typedef uint32_t int_text;
+
+#ifndef Dollar
+#define Dollar 2
+#define EndOfWord 1
+#define EndOfDict 0
+#endif
+#define EXTPARSE "parse"
+#define EXTOCC "occ"
+#define EXTDICT "dict"
+#define EXTBWLST "bwlast"
+#define EXTBWSAI "bwsai"
+#define EXTILIST "ilist"
+#define EXTSA "sa"
+#define EXTSSA "ssa"
+#define EXTESA "esa"
+
+namespace pfbwtf {
+
+[[noreturn]] inline void die(const char *s) { perror(s); exit(1); }
+
+// engine status -> the reference's message + exit(1)
+inline void engine_check(pfp_ctx *ctx, int st, const char *what)
+{
+    if (st == PFP_OK) return;
+    if (st == PFP_E_INVALID_CHAR) {             // include/hash.hpp:31
+        uint64_t pos = 0; int ch = 0; pfp_error_detail(ctx, &pos, &ch);
+        fprintf(stderr, "error, invalid character %d/%c -> %d\n", ch, ch, 5);
+    } else if (st == PFP_E_TOO_LARGE) {
+        fprintf(stderr, "%s: input too long, please use 64-bit version: %s\n", what, pfp_strerror(st));   // pfparser.hpp:326-331
+    } else {
+        fprintf(stderr, "%s: %s\n", what, pfp_strerror(st));
+    }
+    exit(1);
+}
+
+struct FastaRecord { std::string name; std::string seq; };
+
+class FastaReader {
+  public:
+    explicit FastaReader(const std::string &fname)
+    {
+        fp_ = (fname == "-") ? gzdopen(fileno(stdin), "r") : gzopen(fname.c_str(), "r");
+        if (fp_ == NULL) die("failed to open file!\n");
+        gzbuffer(fp_, 1 << 20);
+    }
+    ~FastaReader() { if (fp_) gzclose(fp_); }
+    // next record; false at end of file.  FASTA and FASTQ ('@' headers, '+' quality) are accepted.
+    bool next(FastaRecord &r)
+    {
+        int c;
+        if (!pending_) { while ((c = getc_()) >= 0 && c != '>' && c != '@') {} if (c < 0) return false; }
+        pending_ = 0;
+        r.name.clear(); r.seq.clear();
+        // header line: name up to the first white space, rest is comment
+        bool in_name = true;
+        while ((c = getc_()) >= 0 && c != '\n') { if (in_name) { if (c == ' ' || c == '\t' || c == '\r') in_name = false; else r.name.push_back((char)c); } }
+        // sequence lines
+        bool line_start = true;
+        while ((c = getc_()) >= 0) {
+            if (line_start && (c == '>' || c == '@')) { pending_ = c; return true; }
+            if (line_start && c == '+') break;
+            if (c == '\n') { line_start = true; continue; }
+            line_start = false;
+            if (c != '\r') r.seq.push_back((char)c);
+        }
+        if (c == '+') {   // FASTQ: skip the '+' line, then as many quality characters as bases
+            while ((c = getc_()) >= 0 && c != '\n') {}
+            size_t q = 0;
+            while (q < r.seq.size() && (c = getc_()) >= 0) if (c != '\n' && c != '\r') ++q;
+        }
+        return true;
+    }
+
+  private:
+    int getc_()
+    {
+        if (pos_ == len_) { len_ = gzread(fp_, buf_, sizeof buf_); pos_ = 0; if (len_ <= 0) { len_ = 0; return -1; } }
+        return (unsigned char)buf_[pos_++];
+    }
+    gzFile fp_ = NULL;
+    char buf_[1 << 16];
+    int pos_ = 0, len_ = 0, pending_ = 0;
+};
+
+template <typename T> inline std::vector<T> read_vec(const std::string &path)
+{
+    FILE *fp = fopen(path.c_str(), "rb");
+    if (fp == NULL) { fprintf(stderr, "%s: ", path.c_str()); die("error opening file"); }
+    fseek(fp, 0, SEEK_END); size_t size = (size_t)ftell(fp); rewind(fp);
+    std::vector<T> v(size / sizeof(T));
+    if (v.size() && fread(v.data(), sizeof(T), v.size(), fp) != v.size()) { fprintf(stderr, "error reading from %s\n", path.c_str()); exit(1); }
+    fclose(fp);
+    return v;
+}
+
+} // namespace pfbwtf
+#endif
