@@ -215,12 +215,12 @@ __global__ __launch_bounds__(BLOCK) void k_phrase_hash_long(const uint8_t *Y, co
 }
 // one thread per long phrase folds its chunks (consecutive in the table, first chunk index in first[])
 __global__ __launch_bounds__(BLOCK) void k_phrase_hash_fold(const LongChunk *chunks, const uint32_t *first, const uint32_t *longlist, uint32_t nlong,
-                                                            const uint32_t *spans, const uint64_t *partial, uint64_t B, uint64_t *keys)
+                                                            const uint32_t *spans, const uint64_t *partial, uint64_t B, uint64_t Bchunk, uint64_t *keys)
 {
     const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
     if (k >= nlong) return;
     uint64_t acc = 0;
-    for (uint32_t c = first[k]; c < first[k + 1]; ++c) acc = addmod61(mulmod61(acc, powmod61(B, chunks[c].len)), partial[c]);
+    for (uint32_t c = first[k]; c < first[k + 1]; ++c) acc = addmod61(mulmod61(acc, chunks[c].len == LONG_CHUNK ? Bchunk : powmod61(B, chunks[c].len)), partial[c]);
     keys[longlist[k]] = addmod61(mulmod61(acc, B), (uint64_t)spans[2 * k + 1] % P61);
 }
 // one workgroup per chunk of a long pair: byte compare

@@ -169,7 +169,7 @@ static int sort_dict_suffixes(pfp_ctx *c)
     PFP_LAUNCH(c, K_SS_INIT_KEYS, N * 13, k_dict_init_keys, nblocks(N, DK_TILE), (const uint8_t *)c->d_dict, N, k0, v0);
     BitRange full = {0, 64};
     int rounds = 0;
-    PFP_TRY(suffix_sort_doubling(c, N, k0, v0, k1, v1, &full, 1, DK_CHARS, c->d_ws, c->d_wordid, c->d_gsa, c->d_grank, &rounds));
+    PFP_TRY(suffix_sort_doubling(c, N, k0, v0, k1, v1, &full, 1, DK_CHARS, c->d_ws, c->d_wordid, c->d_dict, c->d_gsa, c->d_grank, &rounds));
     c->arena.release_hi(mk);
     c->gsa_valid = true;
     return PFP_OK;
@@ -198,7 +198,7 @@ static int hash_long_phrases(pfp_ctx *c, const uint8_t *Y, const uint32_t *d_lon
     double bytes = 0; for (auto &t : tab) bytes += t.len;
     PFP_LAUNCH(c, K_PHRASE_HASH_LONG, bytes, k_phrase_hash_long, (unsigned)tab.size(), Y, (const LongChunk *)d_tab, B, d_part);
     PFP_LAUNCH(c, K_MISC, tab.size() * 24, k_phrase_hash_fold, nblocks(nlong, BLOCK), (const LongChunk *)d_tab, (const uint32_t *)d_first, d_longlist, nlong,
-               (const uint32_t *)d_spans, (const uint64_t *)d_part, B, keys);
+               (const uint32_t *)d_spans, (const uint64_t *)d_part, B, powmod61(B, LONG_CHUNK), keys);
     PFP_HIP(c, hipStreamSynchronize(c->stream));   // tab / first are host vectors
     c->arena.release_hi(mk);
     return PFP_OK;
@@ -388,7 +388,7 @@ static int sort_int_suffixes(pfp_ctx *c, const uint32_t *dS, uint64_t N, uint64_
     PFP_LAUNCH(c, K_SS_INIT_KEYS, N * 16, k_int_init_keys, nblocks(N, BLOCK), dS, N, k0, v0);
     const int sb = bits_for(maxsym);
     BitRange rr[2] = {{0, sb}, {32, 32 + sb}};
-    PFP_TRY(suffix_sort_doubling(c, N, k0, v0, k1, v1, rr, 2, 2, nullptr, nullptr, SA, rank, rounds));
+    PFP_TRY(suffix_sort_doubling(c, N, k0, v0, k1, v1, rr, 2, 2, nullptr, nullptr, nullptr, SA, rank, rounds));
     c->arena.release_hi(mk);
     return PFP_OK;
 }

@@ -84,10 +84,10 @@ __global__ __launch_bounds__(BLOCK) void k_ss_write_rank(const uint32_t *vals, c
     const uint64_t a = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (a < na) rank[vals[a]] = newrank[a];
 }
-// keep[a] = 1 while the class of element a still has to be refined with depth h
-// ws/wordid != nullptr selects dictionary semantics: a class whose common prefix already contains the
-// terminator (suff_len < h) is a group of identical suffixes and is final.
-__global__ __launch_bounds__(BLOCK) void k_ss_flag_active(const uint32_t *vals, const uint32_t *head, uint64_t na, uint32_t h,
+// keep[a] = 1 while the class of element a still has to be refined.
+// ws/wordid != nullptr selects dictionary semantics: a class whose covered prefix [x, jump[x]) already
+// contains the terminator is a group of byte-identical suffixes and is final.
+__global__ __launch_bounds__(BLOCK) void k_ss_flag_active(const uint32_t *vals, const uint32_t *head, uint64_t na, const uint32_t *jump,
                                                           const uint32_t *ws, const uint32_t *wordid, uint32_t *keep)
 {
     const uint64_t a = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -96,35 +96,82 @@ __global__ __launch_bounds__(BLOCK) void k_ss_flag_active(const uint32_t *vals, 
     bool fin = single;
     if (!fin && ws) {
         const uint32_t x = vals[a];
-        const uint32_t sl = ws[wordid[x] + 1] - 1u - x;   // distance to the EndOfWord of x's word
-        fin = sl < h;
+        const uint32_t term = ws[wordid[x] + 1] - 1u;     // offset of the EndOfWord of x's word
+        fin = jump[x] > term;
     }
     keep[a] = fin ? 0u : 1u;
 }
-__global__ __launch_bounds__(BLOCK) void k_ss_make_keys(const uint32_t *slots, const uint32_t *SA, const uint32_t *rank, uint64_t na, uint64_t N, uint32_t h,
-                                                        uint64_t *keys, uint32_t *vals)
+__global__ __launch_bounds__(BLOCK) void k_ss_init_jump(uint32_t *jump, uint64_t N, uint32_t h0)
+{
+    const uint64_t x = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (x < N) jump[x] = (uint32_t)(x + h0 < N ? x + h0 : N);
+}
+// Doubling with pointer jumping: rank[x] orders suffix x by its covered prefix [x, jump[x]); the next
+// key is (rank[x], rank[jump[x]]) and the covered prefix grows to [x, jump[jump[x]]).
+// Run round (M != nullptr, first refinement of a byte text): a suffix whose first RUN_MIN characters
+// are one repeated character c sits inside a run c^d; ordering such suffixes by plain doubling takes
+// log2(d) rounds with the whole run active (a 10 Mbp run of N: 20 rounds x 10 M suffixes).  Instead the
+// whole run is consumed at once: c^d a... is ordered among the suffixes starting with c by
+// t = d if a < c, 2^32-1-d if a > c  (a = first character after the run), and jump = x + d.
+constexpr uint32_t RUN_MIN = DK_CHARS;
+__global__ __launch_bounds__(BLOCK) void k_ss_make_keys(const uint32_t *slots, const uint32_t *SA, const uint32_t *rank, const uint32_t *jump, uint64_t na, uint64_t N,
+                                                        const uint8_t *D, const uint32_t *M, uint64_t *keys, uint32_t *vals, uint32_t *nj)
 {
     const uint64_t a = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (a >= na) return;
     const uint32_t x = SA[slots[a]];
-    const uint64_t y = (uint64_t)x + h;
-    keys[a] = ((uint64_t)rank[x] << 32) | (y < N ? rank[y] : 0u);
+    uint32_t low, nx;
+    bool run = false;
+    if (M) {
+        const uint32_t ip = (uint32_t)(N - 1 - x);
+        const uint32_t d = ip - M[ip] + 1u;                 // length of the run of D[x] that starts at x
+        if (d >= RUN_MIN && D[x] > EndOfWord) {
+            const uint64_t e = (uint64_t)x + d;
+            const uint8_t nxt = e < N ? D[e] : (uint8_t)0;
+            low = nxt < D[x] ? d : 0xFFFFFFFFu - d;
+            nx = (uint32_t)(e < N ? e : N);
+            run = true;
+        }
+    }
+    if (!run) {
+        const uint32_t y = jump[x];
+        low = y < N ? rank[y] : 0u;
+        nx = y < N ? jump[y] : (uint32_t)N;
+    }
+    keys[a] = ((uint64_t)rank[x] << 32) | low;
     vals[a] = x;
+    nj[a] = nx;
+}
+__global__ __launch_bounds__(BLOCK) void k_ss_apply_jump(const uint32_t *vals, const uint32_t *nj, uint64_t na, uint32_t *jump)
+{
+    const uint64_t a = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (a < na) jump[vals[a]] = nj[a];
+}
+// i' = N-1-x: g[i'] = i' where x is the last position of a run of equal bytes, else 0.  The inclusive
+// max-scan M of g gives, for every x, the nearest run end at or after x: runlen(x) = i' - M[i'] + 1.
+__global__ __launch_bounds__(BLOCK) void k_ss_runend_marks(const uint8_t *D, uint64_t N, uint32_t *g)
+{
+    const uint64_t ip = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (ip >= N) return;
+    const uint64_t x = N - 1 - ip;
+    g[ip] = (x + 1 == N || D[x] != D[x + 1]) ? (uint32_t)ip : 0u;
 }
 
 // Sorts the N suffixes described by (keys,vals) [already filled: keys = h0-character prefixes, vals = x].
-// Outputs SA (slot -> x) and rank (x -> slot of its class head).  ws/wordid as in k_ss_flag_active.
+// Outputs SA (slot -> x) and rank (x -> slot of its class head).  ws/wordid select dictionary semantics
+// (see k_ss_flag_active); D != nullptr additionally enables the run round (byte texts).
 // keys/vals and their twins k1/v1 (N entries each) are scratch owned by the caller.
 inline int suffix_sort_doubling(pfp_ctx *c, uint64_t N, uint64_t *k0, uint32_t *v0, uint64_t *k1, uint32_t *v1,
                                 const BitRange *init_ranges, int n_init_ranges, uint32_t h0,
-                                const uint32_t *ws, const uint32_t *wordid, uint32_t *SA, uint32_t *rank, int *rounds_out)
+                                const uint32_t *ws, const uint32_t *wordid, const uint8_t *D, uint32_t *SA, uint32_t *rank, int *rounds_out)
 {
     const size_t mk = c->arena.mark_hi();
-    uint32_t *head, *aux, *slots, *slots2, *d_cnt;
+    uint32_t *head, *aux, *slots, *slots2, *d_cnt, *jump, *nj, *M = nullptr;
     PFP_ALLOC_HI(c, head, uint32_t, N);
     PFP_ALLOC_HI(c, aux, uint32_t, N);
     PFP_ALLOC_HI(c, slots, uint32_t, N);
     PFP_ALLOC_HI(c, slots2, uint32_t, N);
+    PFP_ALLOC_HI(c, jump, uint32_t, N);
     PFP_ALLOC_HI(c, d_cnt, uint32_t, 1);
     uint64_t *sk; uint32_t *sv;
     PFP_TRY(radix_sort_pairs<uint64_t>(c, k0, v0, k1, v1, N, init_ranges, n_init_ranges, &sk, &sv));
@@ -132,28 +179,37 @@ inline int suffix_sort_doubling(pfp_ctx *c, uint64_t N, uint64_t *k0, uint32_t *
     PFP_LAUNCH(c, K_SS_HEADS, N * 24, k_ss_heads, gN, (const uint64_t *)sk, (const uint32_t *)sv, (const uint32_t *)nullptr, N, SA, head, aux);
     PFP_TRY((device_scan<uint32_t, 1>(c, aux, aux, N, nullptr)));
     PFP_LAUNCH(c, K_SS_WRITE_RANK, N * 12, k_ss_write_rank, gN, (const uint32_t *)sv, (const uint32_t *)aux, N, rank);
-    uint32_t h = h0;
+    PFP_LAUNCH(c, K_SS_WRITE_RANK, N * 4, k_ss_init_jump, gN, jump, N, h0);
     // first active list
     uint32_t *keep = aux; // aux is free again after write_rank
-    PFP_LAUNCH(c, K_SS_FLAG_ACTIVE, N * 12, k_ss_flag_active, gN, (const uint32_t *)sv, (const uint32_t *)head, N, h, ws, wordid, keep);
+    PFP_LAUNCH(c, K_SS_FLAG_ACTIVE, N * 16, k_ss_flag_active, gN, (const uint32_t *)sv, (const uint32_t *)head, N, (const uint32_t *)jump, ws, wordid, keep);
     PFP_TRY(device_compact(c, nullptr, keep, N, slots, slots2, d_cnt));
     uint32_t na = 0; PFP_TRY(d2h_u32(c, d_cnt, &na));
     int rounds = 1;
     const int rbits = bits_for(N);
+    if (na > 0) {
+        PFP_ALLOC_HI(c, nj, uint32_t, na);
+        if (D) {   // run lengths for the run round
+            PFP_ALLOC_HI(c, M, uint32_t, N);
+            PFP_LAUNCH(c, K_SS_MAKE_KEYS, N * 5, k_ss_runend_marks, gN, D, N, M);
+            PFP_TRY((device_scan<uint32_t, 1>(c, M, M, N, nullptr)));
+        }
+    }
     while (na > 0) {
-        if (h >= (1u << 31) || rounds > 40) return PFP_E_CORRUPT; // cannot happen on well-formed input
+        if (rounds > 64) return PFP_E_CORRUPT; // cannot happen on well-formed input
         const unsigned ga = nblocks(na, BLOCK);
-        uint64_t *ak = (sk == k0) ? k1 : k0; uint32_t *av = (sv == v0) ? v1 : v0; // the buffers not holding the last result
-        (void)ak; (void)av;
-        // build keys for the active list into k0/v0 (previous contents are dead: SA/rank hold the state)
-        PFP_LAUNCH(c, K_SS_MAKE_KEYS, (uint64_t)na * 28, k_ss_make_keys, ga, (const uint32_t *)slots, (const uint32_t *)SA, (const uint32_t *)rank, (uint64_t)na, N, h, k0, v0);
-        BitRange rr[2] = {{0, rbits}, {32, 32 + rbits}};
+        const bool run_round = (M != nullptr && rounds == 1);
+        // build keys for the active list into k0/v0 (previous contents are dead: SA/rank/jump hold the state)
+        PFP_LAUNCH(c, K_SS_MAKE_KEYS, (uint64_t)na * 36, k_ss_make_keys, ga, (const uint32_t *)slots, (const uint32_t *)SA, (const uint32_t *)rank, (const uint32_t *)jump, (uint64_t)na, N,
+                   run_round ? D : (const uint8_t *)nullptr, run_round ? (const uint32_t *)M : (const uint32_t *)nullptr, k0, v0, nj);
+        PFP_LAUNCH(c, K_SS_MAKE_KEYS, (uint64_t)na * 12, k_ss_apply_jump, ga, (const uint32_t *)v0, (const uint32_t *)nj, (uint64_t)na, jump);
+        BitRange rr[2] = {{0, run_round ? 32 : rbits}, {32, 32 + rbits}};
         PFP_TRY(radix_sort_pairs<uint64_t>(c, k0, v0, k1, v1, na, rr, 2, &sk, &sv));
         PFP_LAUNCH(c, K_SS_HEADS, (uint64_t)na * 28, k_ss_heads, ga, (const uint64_t *)sk, (const uint32_t *)sv, (const uint32_t *)slots, (uint64_t)na, SA, head, aux);
         PFP_TRY((device_scan<uint32_t, 1>(c, aux, aux, na, nullptr)));
         PFP_LAUNCH(c, K_SS_WRITE_RANK, (uint64_t)na * 12, k_ss_write_rank, ga, (const uint32_t *)sv, (const uint32_t *)aux, (uint64_t)na, rank);
-        h *= 2; ++rounds;
-        PFP_LAUNCH(c, K_SS_FLAG_ACTIVE, (uint64_t)na * 12, k_ss_flag_active, ga, (const uint32_t *)sv, (const uint32_t *)head, (uint64_t)na, h, ws, wordid, keep);
+        ++rounds;
+        PFP_LAUNCH(c, K_SS_FLAG_ACTIVE, (uint64_t)na * 16, k_ss_flag_active, ga, (const uint32_t *)sv, (const uint32_t *)head, (uint64_t)na, (const uint32_t *)jump, ws, wordid, keep);
         PFP_TRY(device_compact(c, slots, keep, na, slots2, head /*pos scratch*/, d_cnt));
         uint32_t *t = slots; slots = slots2; slots2 = t;
         PFP_TRY(d2h_u32(c, d_cnt, &na));
