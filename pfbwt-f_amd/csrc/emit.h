@@ -83,24 +83,39 @@ struct EmitArgs {
     const uint8_t *D; uint64_t dsize; uint32_t dwords; int w;
     const uint32_t *SA, *grank, *wordid, *ws, *wrank /*nullable*/, *occ, *F, *ilist, *bwsai /*nullable*/;
     const uint8_t *bwlast;
-    const uint32_t *EB; // exclusive scan of cnt over slots
+    const uint32_t *EB;     // exclusive scan of cnt over slots
+    const uint32_t *s_sl;   // per slot: suffix length
+    const uint32_t *s_fb;   // per slot: first ilist index of the slot's word (F[rank])
+    const uint8_t *s_fl;    // per slot: SF_* flags
+    const uint8_t *s_pc;    // per slot: BWT byte of a proper-suffix slot (preceding dictionary byte, 0 after the first Dollar)
     uint64_t nout, n;
 };
+constexpr uint8_t SF_MULTI = 1, SF_FULL = 2;
 
 __device__ __forceinline__ uint32_t word_rank_of(const EmitArgs &a, uint32_t id) { return a.wrank ? a.wrank[id] : id; }
 
-// cnt[i] = number of text rows produced by slot i (0 for suffixes no longer than w, pfbwt.hpp:114)
-__global__ __launch_bounds__(BLOCK) void k_emit_count(EmitArgs a, uint32_t *cnt)
+// Per suffix-array slot (the random gathers happen here, once per slot, not once per output row):
+// cnt = rows produced (occ of the word if suff_len > w, pfbwt.hpp:114), suffix length, ilist base,
+// preceding byte, whole-word flag (pfbwt.hpp:116), multi-word-group flag (pfbwt.hpp:137).
+__global__ __launch_bounds__(BLOCK) void k_emit_slots(EmitArgs a, uint32_t *cnt, uint32_t *mr, uint32_t *s_sl, uint32_t *s_fb, uint8_t *s_fl, uint8_t *s_pc)
 {
     const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= a.dsize) return;
     const uint32_t x = a.SA[i], id = a.wordid[x];
-    uint32_t c = 0;
+    uint32_t c = 0, sl = 0, fb = 0; uint8_t fl = 0, pc = 0;
     if (id < a.dwords) {
-        const uint32_t sl = a.ws[id + 1] - 1u - x;
-        if (sl > (uint32_t)a.w) c = a.occ[word_rank_of(a, id)];
+        const uint32_t wsid = a.ws[id];
+        sl = a.ws[id + 1] - 1u - x;
+        if (sl > (uint32_t)a.w) {
+            const uint32_t rk = word_rank_of(a, id);
+            c = a.occ[rk]; fb = a.F[rk];
+            const uint32_t g0 = a.grank[x];
+            if ((i != g0) || (i + 1 < a.dsize && a.grank[a.SA[i + 1]] == g0)) fl |= SF_MULTI;
+            if (x == wsid) fl |= SF_FULL;
+            else { pc = a.D[x - 1]; if (pc == Dollar && x - 1 == wsid) pc = 0; }   // pfbwt.hpp:132 "gsa[i]-1 ? dict[..] : 0"
+        }
     }
-    cnt[i] = c;
+    cnt[i] = c; mr[i] = (fl & SF_MULTI) ? c : 0u; s_sl[i] = sl; s_fb[i] = fb; s_fl[i] = fl; s_pc[i] = pc;
 }
 
 __device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t *a, uint32_t n, uint32_t x)
@@ -110,63 +125,81 @@ __device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t *a, uint32_t 
     return lo;
 }
 
-template <typename SAT> __global__ __launch_bounds__(BLOCK) void k_emit(EmitArgs a, uint8_t *bwt, SAT *sa)
+// position of a row inside a multi-word group (pfbwt.hpp:137-181) and whether a whole-word member
+// emits EndOfWord.  gsacak puts byte-identical suffixes in dictionary-position order, i.e. by word rank.
+// The reference's loop starts at the FIRST member: if that one is a whole word it is emitted alone
+// (:116-128) and the rest forms its own group; otherwise all members are merged by ilist position and a
+// whole-word member contributes dict[gsa-1] == EndOfWord as its BWT byte (:140).
+__device__ __forceinline__ uint64_t multi_group_pos(const EmitArgs &a, uint32_t i, uint32_t r, uint32_t q, bool self_full, bool *full_emits_eow)
 {
-    const uint64_t o = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (o >= a.nout) return;
-    // slot: last i with EB[i] <= o
-    const uint32_t i = upper_bound_u32(a.EB, (uint32_t)a.dsize, (uint32_t)o) - 1u;
-    const uint32_t x = a.SA[i], id = a.wordid[x];
-    const uint32_t sl = a.ws[id + 1] - 1u - x;                 // suff_len, pfbwt.hpp:83-85
-    const uint32_t rk = word_rank_of(a, id);
-    const uint32_t r = (uint32_t)o - a.EB[i];
-    const uint32_t q = a.ilist[a.F[rk] + r];                   // parse-BWT row of this occurrence
-    const uint32_t g0 = a.grank[x];                            // first slot of the group of equal suffixes
-    uint64_t pos = o;
-    const bool multi = (i != g0) || (i + 1 < a.dsize && a.grank[a.SA[i + 1]] == g0);
-    const bool self_full = (x == a.ws[id]);
-    bool full_emits_eow = false;
-    if (multi) {                                               // pfbwt.hpp:137-181: merge by ilist position
-        // gsacak puts byte-identical suffixes in dictionary-position order, i.e. by word rank.  The
-        // reference's loop starts at the FIRST member: if that one is a whole word it is emitted alone
-        // (:116-128) and the rest forms its own group; otherwise all members are merged by ilist
-        // position and a whole-word member contributes dict[gsa-1] == EndOfWord as its BWT byte (:140).
-        uint64_t before = 0;
-        uint32_t first_rk = rk, first_before = 0, first_occ = a.occ[rk]; bool first_full = self_full;
-        for (uint32_t s = g0; s < a.dsize; ++s) {
-            const uint32_t xs = a.SA[s];
-            if (a.grank[xs] != g0) break;
-            if (s == i) continue;
-            const uint32_t ids = a.wordid[xs];
-            const uint32_t rs = word_rank_of(a, ids);
-            const uint32_t oc = a.occ[rs];
-            const uint32_t lb = lower_bound_u32(a.ilist + a.F[rs], oc, q);
-            before += lb;
-            if (rs < first_rk) { first_rk = rs; first_before = lb; first_occ = oc; first_full = (xs == a.ws[ids]); }
-        }
-        const uint64_t gb = a.EB[g0];
-        if (first_full) pos = (first_rk == rk) ? gb + r : gb + first_occ + (before - first_before) + r;
-        else { pos = gb + before + r; full_emits_eow = self_full; }
+    const uint32_t x = a.SA[i], g0 = a.grank[x];
+    const uint32_t rk = word_rank_of(a, a.wordid[x]);
+    uint64_t before = 0;
+    uint32_t first_rk = rk, first_before = 0, first_occ = a.occ[rk]; bool first_full = self_full;
+    for (uint32_t s = g0; s < a.dsize; ++s) {
+        const uint32_t xs = a.SA[s];
+        if (a.grank[xs] != g0) break;
+        if (s == i) continue;
+        const uint32_t ids = a.wordid[xs];
+        const uint32_t rs = word_rank_of(a, ids);
+        const uint32_t oc = a.occ[rs];
+        const uint32_t lb = lower_bound_u32(a.ilist + a.F[rs], oc, q);
+        before += lb;
+        if (rs < first_rk) { first_rk = rs; first_before = lb; first_occ = oc; first_full = (xs == a.ws[ids]); }
     }
-    uint8_t c;
-    if (self_full) c = full_emits_eow ? EndOfWord : a.bwlast[q];   // whole word, pfbwt.hpp:116-128
-    else { c = a.D[x - 1]; if (c == Dollar && x - 1 == a.ws[id]) c = 0; }   // :132 "gsa[i]-1 ? dict[..] : 0"
-    bwt[pos] = c;
-    if (sa) {
-        SAT v = (SAT)((SAT)(a.bwsai[q]) - (SAT)sl);             // UPDATE_SA, pfbwt.hpp:87-89
-        if (pos == 0) v = (SAT)a.n;                             // src/pfbwt-f.cpp:301
-        sa[pos] = v;
-    }
+    const uint64_t gb = a.EB[g0];
+    *full_emits_eow = false;
+    if (first_full) return (first_rk == rk) ? gb + r : gb + first_occ + (before - first_before) + r;
+    *full_emits_eow = self_full;
+    return gb + before + r;
 }
 
-// number of rows that sit in multi-word groups (the reference's "hard"/EASY2 bookkeeping, pfbwt.hpp:188)
-__global__ __launch_bounds__(BLOCK) void k_multi_rows(EmitArgs a, const uint32_t *cnt, uint32_t *mr)
+// Output-stationary emission.  A workgroup owns EMIT_TILE consecutive rows; the slots they come from
+// are a contiguous range found by two binary searches per workgroup; that slice of EB goes to LDS and
+// every row finds its slot there.
+constexpr int EMIT_PER_THREAD = 8;
+constexpr int EMIT_TILE = BLOCK * EMIT_PER_THREAD;
+constexpr int EMIT_LDS_SLOTS = 4096;
+
+template <typename SAT> __global__ __launch_bounds__(BLOCK) void k_emit(EmitArgs a, uint8_t *bwt, SAT *sa)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= a.dsize) return;
-    const uint32_t x = a.SA[i], g0 = a.grank[x];
-    const bool multi = (i != g0) || (i + 1 < a.dsize && a.grank[a.SA[i + 1]] == g0);
-    mr[i] = multi ? cnt[i] : 0u;
+    __shared__ uint32_t eb[EMIT_LDS_SLOTS];
+    __shared__ uint32_t range[2];
+    const uint64_t o0 = (uint64_t)blockIdx.x * EMIT_TILE;
+    const uint64_t o1 = (o0 + EMIT_TILE < a.nout) ? o0 + EMIT_TILE : a.nout;   // exclusive
+    if (threadIdx.x < 2) {
+        const uint64_t o = threadIdx.x == 0 ? o0 : o1 - 1;
+        range[threadIdx.x] = upper_bound_u32(a.EB, (uint32_t)a.dsize, (uint32_t)o) - 1u;   // last slot with EB <= o
+    }
+    __syncthreads();
+    const uint32_t i0 = range[0], i1 = range[1];
+    const uint32_t ns = i1 - i0 + 1u;
+    const bool in_lds = ns <= (uint32_t)EMIT_LDS_SLOTS;
+    if (in_lds) for (uint32_t k = threadIdx.x; k < ns; k += BLOCK) eb[k] = a.EB[i0 + k];
+    __syncthreads();
+#pragma unroll 1
+    for (int k = 0; k < EMIT_PER_THREAD; ++k) {
+        const uint64_t o = o0 + (uint64_t)k * BLOCK + threadIdx.x;
+        if (o >= o1) break;
+        uint32_t i;
+        if (in_lds) i = i0 + upper_bound_u32(eb, ns, (uint32_t)o) - 1u;
+        else i = upper_bound_u32(a.EB, (uint32_t)a.dsize, (uint32_t)o) - 1u;
+        const uint32_t r = (uint32_t)o - (in_lds ? eb[i - i0] : a.EB[i]);
+        const uint8_t fl = a.s_fl[i];
+        const uint32_t sl = a.s_sl[i];                             // suff_len, pfbwt.hpp:83-85
+        const uint32_t q = a.ilist[a.s_fb[i] + r];                 // parse-BWT row of this occurrence
+        const bool self_full = (fl & SF_FULL) != 0;
+        uint64_t pos = o;
+        bool full_emits_eow = false;
+        if (fl & SF_MULTI) pos = multi_group_pos(a, i, r, q, self_full, &full_emits_eow);
+        const uint8_t c = self_full ? (full_emits_eow ? (uint8_t)EndOfWord : a.bwlast[q]) : a.s_pc[i];   // pfbwt.hpp:116-128 / :132
+        bwt[pos] = c;
+        if (sa) {
+            SAT v = (SAT)((SAT)(a.bwsai[q]) - (SAT)sl);             // UPDATE_SA, pfbwt.hpp:87-89
+            if (pos == 0) v = (SAT)a.n;                             // src/pfbwt-f.cpp:301
+            sa[pos] = v;
+        }
+    }
 }
 
 // run starts: bwt[o] != bwt[o-1] (pbwtc starts at 0, src/pfbwt-f.cpp:304)

@@ -500,7 +500,7 @@ template <typename SAT> static int emit_and_sample(pfp_ctx *c, const EmitArgs &e
     SAT *sa = nullptr;
     if (any_sa) { PFP_ALLOC_LO(c, sa, SAT, nout); }
     c->d_sa = sa;
-    PFP_LAUNCH(c, K_EMIT, nout * (1 + (any_sa ? sizeof(SAT) : 0)) + c->nrows * 9 + c->dsize * 9, (k_emit<SAT>), nblocks(nout, BLOCK), ea, c->d_bwt, sa);
+    PFP_LAUNCH(c, K_EMIT, nout * (1 + (any_sa ? sizeof(SAT) : 0)) + c->nrows * 9 + c->dsize * 9, (k_emit<SAT>), nblocks(nout, EMIT_TILE), ea, c->d_bwt, sa);
     // runs
     uint32_t *flag, *ridx, *d_cnt;
     PFP_ALLOC_HI(c, flag, uint32_t, nout); PFP_ALLOC_HI(c, ridx, uint32_t, nout); PFP_ALLOC_HI(c, d_cnt, uint32_t, 1);
@@ -530,9 +530,11 @@ int pfp_bwt_build(pfp_ctx *c, int want_sa, int want_rssa, pfp_bwt_sizes *out)
     const size_t mk = c->arena.mark_hi();
     if (!c->gsa_valid) { PFP_TRY(sort_dict_suffixes(c)); c->lo_after_pbwt = c->arena.mark_lo(); }   // gsacak, pfbwt.hpp:211
     const uint64_t dsize = c->dsize, dwords = c->dwords;
-    uint32_t *F, *cnt, *EB, *d_tot, *mr;
+    uint32_t *F, *cnt, *EB, *d_tot, *mr, *s_sl, *s_fb; uint8_t *s_fl, *s_pc;
     PFP_ALLOC_HI(c, F, uint32_t, dwords + 1);
     PFP_ALLOC_HI(c, cnt, uint32_t, dsize); PFP_ALLOC_HI(c, EB, uint32_t, dsize); PFP_ALLOC_HI(c, mr, uint32_t, dsize);
+    PFP_ALLOC_HI(c, s_sl, uint32_t, dsize); PFP_ALLOC_HI(c, s_fb, uint32_t, dsize);
+    PFP_ALLOC_HI(c, s_fl, uint8_t, dsize); PFP_ALLOC_HI(c, s_pc, uint8_t, dsize);
     PFP_ALLOC_HI(c, d_tot, uint32_t, 4);
     // F[r] = 1 + sum_{r' < r} occ[r']  (ilist[0] is the EOS row; pfbwt.hpp:259-268)
     PFP_TRY((device_scan<uint32_t, 0>(c, c->d_occ, F, dwords, nullptr)));
@@ -541,10 +543,9 @@ int pfp_bwt_build(pfp_ctx *c, int want_sa, int want_rssa, pfp_bwt_sizes *out)
     ea.D = c->d_dict; ea.dsize = dsize; ea.dwords = (uint32_t)dwords; ea.w = c->w;
     ea.SA = c->d_gsa; ea.grank = c->d_grank; ea.wordid = c->d_wordid; ea.ws = c->d_ws; ea.wrank = c->d_wrank;
     ea.occ = c->d_occ; ea.F = F; ea.ilist = c->d_ilist; ea.bwsai = c->d_bwsai; ea.bwlast = c->d_bwlast;
-    ea.EB = EB; ea.nout = 0; ea.n = 0;
-    PFP_LAUNCH(c, K_EMIT_COUNT, dsize * 16, k_emit_count, nblocks(dsize, BLOCK), ea, cnt);
+    ea.EB = EB; ea.s_sl = s_sl; ea.s_fb = s_fb; ea.s_fl = s_fl; ea.s_pc = s_pc; ea.nout = 0; ea.n = 0;
+    PFP_LAUNCH(c, K_EMIT_COUNT, dsize * 34, k_emit_slots, nblocks(dsize, BLOCK), ea, cnt, mr, s_sl, s_fb, s_fl, s_pc);
     PFP_TRY((device_scan<uint32_t, 0>(c, cnt, EB, dsize, d_tot)));
-    PFP_LAUNCH(c, K_MISC, dsize * 16, k_multi_rows, nblocks(dsize, BLOCK), ea, (const uint32_t *)cnt, mr);
     PFP_TRY((device_scan<uint32_t, 0>(c, mr, mr, dsize, d_tot + 1)));
     uint32_t tot = 0, hardrows = 0;
     PFP_HIP(c, hipMemcpyAsync(&hardrows, d_tot + 1, 4, hipMemcpyDeviceToHost, c->stream));
