@@ -35,21 +35,21 @@ __global__ __launch_bounds__(BLOCK) void k_u32_add_store(const uint32_t *in, uin
     if (i < n) out[i] = in[i] + add;
 }
 
-// word ranks from the sorted dictionary suffixes: flag slots whose suffix starts a word
-__global__ __launch_bounds__(BLOCK) void k_wordstart_flags(const uint32_t *SA, const uint32_t *wordid, const uint32_t *ws, uint32_t dwords, uint64_t dsize, uint32_t *flag)
+// Word ranks (sort_dict + generate_ranks, pfparser.hpp:494-517) from the dictionary suffix sort: the
+// class-head slot of a word's first byte orders the words (two distinct words are never byte-identical,
+// so their whole-word suffixes sit in different classes).  keys = grank[ws[id]], sorted -> rank.
+__global__ __launch_bounds__(BLOCK) void k_wordstart_keys(const uint32_t *ws, const uint32_t *grank, uint64_t dwords, uint32_t *keys, uint32_t *vals)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= dsize) return;
-    const uint32_t x = SA[i], id = wordid[x];
-    flag[i] = (id < dwords && ws[id] == x) ? 1u : 0u;
+    const uint64_t id = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (id >= dwords) return;
+    keys[id] = grank[ws[id]]; vals[id] = (uint32_t)id;
 }
-__global__ __launch_bounds__(BLOCK) void k_word_rank(const uint32_t *SA, const uint32_t *wordid, const uint32_t *flag, const uint32_t *pos, uint64_t dsize,
-                                                     const uint32_t *occw, uint32_t *wrank, uint32_t *idofrank, uint32_t *occ)
+__global__ __launch_bounds__(BLOCK) void k_word_rank(const uint32_t *sorted_ids, uint64_t dwords, const uint32_t *occw, uint32_t *wrank, uint32_t *idofrank, uint32_t *occ)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= dsize || !flag[i]) return;
-    const uint32_t id = wordid[SA[i]], r = pos[i];
-    wrank[id] = r; idofrank[r] = id; occ[r] = occw[id];
+    const uint64_t r = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (r >= dwords) return;
+    const uint32_t id = sorted_ids[r];
+    wrank[id] = (uint32_t)r; idofrank[r] = id; occ[r] = occw[id];
 }
 __global__ __launch_bounds__(BLOCK) void k_parse_ranks(const uint32_t *pid, const uint32_t *wrank, uint64_t m, uint32_t *parse)
 {
@@ -81,7 +81,8 @@ __global__ __launch_bounds__(BLOCK) void k_ws_from_flags(const uint8_t *D, uint6
 // ---- emission -----------------------------------------------------------------------------------
 struct EmitArgs {
     const uint8_t *D; uint64_t dsize; uint32_t dwords; int w;
-    const uint32_t *SA, *grank, *wordid, *ws, *wrank /*nullable*/, *occ, *F, *ilist, *bwsai /*nullable*/;
+    const uint32_t *SA, *ws, *wrank /*nullable*/, *occ, *F, *ilist, *bwsai /*nullable*/;
+    const uint2 *posinfo;
     const uint8_t *bwlast;
     const uint32_t *EB;     // exclusive scan of cnt over slots
     const uint32_t *s_sl;   // per slot: suffix length
@@ -91,6 +92,17 @@ struct EmitArgs {
     uint64_t nout, n;
 };
 constexpr uint8_t SF_MULTI = 1, SF_FULL = 2;
+// posinfo[x] = { word id of dictionary offset x | 4-bit code of D[x-1] << 28 , class-head slot of x }: one 8-byte
+// gather per slot instead of three separate random reads (wordid, grank, D[x-1])
+constexpr uint32_t WID_MASK = 0x0FFFFFFFu;
+__device__ __forceinline__ uint32_t dict_code4(uint32_t c) { return c <= 2 ? c : (c == '-') ? 3u : (c == 'A') ? 4u : (c == 'C') ? 5u : (c == 'G') ? 6u : (c == 'N') ? 7u : 8u; }
+__device__ __forceinline__ uint8_t dict_byte4(uint32_t code) { return code <= 2 ? (uint8_t)code : code == 3 ? (uint8_t)'-' : code == 4 ? (uint8_t)'A' : code == 5 ? (uint8_t)'C' : code == 6 ? (uint8_t)'G' : code == 7 ? (uint8_t)'N' : (uint8_t)'T'; }
+__global__ __launch_bounds__(BLOCK) void k_pack_posinfo(const uint8_t *D, const uint32_t *wordid, const uint32_t *grank, uint64_t dsize, uint2 *posinfo)
+{
+    const uint64_t x = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (x >= dsize) return;
+    posinfo[x] = make_uint2(wordid[x] | (dict_code4(x ? D[x - 1] : 0u) << 28), grank[x]);
+}
 
 __device__ __forceinline__ uint32_t word_rank_of(const EmitArgs &a, uint32_t id) { return a.wrank ? a.wrank[id] : id; }
 
@@ -99,9 +111,19 @@ __device__ __forceinline__ uint32_t word_rank_of(const EmitArgs &a, uint32_t id)
 // preceding byte, whole-word flag (pfbwt.hpp:116), multi-word-group flag (pfbwt.hpp:137).
 __global__ __launch_bounds__(BLOCK) void k_emit_slots(EmitArgs a, uint32_t *cnt, uint32_t *mr, uint32_t *s_sl, uint32_t *s_fb, uint8_t *s_fl, uint8_t *s_pc)
 {
+    __shared__ uint8_t hd[BLOCK + 1];   // is slot (block base + t) the head of its class of equal suffixes
     const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= a.dsize) return;
-    const uint32_t x = a.SA[i], id = a.wordid[x];
+    const bool valid = i < a.dsize;
+    uint32_t x = 0; uint2 P = make_uint2(0, 0);
+    if (valid) { x = a.SA[i]; P = a.posinfo[x]; }
+    hd[threadIdx.x] = (valid && P.y == (uint32_t)i) ? 1 : 0;
+    if (threadIdx.x == 0) {
+        const uint64_t nx = (uint64_t)(blockIdx.x + 1) * BLOCK;
+        hd[BLOCK] = (nx < a.dsize) ? (a.posinfo[a.SA[nx]].y == (uint32_t)nx ? 1 : 0) : 1;
+    }
+    __syncthreads();
+    if (!valid) return;
+    const uint32_t id = P.x & WID_MASK;
     uint32_t c = 0, sl = 0, fb = 0; uint8_t fl = 0, pc = 0;
     if (id < a.dwords) {
         const uint32_t wsid = a.ws[id];
@@ -109,10 +131,9 @@ __global__ __launch_bounds__(BLOCK) void k_emit_slots(EmitArgs a, uint32_t *cnt,
         if (sl > (uint32_t)a.w) {
             const uint32_t rk = word_rank_of(a, id);
             c = a.occ[rk]; fb = a.F[rk];
-            const uint32_t g0 = a.grank[x];
-            if ((i != g0) || (i + 1 < a.dsize && a.grank[a.SA[i + 1]] == g0)) fl |= SF_MULTI;
+            if (!hd[threadIdx.x] || (i + 1 < a.dsize && !hd[threadIdx.x + 1])) fl |= SF_MULTI;   // group of >= 2 equal suffixes (pfbwt.hpp:137)
             if (x == wsid) fl |= SF_FULL;
-            else { pc = a.D[x - 1]; if (pc == Dollar && x - 1 == wsid) pc = 0; }   // pfbwt.hpp:132 "gsa[i]-1 ? dict[..] : 0"
+            else { pc = dict_byte4(P.x >> 28); if (pc == Dollar && x - 1 == wsid) pc = 0; }   // pfbwt.hpp:132 "gsa[i]-1 ? dict[..] : 0"
         }
     }
     cnt[i] = c; mr[i] = (fl & SF_MULTI) ? c : 0u; s_sl[i] = sl; s_fb[i] = fb; s_fl[i] = fl; s_pc[i] = pc;
@@ -132,15 +153,17 @@ __device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t *a, uint32_t 
 // whole-word member contributes dict[gsa-1] == EndOfWord as its BWT byte (:140).
 __device__ __forceinline__ uint64_t multi_group_pos(const EmitArgs &a, uint32_t i, uint32_t r, uint32_t q, bool self_full, bool *full_emits_eow)
 {
-    const uint32_t x = a.SA[i], g0 = a.grank[x];
-    const uint32_t rk = word_rank_of(a, a.wordid[x]);
+    const uint2 P = a.posinfo[a.SA[i]];
+    const uint32_t g0 = P.y;
+    const uint32_t rk = word_rank_of(a, P.x & WID_MASK);
     uint64_t before = 0;
     uint32_t first_rk = rk, first_before = 0, first_occ = a.occ[rk]; bool first_full = self_full;
     for (uint32_t s = g0; s < a.dsize; ++s) {
         const uint32_t xs = a.SA[s];
-        if (a.grank[xs] != g0) break;
+        const uint2 Ps = a.posinfo[xs];
+        if (Ps.y != g0) break;
         if (s == i) continue;
-        const uint32_t ids = a.wordid[xs];
+        const uint32_t ids = Ps.x & WID_MASK;
         const uint32_t rs = word_rank_of(a, ids);
         const uint32_t oc = a.occ[rs];
         const uint32_t lb = lower_bound_u32(a.ilist + a.F[rs], oc, q);

@@ -323,19 +323,21 @@ int pfp_parse_finalize(pfp_ctx *c, pfp_parse_sizes *out)
     PFP_TRY(sort_dict_suffixes(c));
 
     // 4. ranks, occ, last, sorted .dict image
-    uint32_t *flag, *pos, *idofrank, *len1;
-    PFP_ALLOC_HI(c, flag, uint32_t, dsize); PFP_ALLOC_HI(c, pos, uint32_t, dsize);
+    uint32_t *wk0, *wk1, *wv0, *wv1, *idofrank, *len1;
+    PFP_ALLOC_HI(c, wk0, uint32_t, dwords); PFP_ALLOC_HI(c, wk1, uint32_t, dwords); PFP_ALLOC_HI(c, wv0, uint32_t, dwords); PFP_ALLOC_HI(c, wv1, uint32_t, dwords);
     PFP_ALLOC_HI(c, idofrank, uint32_t, dwords); PFP_ALLOC_HI(c, len1, uint32_t, dwords + 1);
     PFP_ALLOC_LO(c, c->d_wrank, uint32_t, dwords);
     PFP_ALLOC_LO(c, c->d_occ, uint32_t, dwords);
     PFP_ALLOC_LO(c, c->d_parse, uint32_t, m + 1);
     PFP_ALLOC_LO(c, c->d_last, uint8_t, m);
     PFP_ALLOC_LO(c, c->d_sdict, uint8_t, dsize + 16);
-    const unsigned gds = nblocks(dsize, BLOCK);
-    PFP_LAUNCH(c, K_WORD_RANK, dsize * 12, k_wordstart_flags, gds, (const uint32_t *)c->d_gsa, (const uint32_t *)c->d_wordid, (const uint32_t *)c->d_ws, (uint32_t)dwords, dsize, flag);
-    PFP_TRY((device_scan<uint32_t, 0>(c, flag, pos, dsize, nullptr)));
-    PFP_LAUNCH(c, K_WORD_RANK, dsize * 12, k_word_rank, gds, (const uint32_t *)c->d_gsa, (const uint32_t *)c->d_wordid, (const uint32_t *)flag, (const uint32_t *)pos, dsize,
-               (const uint32_t *)occw, c->d_wrank, idofrank, c->d_occ);
+    {
+        PFP_LAUNCH(c, K_WORD_RANK, dwords * 16, k_wordstart_keys, gd, (const uint32_t *)c->d_ws, (const uint32_t *)c->d_grank, dwords, wk0, wv0);
+        BitRange br = {0, bits_for(dsize)};
+        uint32_t *sk32, *sv32;
+        PFP_TRY(radix_sort_pairs<uint32_t>(c, wk0, wv0, wk1, wv1, dwords, &br, 1, &sk32, &sv32));
+        PFP_LAUNCH(c, K_WORD_RANK, dwords * 20, k_word_rank, gd, (const uint32_t *)sv32, dwords, (const uint32_t *)occw, c->d_wrank, idofrank, c->d_occ);
+    }
     PFP_LAUNCH(c, K_PARSE_RANKS, m * 12, k_parse_ranks, gm, (const uint32_t *)c->d_pid, (const uint32_t *)c->d_wrank, m, c->d_parse);
     PFP_LAUNCH(c, K_MISC, m * 6, k_last_chars, gm, Y, (const uint32_t *)c->d_ye, m, w, c->d_last);
     PFP_LAUNCH(c, K_DICT_SORTED, dwords * 12, k_sorted_lengths, gd, (const uint32_t *)c->d_ws, (const uint32_t *)idofrank, dwords, len1, srcstart);
@@ -530,7 +532,10 @@ int pfp_bwt_build(pfp_ctx *c, int want_sa, int want_rssa, pfp_bwt_sizes *out)
     const size_t mk = c->arena.mark_hi();
     if (!c->gsa_valid) { PFP_TRY(sort_dict_suffixes(c)); c->lo_after_pbwt = c->arena.mark_lo(); }   // gsacak, pfbwt.hpp:211
     const uint64_t dsize = c->dsize, dwords = c->dwords;
-    uint32_t *F, *cnt, *EB, *d_tot, *mr, *s_sl, *s_fb; uint8_t *s_fl, *s_pc;
+    uint32_t *F, *cnt, *EB, *d_tot, *mr, *s_sl, *s_fb; uint8_t *s_fl, *s_pc; uint2 *posinfo;
+    if (dwords > WID_MASK) return PFP_E_TOO_LARGE;
+    PFP_ALLOC_HI(c, posinfo, uint2, dsize);
+    PFP_LAUNCH(c, K_EMIT_COUNT, dsize * 17, k_pack_posinfo, nblocks(dsize, BLOCK), (const uint8_t *)c->d_dict, (const uint32_t *)c->d_wordid, (const uint32_t *)c->d_grank, dsize, posinfo);
     PFP_ALLOC_HI(c, F, uint32_t, dwords + 1);
     PFP_ALLOC_HI(c, cnt, uint32_t, dsize); PFP_ALLOC_HI(c, EB, uint32_t, dsize); PFP_ALLOC_HI(c, mr, uint32_t, dsize);
     PFP_ALLOC_HI(c, s_sl, uint32_t, dsize); PFP_ALLOC_HI(c, s_fb, uint32_t, dsize);
@@ -541,7 +546,7 @@ int pfp_bwt_build(pfp_ctx *c, int want_sa, int want_rssa, pfp_bwt_sizes *out)
     PFP_LAUNCH(c, K_MISC, dwords * 8, k_u32_add_store, nblocks(dwords, BLOCK), (const uint32_t *)F, dwords, 1u, F);
     EmitArgs ea;
     ea.D = c->d_dict; ea.dsize = dsize; ea.dwords = (uint32_t)dwords; ea.w = c->w;
-    ea.SA = c->d_gsa; ea.grank = c->d_grank; ea.wordid = c->d_wordid; ea.ws = c->d_ws; ea.wrank = c->d_wrank;
+    ea.SA = c->d_gsa; ea.posinfo = posinfo; ea.ws = c->d_ws; ea.wrank = c->d_wrank;
     ea.occ = c->d_occ; ea.F = F; ea.ilist = c->d_ilist; ea.bwsai = c->d_bwsai; ea.bwlast = c->d_bwlast;
     ea.EB = EB; ea.s_sl = s_sl; ea.s_fb = s_fb; ea.s_fl = s_fl; ea.s_pc = s_pc; ea.nout = 0; ea.n = 0;
     PFP_LAUNCH(c, K_EMIT_COUNT, dsize * 34, k_emit_slots, nblocks(dsize, BLOCK), ea, cnt, mr, s_sl, s_fb, s_fl, s_pc);

@@ -162,42 +162,98 @@ constexpr int RS_ITEMS = 16;
 constexpr int RS_TILE = BLOCK * RS_ITEMS;
 constexpr int RS_RADIX = 256;
 
-template <typename K> __global__ __launch_bounds__(BLOCK) void k_radix_hist(const K *keys, uint64_t n, int shift, uint32_t *hist, unsigned nb)
+struct BitRange { int lo, hi; };
+
+// ---- single-pass ("onesweep") variant: chained scan with decoupled look-back -------------------------
+// One upfront kernel histograms every digit position (keys read once); then each pass is ONE kernel:
+// a workgroup takes a ticket (tile id in arrival order, so a tile only ever waits for tiles that are
+// already running), counts its digits, publishes the tile aggregate, walks back over its predecessors'
+// status words until it meets an inclusive prefix, publishes its own inclusive prefix and scatters.
+// Status word = flag (2 bits) | count (62 bits) in ONE 8-byte word written by one agent-scope relaxed
+// atomic store and read by agent-scope relaxed atomic loads (L1-bypassing): flag and value travel
+// together, so no fence is needed (MI355X_MICROARCH.md "Valid forms": granule needs no ordering).
+constexpr int OS_MAX_PASSES = 8;
+constexpr unsigned long long OS_FLAG_AGG = 1ULL << 62, OS_FLAG_PREFIX = 2ULL << 62, OS_VAL_MASK = (1ULL << 62) - 1ULL;
+struct OsShifts { int shift[OS_MAX_PASSES]; int npass; };
+
+template <typename K> __global__ __launch_bounds__(BLOCK) void k_radix_hist_all(const K *keys, uint64_t n, OsShifts sh, unsigned long long *ghist /*[npass][256]*/)
 {
-    __shared__ uint32_t h[RS_RADIX];
-    h[threadIdx.x] = 0;
+    __shared__ uint32_t h[OS_MAX_PASSES][RS_RADIX];
+    for (int p = 0; p < sh.npass; ++p) h[p][threadIdx.x] = 0;
     __syncthreads();
-    const uint64_t base = (uint64_t)blockIdx.x * RS_TILE + (uint64_t)(threadIdx.x >> 6) * (RS_ITEMS * WAVE) + (threadIdx.x & 63);
-#pragma unroll
+    const uint64_t base = (uint64_t)blockIdx.x * RS_TILE + threadIdx.x;
+#pragma unroll 4
     for (int it = 0; it < RS_ITEMS; ++it) {
-        uint64_t i = base + (uint64_t)it * WAVE;
-        if (i < n) atomicAdd(&h[(unsigned)(keys[i] >> shift) & (RS_RADIX - 1)], 1u);
+        const uint64_t i = base + (uint64_t)it * BLOCK;
+        if (i < n) { const K k = keys[i]; for (int p = 0; p < sh.npass; ++p) atomicAdd(&h[p][(unsigned)(k >> sh.shift[p]) & (RS_RADIX - 1)], 1u); }
     }
     __syncthreads();
-    hist[(uint64_t)threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];
+    for (int p = 0; p < sh.npass; ++p) { const uint32_t v = h[p][threadIdx.x]; if (v) atomicAdd(&ghist[(size_t)p * RS_RADIX + threadIdx.x], (unsigned long long)v); }
+}
+// exclusive scan of each pass' 256 global counts -> first output index of every digit value
+__global__ __launch_bounds__(BLOCK) void k_radix_bases(unsigned long long *ghist, int npass)
+{
+    __shared__ unsigned long long lds[4];
+    for (int p = 0; p < npass; ++p) {
+        unsigned long long tot;
+        const unsigned long long v = ghist[(size_t)p * RS_RADIX + threadIdx.x];
+        const unsigned long long e = block_excl_sum(v, lds, &tot);
+        ghist[(size_t)p * RS_RADIX + threadIdx.x] = e;
+    }
 }
 
-template <typename K> __global__ __launch_bounds__(BLOCK) void k_radix_scatter(const K *keys, const uint32_t *vals, K *okeys, uint32_t *ovals,
-                                                                             uint64_t n, int shift, const uint32_t *gbase, unsigned nb)
+template <typename K> __global__ __launch_bounds__(BLOCK) void k_radix_onesweep(const K *keys, const uint32_t *vals, K *okeys, uint32_t *ovals, uint64_t n, int shift,
+                                                                              const unsigned long long *gbase /*[256]*/, unsigned long long *status /*[tiles][256]*/,
+                                                                              uint32_t *ticket, uint32_t *stuck)
 {
     __shared__ uint32_t wh[BLOCK / WAVE][RS_RADIX];
+    __shared__ unsigned long long cur[BLOCK / WAVE][RS_RADIX];
+    __shared__ uint32_t s_tile;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    K k[RS_ITEMS]; uint32_t v[RS_ITEMS];
-    const uint64_t base = (uint64_t)blockIdx.x * RS_TILE + (uint64_t)wave * (RS_ITEMS * WAVE) + lane;
+    if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
 #pragma unroll
     for (int w = 0; w < BLOCK / WAVE; ++w) wh[w][threadIdx.x] = 0;
     __syncthreads();
+    const uint32_t tile = s_tile;
+    K k[RS_ITEMS]; uint32_t v[RS_ITEMS];
+    const uint64_t base = (uint64_t)tile * RS_TILE + (uint64_t)wave * (RS_ITEMS * WAVE) + lane;
 #pragma unroll
     for (int it = 0; it < RS_ITEMS; ++it) {
-        uint64_t i = base + (uint64_t)it * WAVE;
+        const uint64_t i = base + (uint64_t)it * WAVE;
         if (i < n) { k[it] = keys[i]; v[it] = vals[i]; atomicAdd(&wh[wave][(unsigned)(k[it] >> shift) & (RS_RADIX - 1)], 1u); }
         else { k[it] = 0; v[it] = 0; }
     }
     __syncthreads();
-    {   // thread d turns the four per-wave counts of digit d into global write cursors
-        uint32_t run = gbase[(uint64_t)threadIdx.x * nb + blockIdx.x];
+    {   // thread d owns digit value d
+        const unsigned d = threadIdx.x;
+        uint32_t cw[BLOCK / WAVE]; unsigned long long total = 0;
 #pragma unroll
-        for (int w = 0; w < BLOCK / WAVE; ++w) { uint32_t cnt = wh[w][threadIdx.x]; wh[w][threadIdx.x] = run; run += cnt; }
+        for (int w = 0; w < BLOCK / WAVE; ++w) { cw[w] = wh[w][d]; total += cw[w]; }
+        unsigned long long *mine = status + (size_t)tile * RS_RADIX + d;
+        unsigned long long excl = 0;
+        if (tile == 0) {
+            __hip_atomic_store(mine, OS_FLAG_PREFIX | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            __hip_atomic_store(mine, OS_FLAG_AGG | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint32_t t = tile;
+            while (t > 0) {
+                --t;
+                const unsigned long long *pred = status + (size_t)t * RS_RADIX + d;
+                unsigned long long sv = __hip_atomic_load(pred, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                uint32_t spins = 0;
+                while ((sv >> 62) == 0) {              // predecessor has its ticket but has not published yet
+                    __builtin_amdgcn_s_sleep(2);
+                    sv = __hip_atomic_load(pred, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (++spins > (1u << 24)) { atomicAdd(stuck, 1u); break; }   // never expected; bounds the wait
+                }
+                excl += sv & OS_VAL_MASK;
+                if ((sv >> 62) != 1) break;           // inclusive prefix met (or bail-out)
+            }
+            __hip_atomic_store(mine, OS_FLAG_PREFIX | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        unsigned long long run = gbase[d] + excl;
+#pragma unroll
+        for (int w = 0; w < BLOCK / WAVE; ++w) { cur[w][d] = run; run += cw[w]; }
     }
     __syncthreads();
     const unsigned long long lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;
@@ -212,19 +268,16 @@ template <typename K> __global__ __launch_bounds__(BLOCK) void k_radix_scatter(c
             unsigned long long m = __ballot((d >> b) & 1);
             peers &= ((d >> b) & 1) ? m : ~m;
         }
-        // peers: valid lanes with my digit (garbage for invalid lanes, which are masked below)
         const int leader = valid ? (__ffsll((long long)peers) - 1) : lane;
-        uint32_t old = 0;
-        if (valid && lane == leader) { old = wh[wave][d]; wh[wave][d] = old + (uint32_t)__popcll(peers); }
+        unsigned long long old = 0;
+        if (valid && lane == leader) { old = cur[wave][d]; cur[wave][d] = old + (unsigned long long)__popcll(peers); }
         old = __shfl(old, leader);
         if (valid) {
-            const uint32_t dst = old + (uint32_t)__popcll(peers & lt);
+            const unsigned long long dst = old + (unsigned long long)__popcll(peers & lt);
             okeys[dst] = k[it]; ovals[dst] = v[it];
         }
     }
 }
-
-struct BitRange { int lo, hi; };
 
 // Sorts n pairs by the key bits in `ranges` (least significant range first).  Buffers (k0,v0) hold
 // the input; (k1,v1) are scratch of the same size.  On return *rk,*rv point at the sorted arrays.
@@ -235,16 +288,23 @@ template <typename K> inline int radix_sort_pairs(pfp_ctx *c, K *k0, uint32_t *v
     if (n <= 1) return PFP_OK;
     const size_t mk = c->arena.mark_hi();
     const unsigned nb = nblocks(n, RS_TILE);
-    uint32_t *hist; PFP_ALLOC_HI(c, hist, uint32_t, (size_t)RS_RADIX * nb);
+    OsShifts sh; sh.npass = 0;
+    for (int r = 0; r < nranges; ++r) for (int s = ranges[r].lo; s < ranges[r].hi; s += 8) { if (sh.npass == OS_MAX_PASSES) return PFP_E_ARG; sh.shift[sh.npass++] = s; }
+    for (int p = sh.npass; p < OS_MAX_PASSES; ++p) sh.shift[p] = 0;
+    unsigned long long *ghist, *status; uint32_t *ctl;
+    PFP_ALLOC_HI(c, ghist, unsigned long long, (size_t)OS_MAX_PASSES * RS_RADIX);
+    PFP_ALLOC_HI(c, status, unsigned long long, (size_t)nb * RS_RADIX);
+    PFP_ALLOC_HI(c, ctl, uint32_t, 2 * OS_MAX_PASSES + 2);   // ticket per pass, then the shared "stuck" counter
+    PFP_HIP(c, hipMemsetAsync(ghist, 0, sizeof(unsigned long long) * OS_MAX_PASSES * RS_RADIX, c->stream));
+    PFP_HIP(c, hipMemsetAsync(ctl, 0, sizeof(uint32_t) * (2 * OS_MAX_PASSES + 2), c->stream));
+    PFP_LAUNCH(c, K_RADIX_HIST, n * sizeof(K), (k_radix_hist_all<K>), nb, (const K *)k0, n, sh, ghist);
+    PFP_LAUNCH(c, K_SCAN_SPINE, sh.npass * 4096, k_radix_bases, 1, ghist, sh.npass);
     K *src = k0, *dst = k1; uint32_t *sv = v0, *dv = v1;
-    for (int r = 0; r < nranges; ++r) {
-        for (int shift = ranges[r].lo; shift < ranges[r].hi; shift += 8) {
-            PFP_LAUNCH(c, K_RADIX_HIST, n * sizeof(K), (k_radix_hist<K>), nb, (const K *)src, n, shift, hist, nb);
-            PFP_TRY((device_scan<uint32_t, 0>(c, hist, hist, (uint64_t)RS_RADIX * nb, nullptr)));
-            PFP_LAUNCH(c, K_RADIX_SCATTER, n * 2 * (sizeof(K) + 4), (k_radix_scatter<K>), nb, (const K *)src, (const uint32_t *)sv, dst, dv, n, shift,
-                       (const uint32_t *)hist, nb);
-            K *tk = src; src = dst; dst = tk; uint32_t *tv = sv; sv = dv; dv = tv;
-        }
+    for (int p = 0; p < sh.npass; ++p) {
+        PFP_HIP(c, hipMemsetAsync(status, 0, sizeof(unsigned long long) * (size_t)nb * RS_RADIX, c->stream));
+        PFP_LAUNCH(c, K_RADIX_SCATTER, n * 2 * (sizeof(K) + 4), (k_radix_onesweep<K>), nb, (const K *)src, (const uint32_t *)sv, dst, dv, n, sh.shift[p],
+                   (const unsigned long long *)(ghist + (size_t)p * RS_RADIX), status, ctl + p, ctl + 2 * OS_MAX_PASSES);
+        K *tk = src; src = dst; dst = tk; uint32_t *tv = sv; sv = dv; dv = tv;
     }
     *rk = src; *rv = sv;
     c->arena.release_hi(mk);

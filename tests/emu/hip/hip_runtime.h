@@ -177,6 +177,11 @@ template <typename T> static inline T atomicOr(T *p, T v) { T o = *p; *p = o | v
 template <typename T> static inline T atomicExch(T *p, T v) { T o = *p; *p = v; return o; }
 template <typename T> static inline T atomicCAS(T *p, T c, T v) { T o = *p; if (o == c) *p = v; return o; }
 
+#define __HIP_MEMORY_SCOPE_AGENT 4
+template <typename T> static inline T __hip_atomic_load(const T *p, int, int) { return *p; }
+template <typename T, typename V> static inline void __hip_atomic_store(T *p, V v, int, int) { *p = (T)v; }
+static inline void __builtin_amdgcn_s_sleep(int) {}
+
 // ---- host runtime ---------------------------------------------------------------------------
 static inline hipError_t hipMalloc(void **p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 template <typename T> static inline hipError_t hipMalloc(T **p, size_t n) { return hipMalloc((void **)p, n); }
