@@ -109,9 +109,10 @@ __device__ __forceinline__ uint32_t word_rank_of(const EmitArgs &a, uint32_t id)
 // Per suffix-array slot (the random gathers happen here, once per slot, not once per output row):
 // cnt = rows produced (occ of the word if suff_len > w, pfbwt.hpp:114), suffix length, ilist base,
 // preceding byte, whole-word flag (pfbwt.hpp:116), multi-word-group flag (pfbwt.hpp:137).
-__global__ __launch_bounds__(BLOCK) void k_emit_slots(EmitArgs a, uint32_t *cnt, uint32_t *mr, uint32_t *s_sl, uint32_t *s_fb, uint8_t *s_fl, uint8_t *s_pc)
+__global__ __launch_bounds__(BLOCK) void k_emit_slots(EmitArgs a, uint32_t *cnt, unsigned long long *hard_rows, uint32_t *s_sl, uint32_t *s_fb, uint8_t *s_fl, uint8_t *s_pc)
 {
-    __shared__ uint8_t hd[BLOCK + 1];   // is slot (block base + t) the head of its class of equal suffixes
+    __shared__ uint8_t hd[BLOCK + 1];
+    __shared__ uint32_t red[4];   // is slot (block base + t) the head of its class of equal suffixes
     const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     const bool valid = i < a.dsize;
     uint32_t x = 0; uint2 P = make_uint2(0, 0);
@@ -122,10 +123,9 @@ __global__ __launch_bounds__(BLOCK) void k_emit_slots(EmitArgs a, uint32_t *cnt,
         hd[BLOCK] = (nx < a.dsize) ? (a.posinfo[a.SA[nx]].y == (uint32_t)nx ? 1 : 0) : 1;
     }
     __syncthreads();
-    if (!valid) return;
     const uint32_t id = P.x & WID_MASK;
     uint32_t c = 0, sl = 0, fb = 0; uint8_t fl = 0, pc = 0;
-    if (id < a.dwords) {
+    if (valid && id < a.dwords) {
         const uint32_t wsid = a.ws[id];
         sl = a.ws[id + 1] - 1u - x;
         if (sl > (uint32_t)a.w) {
@@ -136,7 +136,10 @@ __global__ __launch_bounds__(BLOCK) void k_emit_slots(EmitArgs a, uint32_t *cnt,
             else { pc = dict_byte4(P.x >> 28); if (pc == Dollar && x - 1 == wsid) pc = 0; }   // pfbwt.hpp:132 "gsa[i]-1 ? dict[..] : 0"
         }
     }
-    cnt[i] = c; mr[i] = (fl & SF_MULTI) ? c : 0u; s_sl[i] = sl; s_fb[i] = fb; s_fl[i] = fl; s_pc[i] = pc;
+    if (valid) { cnt[i] = c; s_sl[i] = sl; s_fb[i] = fb; s_fl[i] = fl; s_pc[i] = pc; }
+    uint32_t tot;   // rows that sit in multi-word groups (the reference's "hard" bookkeeping, pfbwt.hpp:188)
+    (void)block_excl_sum((fl & SF_MULTI) ? c : 0u, red, &tot);
+    if (threadIdx.x == 0 && tot) atomicAdd(hard_rows, (unsigned long long)tot);
 }
 
 __device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t *a, uint32_t n, uint32_t x)
@@ -230,6 +233,20 @@ __global__ __launch_bounds__(BLOCK) void k_run_flags(const uint8_t *bwt, uint64_
 {
     const uint64_t o = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (o < nout) flag[o] = bwt[o] != (o ? bwt[o - 1] : (uint8_t)0) ? 1u : 0u;
+}
+// run count only (no samples wanted): workgroup reduction + one atomic per workgroup
+__global__ __launch_bounds__(BLOCK) void k_run_count(const uint8_t *bwt, uint64_t nout, unsigned long long *runs)
+{
+    __shared__ uint32_t red[4];
+    const uint64_t o0 = ((uint64_t)blockIdx.x * BLOCK + threadIdx.x) * 16;
+    uint32_t cntr = 0;
+    if (o0 < nout) {
+        uint8_t prev = o0 ? bwt[o0 - 1] : (uint8_t)0;
+        for (int k = 0; k < 16 && o0 + k < nout; ++k) { const uint8_t cc = bwt[o0 + k]; cntr += cc != prev; prev = cc; }
+    }
+    uint32_t tot;
+    (void)block_excl_sum(cntr, red, &tot);
+    if (threadIdx.x == 0 && tot) atomicAdd(runs, (unsigned long long)tot);
 }
 // .ssa / .esa pairs, src/pfbwt-f.cpp:306-315 and :325-328
 template <typename SAT> __global__ __launch_bounds__(BLOCK) void k_samples(const uint32_t *flag, const uint32_t *runidx, const SAT *sa, uint64_t nout, uint64_t runs,

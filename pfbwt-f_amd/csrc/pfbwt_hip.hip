@@ -503,15 +503,23 @@ template <typename SAT> static int emit_and_sample(pfp_ctx *c, const EmitArgs &e
     if (any_sa) { PFP_ALLOC_LO(c, sa, SAT, nout); }
     c->d_sa = sa;
     PFP_LAUNCH(c, K_EMIT, nout * (1 + (any_sa ? sizeof(SAT) : 0)) + c->nrows * 9 + c->dsize * 9, (k_emit<SAT>), nblocks(nout, EMIT_TILE), ea, c->d_bwt, sa);
-    // runs
-    uint32_t *flag, *ridx, *d_cnt;
-    PFP_ALLOC_HI(c, flag, uint32_t, nout); PFP_ALLOC_HI(c, ridx, uint32_t, nout); PFP_ALLOC_HI(c, d_cnt, uint32_t, 1);
-    PFP_LAUNCH(c, K_RUNS, nout * 5, k_run_flags, nblocks(nout, BLOCK), (const uint8_t *)c->d_bwt, nout, flag);
-    PFP_TRY((device_scan<uint32_t, 0>(c, flag, ridx, nout, d_cnt)));
-    uint32_t r = 0; PFP_TRY(d2h_u32(c, d_cnt, &r));
-    c->runs = r;
+    // runs (src/pfbwt-f.cpp:304-305); the samples need the index of every run start, the count alone does not
     c->d_ssa = c->d_esa = nullptr;
-    if (want_rssa) {
+    if (!want_rssa) {
+        unsigned long long *d_runs; PFP_ALLOC_HI(c, d_runs, unsigned long long, 1);
+        PFP_HIP(c, hipMemsetAsync(d_runs, 0, 8, c->stream));
+        PFP_LAUNCH(c, K_RUNS, nout, k_run_count, nblocks(nout, 16 * BLOCK), (const uint8_t *)c->d_bwt, nout, d_runs);
+        unsigned long long r = 0;
+        PFP_HIP(c, hipMemcpyAsync(&r, d_runs, 8, hipMemcpyDeviceToHost, c->stream));
+        PFP_HIP(c, hipStreamSynchronize(c->stream));
+        c->runs = r;
+    } else {
+        uint32_t *flag, *ridx, *d_cnt;
+        PFP_ALLOC_HI(c, flag, uint32_t, nout); PFP_ALLOC_HI(c, ridx, uint32_t, nout); PFP_ALLOC_HI(c, d_cnt, uint32_t, 1);
+        PFP_LAUNCH(c, K_RUNS, nout * 5, k_run_flags, nblocks(nout, BLOCK), (const uint8_t *)c->d_bwt, nout, flag);
+        PFP_TRY((device_scan<uint32_t, 0>(c, flag, ridx, nout, d_cnt)));
+        uint32_t r = 0; PFP_TRY(d2h_u32(c, d_cnt, &r));
+        c->runs = r;
         SAT *ssa, *esa;
         PFP_ALLOC_LO(c, ssa, SAT, 2 * (uint64_t)r); PFP_ALLOC_LO(c, esa, SAT, 2 * (uint64_t)r);
         PFP_LAUNCH(c, K_SAMPLES, nout * 8 + (uint64_t)r * 4 * sizeof(SAT), (k_samples<SAT>), nblocks(nout, BLOCK), (const uint32_t *)flag, (const uint32_t *)ridx, (const SAT *)sa, nout, (uint64_t)r, ssa, esa);
@@ -532,12 +540,13 @@ int pfp_bwt_build(pfp_ctx *c, int want_sa, int want_rssa, pfp_bwt_sizes *out)
     const size_t mk = c->arena.mark_hi();
     if (!c->gsa_valid) { PFP_TRY(sort_dict_suffixes(c)); c->lo_after_pbwt = c->arena.mark_lo(); }   // gsacak, pfbwt.hpp:211
     const uint64_t dsize = c->dsize, dwords = c->dwords;
-    uint32_t *F, *cnt, *EB, *d_tot, *mr, *s_sl, *s_fb; uint8_t *s_fl, *s_pc; uint2 *posinfo;
+    uint32_t *F, *cnt, *EB, *d_tot, *s_sl, *s_fb; uint8_t *s_fl, *s_pc; uint2 *posinfo; unsigned long long *d_hard;
     if (dwords > WID_MASK) return PFP_E_TOO_LARGE;
     PFP_ALLOC_HI(c, posinfo, uint2, dsize);
     PFP_LAUNCH(c, K_EMIT_COUNT, dsize * 17, k_pack_posinfo, nblocks(dsize, BLOCK), (const uint8_t *)c->d_dict, (const uint32_t *)c->d_wordid, (const uint32_t *)c->d_grank, dsize, posinfo);
     PFP_ALLOC_HI(c, F, uint32_t, dwords + 1);
-    PFP_ALLOC_HI(c, cnt, uint32_t, dsize); PFP_ALLOC_HI(c, EB, uint32_t, dsize); PFP_ALLOC_HI(c, mr, uint32_t, dsize);
+    PFP_ALLOC_HI(c, cnt, uint32_t, dsize); PFP_ALLOC_HI(c, EB, uint32_t, dsize); PFP_ALLOC_HI(c, d_hard, unsigned long long, 2);
+    PFP_HIP(c, hipMemsetAsync(d_hard, 0, 16, c->stream));
     PFP_ALLOC_HI(c, s_sl, uint32_t, dsize); PFP_ALLOC_HI(c, s_fb, uint32_t, dsize);
     PFP_ALLOC_HI(c, s_fl, uint8_t, dsize); PFP_ALLOC_HI(c, s_pc, uint8_t, dsize);
     PFP_ALLOC_HI(c, d_tot, uint32_t, 4);
@@ -549,11 +558,10 @@ int pfp_bwt_build(pfp_ctx *c, int want_sa, int want_rssa, pfp_bwt_sizes *out)
     ea.SA = c->d_gsa; ea.posinfo = posinfo; ea.ws = c->d_ws; ea.wrank = c->d_wrank;
     ea.occ = c->d_occ; ea.F = F; ea.ilist = c->d_ilist; ea.bwsai = c->d_bwsai; ea.bwlast = c->d_bwlast;
     ea.EB = EB; ea.s_sl = s_sl; ea.s_fb = s_fb; ea.s_fl = s_fl; ea.s_pc = s_pc; ea.nout = 0; ea.n = 0;
-    PFP_LAUNCH(c, K_EMIT_COUNT, dsize * 34, k_emit_slots, nblocks(dsize, BLOCK), ea, cnt, mr, s_sl, s_fb, s_fl, s_pc);
+    PFP_LAUNCH(c, K_EMIT_COUNT, dsize * 34, k_emit_slots, nblocks(dsize, BLOCK), ea, cnt, d_hard, s_sl, s_fb, s_fl, s_pc);
     PFP_TRY((device_scan<uint32_t, 0>(c, cnt, EB, dsize, d_tot)));
-    PFP_TRY((device_scan<uint32_t, 0>(c, mr, mr, dsize, d_tot + 1)));
-    uint32_t tot = 0, hardrows = 0;
-    PFP_HIP(c, hipMemcpyAsync(&hardrows, d_tot + 1, 4, hipMemcpyDeviceToHost, c->stream));
+    uint32_t tot = 0; unsigned long long hardrows = 0;
+    PFP_HIP(c, hipMemcpyAsync(&hardrows, d_hard, 8, hipMemcpyDeviceToHost, c->stream));
     PFP_TRY(d2h_u32(c, d_tot, &tot));
     const uint64_t nout = tot;
     if (nout < 2) return PFP_E_CORRUPT;

@@ -202,7 +202,7 @@ __global__ __launch_bounds__(BLOCK) void k_radix_bases(unsigned long long *ghist
     }
 }
 
-template <typename K> __global__ __launch_bounds__(BLOCK) void k_radix_onesweep(const K *keys, const uint32_t *vals, K *okeys, uint32_t *ovals, uint64_t n, int shift,
+template <typename K, int ITEMS> __global__ __launch_bounds__(BLOCK) void k_radix_onesweep(const K *keys, const uint32_t *vals, K *okeys, uint32_t *ovals, uint64_t n, int shift,
                                                                               const unsigned long long *gbase /*[256]*/, unsigned long long *status /*[tiles][256]*/,
                                                                               uint32_t *ticket, uint32_t *stuck)
 {
@@ -215,10 +215,10 @@ template <typename K> __global__ __launch_bounds__(BLOCK) void k_radix_onesweep(
     for (int w = 0; w < BLOCK / WAVE; ++w) wh[w][threadIdx.x] = 0;
     __syncthreads();
     const uint32_t tile = s_tile;
-    K k[RS_ITEMS]; uint32_t v[RS_ITEMS];
-    const uint64_t base = (uint64_t)tile * RS_TILE + (uint64_t)wave * (RS_ITEMS * WAVE) + lane;
+    K k[ITEMS]; uint32_t v[ITEMS];
+    const uint64_t base = (uint64_t)tile * (BLOCK * ITEMS) + (uint64_t)wave * (ITEMS * WAVE) + lane;
 #pragma unroll
-    for (int it = 0; it < RS_ITEMS; ++it) {
+    for (int it = 0; it < ITEMS; ++it) {
         const uint64_t i = base + (uint64_t)it * WAVE;
         if (i < n) { k[it] = keys[i]; v[it] = vals[i]; atomicAdd(&wh[wave][(unsigned)(k[it] >> shift) & (RS_RADIX - 1)], 1u); }
         else { k[it] = 0; v[it] = 0; }
@@ -258,7 +258,7 @@ template <typename K> __global__ __launch_bounds__(BLOCK) void k_radix_onesweep(
     __syncthreads();
     const unsigned long long lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;
 #pragma unroll
-    for (int it = 0; it < RS_ITEMS; ++it) {
+    for (int it = 0; it < ITEMS; ++it) {
         const uint64_t i = base + (uint64_t)it * WAVE;
         const bool valid = i < n;
         const unsigned d = (unsigned)(k[it] >> shift) & (RS_RADIX - 1);
@@ -287,7 +287,11 @@ template <typename K> inline int radix_sort_pairs(pfp_ctx *c, K *k0, uint32_t *v
     *rk = k0; *rv = v0;
     if (n <= 1) return PFP_OK;
     const size_t mk = c->arena.mark_hi();
-    const unsigned nb = nblocks(n, RS_TILE);
+    static int os_items = 0;   // pairs per thread of the scatter tile: 16 (4096-pair tiles) or 32 (8192)
+    if (!os_items) { const char *e = getenv("PFP_OS_ITEMS"); os_items = (e && atoi(e) == 16) ? 16 : 32; }
+    const int items = (n < (1u << 20)) ? 16 : os_items;
+    const unsigned nb = nblocks(n, (uint64_t)BLOCK * items);
+    const unsigned nbh = nblocks(n, RS_TILE);
     OsShifts sh; sh.npass = 0;
     for (int r = 0; r < nranges; ++r) for (int s = ranges[r].lo; s < ranges[r].hi; s += 8) { if (sh.npass == OS_MAX_PASSES) return PFP_E_ARG; sh.shift[sh.npass++] = s; }
     for (int p = sh.npass; p < OS_MAX_PASSES; ++p) sh.shift[p] = 0;
@@ -297,13 +301,17 @@ template <typename K> inline int radix_sort_pairs(pfp_ctx *c, K *k0, uint32_t *v
     PFP_ALLOC_HI(c, ctl, uint32_t, 2 * OS_MAX_PASSES + 2);   // ticket per pass, then the shared "stuck" counter
     PFP_HIP(c, hipMemsetAsync(ghist, 0, sizeof(unsigned long long) * OS_MAX_PASSES * RS_RADIX, c->stream));
     PFP_HIP(c, hipMemsetAsync(ctl, 0, sizeof(uint32_t) * (2 * OS_MAX_PASSES + 2), c->stream));
-    PFP_LAUNCH(c, K_RADIX_HIST, n * sizeof(K), (k_radix_hist_all<K>), nb, (const K *)k0, n, sh, ghist);
+    PFP_LAUNCH(c, K_RADIX_HIST, n * sizeof(K), (k_radix_hist_all<K>), nbh, (const K *)k0, n, sh, ghist);
     PFP_LAUNCH(c, K_SCAN_SPINE, sh.npass * 4096, k_radix_bases, 1, ghist, sh.npass);
     K *src = k0, *dst = k1; uint32_t *sv = v0, *dv = v1;
     for (int p = 0; p < sh.npass; ++p) {
         PFP_HIP(c, hipMemsetAsync(status, 0, sizeof(unsigned long long) * (size_t)nb * RS_RADIX, c->stream));
-        PFP_LAUNCH(c, K_RADIX_SCATTER, n * 2 * (sizeof(K) + 4), (k_radix_onesweep<K>), nb, (const K *)src, (const uint32_t *)sv, dst, dv, n, sh.shift[p],
-                   (const unsigned long long *)(ghist + (size_t)p * RS_RADIX), status, ctl + p, ctl + 2 * OS_MAX_PASSES);
+        if (items == 16)
+            PFP_LAUNCH(c, K_RADIX_SCATTER, n * 2 * (sizeof(K) + 4), (k_radix_onesweep<K, 16>), nb, (const K *)src, (const uint32_t *)sv, dst, dv, n, sh.shift[p],
+                       (const unsigned long long *)(ghist + (size_t)p * RS_RADIX), status, ctl + p, ctl + 2 * OS_MAX_PASSES);
+        else
+            PFP_LAUNCH(c, K_RADIX_SCATTER, n * 2 * (sizeof(K) + 4), (k_radix_onesweep<K, 32>), nb, (const K *)src, (const uint32_t *)sv, dst, dv, n, sh.shift[p],
+                       (const unsigned long long *)(ghist + (size_t)p * RS_RADIX), status, ctl + p, ctl + 2 * OS_MAX_PASSES);
         K *tk = src; src = dst; dst = tk; uint32_t *tv = sv; sv = dv; dv = tv;
     }
     *rk = src; *rv = sv;
