@@ -204,78 +204,95 @@ __global__ __launch_bounds__(BLOCK) void k_radix_bases(unsigned long long *ghist
 
 template <typename K, int ITEMS> __global__ __launch_bounds__(BLOCK) void k_radix_onesweep(const K *keys, const uint32_t *vals, K *okeys, uint32_t *ovals, uint64_t n, int shift,
                                                                               const unsigned long long *gbase /*[256]*/, unsigned long long *status /*[tiles][256]*/,
-                                                                              uint32_t *ticket, uint32_t *stuck)
+                                                                              uint32_t *ticket, uint32_t *stuck, uint32_t ntiles)
 {
     __shared__ uint32_t wh[BLOCK / WAVE][RS_RADIX];
     __shared__ unsigned long long cur[BLOCK / WAVE][RS_RADIX];
     __shared__ uint32_t s_tile;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
-#pragma unroll
-    for (int w = 0; w < BLOCK / WAVE; ++w) wh[w][threadIdx.x] = 0;
-    __syncthreads();
-    const uint32_t tile = s_tile;
-    K k[ITEMS]; uint32_t v[ITEMS];
-    const uint64_t base = (uint64_t)tile * (BLOCK * ITEMS) + (uint64_t)wave * (ITEMS * WAVE) + lane;
-#pragma unroll
-    for (int it = 0; it < ITEMS; ++it) {
-        const uint64_t i = base + (uint64_t)it * WAVE;
-        if (i < n) { k[it] = keys[i]; v[it] = vals[i]; atomicAdd(&wh[wave][(unsigned)(k[it] >> shift) & (RS_RADIX - 1)], 1u); }
-        else { k[it] = 0; v[it] = 0; }
-    }
-    __syncthreads();
-    {   // thread d owns digit value d
-        const unsigned d = threadIdx.x;
-        uint32_t cw[BLOCK / WAVE]; unsigned long long total = 0;
-#pragma unroll
-        for (int w = 0; w < BLOCK / WAVE; ++w) { cw[w] = wh[w][d]; total += cw[w]; }
-        unsigned long long *mine = status + (size_t)tile * RS_RADIX + d;
-        unsigned long long excl = 0;
-        if (tile == 0) {
-            __hip_atomic_store(mine, OS_FLAG_PREFIX | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            __hip_atomic_store(mine, OS_FLAG_AGG | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            uint32_t t = tile;
-            while (t > 0) {
-                --t;
-                const unsigned long long *pred = status + (size_t)t * RS_RADIX + d;
-                unsigned long long sv = __hip_atomic_load(pred, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                uint32_t spins = 0;
-                while ((sv >> 62) == 0) {              // predecessor has its ticket but has not published yet
-                    __builtin_amdgcn_s_sleep(2);
-                    sv = __hip_atomic_load(pred, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (++spins > (1u << 24)) { atomicAdd(stuck, 1u); break; }   // never expected; bounds the wait
-                }
-                excl += sv & OS_VAL_MASK;
-                if ((sv >> 62) != 1) break;           // inclusive prefix met (or bail-out)
-            }
-            __hip_atomic_store(mine, OS_FLAG_PREFIX | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        unsigned long long run = gbase[d] + excl;
-#pragma unroll
-        for (int w = 0; w < BLOCK / WAVE; ++w) { cur[w][d] = run; run += cw[w]; }
-    }
-    __syncthreads();
     const unsigned long long lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;
+    // Persistent workgroups: each takes tiles by ticket until none is left.  After the first round the
+    // workgroups drift apart in time, which keeps the look-back short (tiles that start in lock-step all
+    // see only aggregates and walk back to the beginning of the batch).
+    for (;;) {
+        if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
 #pragma unroll
-    for (int it = 0; it < ITEMS; ++it) {
-        const uint64_t i = base + (uint64_t)it * WAVE;
-        const bool valid = i < n;
-        const unsigned d = (unsigned)(k[it] >> shift) & (RS_RADIX - 1);
-        unsigned long long peers = __ballot(valid);
+        for (int w = 0; w < BLOCK / WAVE; ++w) wh[w][threadIdx.x] = 0;
+        __syncthreads();
+        const uint32_t tile = s_tile;
+        if (tile >= ntiles) break;                       // uniform: every wave leaves here
+        K k[ITEMS]; uint32_t v[ITEMS];
+        const uint64_t base = (uint64_t)tile * (BLOCK * ITEMS) + (uint64_t)wave * (ITEMS * WAVE) + lane;
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            unsigned long long m = __ballot((d >> b) & 1);
-            peers &= ((d >> b) & 1) ? m : ~m;
+        for (int it = 0; it < ITEMS; ++it) {
+            const uint64_t i = base + (uint64_t)it * WAVE;
+            if (i < n) { k[it] = keys[i]; v[it] = vals[i]; atomicAdd(&wh[wave][(unsigned)(k[it] >> shift) & (RS_RADIX - 1)], 1u); }
+            else { k[it] = 0; v[it] = 0; }
         }
-        const int leader = valid ? (__ffsll((long long)peers) - 1) : lane;
-        unsigned long long old = 0;
-        if (valid && lane == leader) { old = cur[wave][d]; cur[wave][d] = old + (unsigned long long)__popcll(peers); }
-        old = __shfl(old, leader);
-        if (valid) {
-            const unsigned long long dst = old + (unsigned long long)__popcll(peers & lt);
-            okeys[dst] = k[it]; ovals[dst] = v[it];
+        __syncthreads();
+        {   // thread d owns digit value d
+            const unsigned d = threadIdx.x;
+            uint32_t cw[BLOCK / WAVE]; unsigned long long total = 0;
+#pragma unroll
+            for (int w = 0; w < BLOCK / WAVE; ++w) { cw[w] = wh[w][d]; total += cw[w]; }
+            unsigned long long *mine = status + (size_t)tile * RS_RADIX + d;
+            unsigned long long excl = 0;
+            if (tile == 0) {
+                __hip_atomic_store(mine, OS_FLAG_PREFIX | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                __hip_atomic_store(mine, OS_FLAG_AGG | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                constexpr int WIN = 4;                   // predecessors fetched per round trip
+                uint32_t t = tile; bool done = false;
+                while (t > 0 && !done) {
+                    unsigned long long sv[WIN];
+                    const int cntw = t < (uint32_t)WIN ? (int)t : WIN;
+#pragma unroll
+                    for (int j = 0; j < WIN; ++j)
+                        sv[j] = j < cntw ? __hip_atomic_load(status + (size_t)(t - 1 - j) * RS_RADIX + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ULL;
+#pragma unroll
+                    for (int j = 0; j < WIN; ++j) {
+                        if (j < cntw && !done) {
+                            unsigned long long x = sv[j];
+                            uint32_t spins = 0;
+                            while ((x >> 62) == 0) {      // predecessor holds a ticket but has not published yet
+                                __builtin_amdgcn_s_sleep(8);
+                                x = __hip_atomic_load(status + (size_t)(t - 1 - j) * RS_RADIX + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if (++spins > (1u << 22)) { atomicAdd(stuck, 1u); x = OS_FLAG_PREFIX; break; }   // never expected; bounds the wait
+                            }
+                            excl += x & OS_VAL_MASK;
+                            if ((x >> 62) != 1) done = true;   // inclusive prefix met
+                        }
+                    }
+                    t -= (uint32_t)cntw;
+                }
+                __hip_atomic_store(mine, OS_FLAG_PREFIX | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            unsigned long long run = gbase[d] + excl;
+#pragma unroll
+            for (int w = 0; w < BLOCK / WAVE; ++w) { cur[w][d] = run; run += cw[w]; }
         }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            const uint64_t i = base + (uint64_t)it * WAVE;
+            const bool valid = i < n;
+            const unsigned d = (unsigned)(k[it] >> shift) & (RS_RADIX - 1);
+            unsigned long long peers = __ballot(valid);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                unsigned long long m = __ballot((d >> b) & 1);
+                peers &= ((d >> b) & 1) ? m : ~m;
+            }
+            const int leader = valid ? (__ffsll((long long)peers) - 1) : lane;
+            unsigned long long old = 0;
+            if (valid && lane == leader) { old = cur[wave][d]; cur[wave][d] = old + (unsigned long long)__popcll(peers); }
+            old = __shfl(old, leader);
+            if (valid) {
+                const unsigned long long dst = old + (unsigned long long)__popcll(peers & lt);
+                okeys[dst] = k[it]; ovals[dst] = v[it];
+            }
+        }
+        __syncthreads();                                  // wh / cur / s_tile are reused by the next tile
     }
 }
 
@@ -292,6 +309,9 @@ template <typename K> inline int radix_sort_pairs(pfp_ctx *c, K *k0, uint32_t *v
     const int items = (n < (1u << 20)) ? 16 : os_items;
     const unsigned nb = nblocks(n, (uint64_t)BLOCK * items);
     const unsigned nbh = nblocks(n, RS_TILE);
+    static int os_grid = 0;    // persistent workgroups of the scatter kernel (default 3 per CU on a 256-CU device)
+    if (!os_grid) { const char *e = getenv("PFP_OS_GRID"); os_grid = (e && atoi(e) > 0) ? atoi(e) : 768; }
+    const unsigned grid = nb < (unsigned)os_grid ? nb : (unsigned)os_grid;
     OsShifts sh; sh.npass = 0;
     for (int r = 0; r < nranges; ++r) for (int s = ranges[r].lo; s < ranges[r].hi; s += 8) { if (sh.npass == OS_MAX_PASSES) return PFP_E_ARG; sh.shift[sh.npass++] = s; }
     for (int p = sh.npass; p < OS_MAX_PASSES; ++p) sh.shift[p] = 0;
@@ -307,11 +327,11 @@ template <typename K> inline int radix_sort_pairs(pfp_ctx *c, K *k0, uint32_t *v
     for (int p = 0; p < sh.npass; ++p) {
         PFP_HIP(c, hipMemsetAsync(status, 0, sizeof(unsigned long long) * (size_t)nb * RS_RADIX, c->stream));
         if (items == 16)
-            PFP_LAUNCH(c, K_RADIX_SCATTER, n * 2 * (sizeof(K) + 4), (k_radix_onesweep<K, 16>), nb, (const K *)src, (const uint32_t *)sv, dst, dv, n, sh.shift[p],
-                       (const unsigned long long *)(ghist + (size_t)p * RS_RADIX), status, ctl + p, ctl + 2 * OS_MAX_PASSES);
+            PFP_LAUNCH(c, K_RADIX_SCATTER, n * 2 * (sizeof(K) + 4), (k_radix_onesweep<K, 16>), grid, (const K *)src, (const uint32_t *)sv, dst, dv, n, sh.shift[p],
+                       (const unsigned long long *)(ghist + (size_t)p * RS_RADIX), status, ctl + p, ctl + 2 * OS_MAX_PASSES, nb);
         else
-            PFP_LAUNCH(c, K_RADIX_SCATTER, n * 2 * (sizeof(K) + 4), (k_radix_onesweep<K, 32>), nb, (const K *)src, (const uint32_t *)sv, dst, dv, n, sh.shift[p],
-                       (const unsigned long long *)(ghist + (size_t)p * RS_RADIX), status, ctl + p, ctl + 2 * OS_MAX_PASSES);
+            PFP_LAUNCH(c, K_RADIX_SCATTER, n * 2 * (sizeof(K) + 4), (k_radix_onesweep<K, 32>), grid, (const K *)src, (const uint32_t *)sv, dst, dv, n, sh.shift[p],
+                       (const unsigned long long *)(ghist + (size_t)p * RS_RADIX), status, ctl + p, ctl + 2 * OS_MAX_PASSES, nb);
         K *tk = src; src = dst; dst = tk; uint32_t *tv = sv; sv = dv; dv = tv;
     }
     *rk = src; *rv = sv;
