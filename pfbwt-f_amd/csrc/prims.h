@@ -206,14 +206,16 @@ template <typename K, int ITEMS> __global__ __launch_bounds__(BLOCK) void k_radi
                                                                               const unsigned long long *gbase /*[256]*/, unsigned long long *status /*[tiles][256]*/,
                                                                               uint32_t *ticket, uint32_t *stuck, uint32_t ntiles)
 {
-    __shared__ uint32_t wh[BLOCK / WAVE][RS_RADIX];
-    __shared__ unsigned long long cur[BLOCK / WAVE][RS_RADIX];
+    constexpr int TILE = BLOCK * ITEMS;
+    __shared__ uint32_t wh[BLOCK / WAVE][RS_RADIX];      // per-wave digit counts, then per-wave local cursors
+    __shared__ unsigned long long gdelta[RS_RADIX];      // global index of tile-sorted element j with digit d = gdelta[d] + j
+    __shared__ K skeys[TILE];                            // the tile in digit order: global stores become contiguous runs
+    __shared__ uint32_t svals[TILE];
+    __shared__ uint32_t red[4];
     __shared__ uint32_t s_tile;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;
-    // Persistent workgroups: each takes tiles by ticket until none is left.  After the first round the
-    // workgroups drift apart in time, which keeps the look-back short (tiles that start in lock-step all
-    // see only aggregates and walk back to the beginning of the batch).
+    // Persistent workgroups: each takes tiles by ticket until none is left.
     for (;;) {
         if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
 #pragma unroll
@@ -222,7 +224,9 @@ template <typename K, int ITEMS> __global__ __launch_bounds__(BLOCK) void k_radi
         const uint32_t tile = s_tile;
         if (tile >= ntiles) break;                       // uniform: every wave leaves here
         K k[ITEMS]; uint32_t v[ITEMS];
-        const uint64_t base = (uint64_t)tile * (BLOCK * ITEMS) + (uint64_t)wave * (ITEMS * WAVE) + lane;
+        const uint64_t tbase = (uint64_t)tile * TILE;
+        const uint32_t tile_n = (n - tbase) < (uint64_t)TILE ? (uint32_t)(n - tbase) : (uint32_t)TILE;
+        const uint64_t base = tbase + (uint64_t)wave * (ITEMS * WAVE) + lane;
 #pragma unroll
         for (int it = 0; it < ITEMS; ++it) {
             const uint64_t i = base + (uint64_t)it * WAVE;
@@ -232,15 +236,15 @@ template <typename K, int ITEMS> __global__ __launch_bounds__(BLOCK) void k_radi
         __syncthreads();
         {   // thread d owns digit value d
             const unsigned d = threadIdx.x;
-            uint32_t cw[BLOCK / WAVE]; unsigned long long total = 0;
+            uint32_t cw[BLOCK / WAVE]; uint32_t total = 0;
 #pragma unroll
             for (int w = 0; w < BLOCK / WAVE; ++w) { cw[w] = wh[w][d]; total += cw[w]; }
             unsigned long long *mine = status + (size_t)tile * RS_RADIX + d;
             unsigned long long excl = 0;
             if (tile == 0) {
-                __hip_atomic_store(mine, OS_FLAG_PREFIX | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(mine, OS_FLAG_PREFIX | (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {
-                __hip_atomic_store(mine, OS_FLAG_AGG | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(mine, OS_FLAG_AGG | (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 constexpr int WIN = 4;                   // predecessors fetched per round trip
                 uint32_t t = tile; bool done = false;
                 while (t > 0 && !done) {
@@ -265,11 +269,14 @@ template <typename K, int ITEMS> __global__ __launch_bounds__(BLOCK) void k_radi
                     }
                     t -= (uint32_t)cntw;
                 }
-                __hip_atomic_store(mine, OS_FLAG_PREFIX | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(mine, OS_FLAG_PREFIX | (excl + (unsigned long long)total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            unsigned long long run = gbase[d] + excl;
+            uint32_t tt;
+            const uint32_t locbase = block_excl_sum(total, red, &tt);     // first tile-sorted index of digit d
+            gdelta[d] = gbase[d] + excl - (unsigned long long)locbase;
+            uint32_t run = locbase;
 #pragma unroll
-            for (int w = 0; w < BLOCK / WAVE; ++w) { cur[w][d] = run; run += cw[w]; }
+            for (int w = 0; w < BLOCK / WAVE; ++w) { wh[w][d] = run; run += cw[w]; }
         }
         __syncthreads();
 #pragma unroll
@@ -284,15 +291,18 @@ template <typename K, int ITEMS> __global__ __launch_bounds__(BLOCK) void k_radi
                 peers &= ((d >> b) & 1) ? m : ~m;
             }
             const int leader = valid ? (__ffsll((long long)peers) - 1) : lane;
-            unsigned long long old = 0;
-            if (valid && lane == leader) { old = cur[wave][d]; cur[wave][d] = old + (unsigned long long)__popcll(peers); }
+            uint32_t old = 0;
+            if (valid && lane == leader) { old = wh[wave][d]; wh[wave][d] = old + (uint32_t)__popcll(peers); }
             old = __shfl(old, leader);
-            if (valid) {
-                const unsigned long long dst = old + (unsigned long long)__popcll(peers & lt);
-                okeys[dst] = k[it]; ovals[dst] = v[it];
-            }
+            if (valid) { const uint32_t li = old + (uint32_t)__popcll(peers & lt); skeys[li] = k[it]; svals[li] = v[it]; }
         }
-        __syncthreads();                                  // wh / cur / s_tile are reused by the next tile
+        __syncthreads();
+        for (uint32_t j = threadIdx.x; j < tile_n; j += BLOCK) {
+            const K kk = skeys[j];
+            const unsigned long long pos = gdelta[(unsigned)(kk >> shift) & (RS_RADIX - 1)] + j;
+            okeys[pos] = kk; ovals[pos] = svals[j];
+        }
+        __syncthreads();                                  // LDS is reused by the next tile
     }
 }
 
@@ -305,8 +315,8 @@ template <typename K> inline int radix_sort_pairs(pfp_ctx *c, K *k0, uint32_t *v
     if (n <= 1) return PFP_OK;
     const size_t mk = c->arena.mark_hi();
     static int os_items = 0;   // pairs per thread of the scatter tile: 16 (4096-pair tiles) or 32 (8192)
-    if (!os_items) { const char *e = getenv("PFP_OS_ITEMS"); os_items = (e && atoi(e) == 16) ? 16 : 32; }
-    const int items = (n < (1u << 20)) ? 16 : os_items;
+    if (!os_items) { const char *e = getenv("PFP_OS_ITEMS"); os_items = 15; (void)e; }
+    const int items = 15;   // 3840-pair tiles: 52 KiB of LDS -> three workgroups per CU
     const unsigned nb = nblocks(n, (uint64_t)BLOCK * items);
     const unsigned nbh = nblocks(n, RS_TILE);
     static int os_grid = 0;    // persistent workgroups of the scatter kernel (default 3 per CU on a 256-CU device)
@@ -326,12 +336,8 @@ template <typename K> inline int radix_sort_pairs(pfp_ctx *c, K *k0, uint32_t *v
     K *src = k0, *dst = k1; uint32_t *sv = v0, *dv = v1;
     for (int p = 0; p < sh.npass; ++p) {
         PFP_HIP(c, hipMemsetAsync(status, 0, sizeof(unsigned long long) * (size_t)nb * RS_RADIX, c->stream));
-        if (items == 16)
-            PFP_LAUNCH(c, K_RADIX_SCATTER, n * 2 * (sizeof(K) + 4), (k_radix_onesweep<K, 16>), grid, (const K *)src, (const uint32_t *)sv, dst, dv, n, sh.shift[p],
-                       (const unsigned long long *)(ghist + (size_t)p * RS_RADIX), status, ctl + p, ctl + 2 * OS_MAX_PASSES, nb);
-        else
-            PFP_LAUNCH(c, K_RADIX_SCATTER, n * 2 * (sizeof(K) + 4), (k_radix_onesweep<K, 32>), grid, (const K *)src, (const uint32_t *)sv, dst, dv, n, sh.shift[p],
-                       (const unsigned long long *)(ghist + (size_t)p * RS_RADIX), status, ctl + p, ctl + 2 * OS_MAX_PASSES, nb);
+        PFP_LAUNCH(c, K_RADIX_SCATTER, n * 2 * (sizeof(K) + 4), (k_radix_onesweep<K, 15>), grid, (const K *)src, (const uint32_t *)sv, dst, dv, n, sh.shift[p],
+                   (const unsigned long long *)(ghist + (size_t)p * RS_RADIX), status, ctl + p, ctl + 2 * OS_MAX_PASSES, nb);
         K *tk = src; src = dst; dst = tk; uint32_t *tv = sv; sv = dv; dv = tv;
     }
     *rk = src; *rv = sv;
