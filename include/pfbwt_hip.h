@@ -117,6 +117,9 @@ int pfp_profile_get(pfp_ctx *ctx, int idx, const char **name, uint64_t *launches
 /* wall-clock milliseconds of the last call of each stage (host timer around a stream sync):
  * [0] parse_finalize [1] parse_bwt [2] bwt_build */
 int pfp_stage_ms(pfp_ctx *ctx, double out[3]);
+/* development aid: sorts n pseudo-random (key, value) pairs with `bits` significant key bits, returns the best
+ * wall time of `reps` runs and the number of out-of-order neighbours (0 when ablate == 0) */
+int pfp_debug_sort(pfp_ctx *ctx, uint64_t n, int bits, int reps, int ablate, double *ms_out, uint32_t *unsorted_pairs);
 /* library build info: "hip-gfx950" for the product library */
 const char *pfp_backend(void);
 

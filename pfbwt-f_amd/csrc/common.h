@@ -103,6 +103,7 @@ struct pfp_ctx {
     std::vector<hipEvent_t> ev_pool;
     double stage_ms[3] = {0, 0, 0};
     int hip_err = 0;
+    int debug_ablate = 0;
     uint64_t hash_seed = 0x9E3779B97F4A7C15ULL;
 };
 

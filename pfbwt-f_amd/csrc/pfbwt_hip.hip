@@ -606,6 +606,51 @@ int pfp_bwt_device_ptrs(pfp_ctx *c, const void **d_bwt, const void **d_sa, const
     return PFP_OK;
 }
 
+// ---- development aid: time the pair sort on pseudo-random keys (no product path calls this) ----------
+__global__ __launch_bounds__(BLOCK) void k_debug_fill(uint64_t *keys, uint32_t *vals, uint64_t n, int bits, uint64_t seed)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    uint64_t z = (i + seed) * 0x9E3779B97F4A7C15ULL; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL; z ^= z >> 31;
+    keys[i] = bits >= 64 ? z : (z & ((1ULL << bits) - 1ULL)); vals[i] = (uint32_t)i;
+}
+__global__ __launch_bounds__(BLOCK) void k_debug_check_sorted(const uint64_t *keys, uint64_t n, uint32_t *bad)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i + 1 < n && keys[i] > keys[i + 1]) atomicAdd(bad, 1u);
+}
+int pfp_debug_sort(pfp_ctx *c, uint64_t n, int bits, int reps, int ablate, double *ms_out, uint32_t *unsorted_pairs)
+{
+    if (!c || n < 2 || bits < 1 || bits > 64) return PFP_E_ARG;
+    PFP_HIP(c, hipSetDevice(c->device));
+    PFP_TRY(ensure_arena(c, n));
+    c->arena.reset(); c->stage = 0;
+    uint64_t *k0, *k1; uint32_t *v0, *v1, *d_bad;
+    PFP_ALLOC_HI(c, k0, uint64_t, n); PFP_ALLOC_HI(c, k1, uint64_t, n); PFP_ALLOC_HI(c, v0, uint32_t, n); PFP_ALLOC_HI(c, v1, uint32_t, n); PFP_ALLOC_HI(c, d_bad, uint32_t, 1);
+    BitRange br = {0, bits};
+    double best = 1e30;
+    uint64_t *sk = k0; uint32_t *sv = v0;
+    for (int r = 0; r < reps; ++r) {
+        PFP_LAUNCH(c, K_MISC, n * 12, k_debug_fill, nblocks(n, BLOCK), k0, v0, n, bits, (uint64_t)r * 7919);
+        PFP_HIP(c, hipStreamSynchronize(c->stream));
+        c->debug_ablate = ablate;
+        HostTimer t;
+        int rc = radix_sort_pairs<uint64_t>(c, k0, v0, k1, v1, n, &br, 1, &sk, &sv);
+        c->debug_ablate = 0;
+        if (rc != PFP_OK) return rc;
+        PFP_HIP(c, hipStreamSynchronize(c->stream));
+        const double ms = t.ms();
+        if (ms < best) best = ms;
+    }
+    PFP_HIP(c, hipMemsetAsync(d_bad, 0, 4, c->stream));
+    PFP_LAUNCH(c, K_MISC, n * 8, k_debug_check_sorted, nblocks(n, BLOCK), (const uint64_t *)sk, n, d_bad);
+    uint32_t bad = 0; PFP_TRY(d2h_u32(c, d_bad, &bad));
+    if (ms_out) *ms_out = best;
+    if (unsorted_pairs) *unsorted_pairs = bad;
+    c->arena.reset();
+    return PFP_OK;
+}
+
 // ---- gsa/gsacak.h:76-103 drop-ins ------------------------------------------------------------------
 static int sacak_int_impl(const uint32_t *s, void *SA, uint64_t n, uint64_t k, bool u64)
 {

@@ -202,11 +202,12 @@ __global__ __launch_bounds__(BLOCK) void k_radix_bases(unsigned long long *ghist
     }
 }
 
-template <typename K, int ITEMS> __global__ __launch_bounds__(BLOCK) void k_radix_onesweep(const K *keys, const uint32_t *vals, K *okeys, uint32_t *ovals, uint64_t n, int shift,
+template <typename K, int ITEMS, int WIN> __global__ __launch_bounds__(BLOCK) void k_radix_onesweep(const K *keys, const uint32_t *vals, K *okeys, uint32_t *ovals, uint64_t n, int shift,
                                                                               const unsigned long long *gbase /*[256]*/, unsigned long long *status /*[tiles][256]*/,
-                                                                              uint32_t *ticket, uint32_t *stuck, uint32_t ntiles)
+                                                                              uint32_t *ticket, uint32_t *stuck, uint32_t ntiles, int ablate /*timing experiments only*/)
 {
     constexpr int TILE = BLOCK * ITEMS;
+    uint32_t static_tile = blockIdx.x;
     __shared__ uint32_t wh[BLOCK / WAVE][RS_RADIX];      // per-wave digit counts, then per-wave local cursors
     __shared__ unsigned long long gdelta[RS_RADIX];      // global index of tile-sorted element j with digit d = gdelta[d] + j
     __shared__ K skeys[TILE];                            // the tile in digit order: global stores become contiguous runs
@@ -217,7 +218,8 @@ template <typename K, int ITEMS> __global__ __launch_bounds__(BLOCK) void k_radi
     const unsigned long long lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;
     // Persistent workgroups: each takes tiles by ticket until none is left.
     for (;;) {
-        if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+        if (threadIdx.x == 0) { if (ablate & 4) { s_tile = static_tile; } else s_tile = atomicAdd(ticket, 1u); }
+        static_tile += gridDim.x;
 #pragma unroll
         for (int w = 0; w < BLOCK / WAVE; ++w) wh[w][threadIdx.x] = 0;
         __syncthreads();
@@ -241,11 +243,10 @@ template <typename K, int ITEMS> __global__ __launch_bounds__(BLOCK) void k_radi
             for (int w = 0; w < BLOCK / WAVE; ++w) { cw[w] = wh[w][d]; total += cw[w]; }
             unsigned long long *mine = status + (size_t)tile * RS_RADIX + d;
             unsigned long long excl = 0;
-            if (tile == 0) {
+            if (tile == 0 || (ablate & 1)) {
                 __hip_atomic_store(mine, OS_FLAG_PREFIX | (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {
                 __hip_atomic_store(mine, OS_FLAG_AGG | (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                constexpr int WIN = 4;                   // predecessors fetched per round trip
                 uint32_t t = tile; bool done = false;
                 while (t > 0 && !done) {
                     unsigned long long sv[WIN];
@@ -281,6 +282,7 @@ template <typename K, int ITEMS> __global__ __launch_bounds__(BLOCK) void k_radi
         __syncthreads();
 #pragma unroll
         for (int it = 0; it < ITEMS; ++it) {
+            if (ablate & 8) break;
             const uint64_t i = base + (uint64_t)it * WAVE;
             const bool valid = i < n;
             const unsigned d = (unsigned)(k[it] >> shift) & (RS_RADIX - 1);
@@ -298,6 +300,7 @@ template <typename K, int ITEMS> __global__ __launch_bounds__(BLOCK) void k_radi
         }
         __syncthreads();
         for (uint32_t j = threadIdx.x; j < tile_n; j += BLOCK) {
+            if (ablate & 2) break;
             const K kk = skeys[j];
             const unsigned long long pos = gdelta[(unsigned)(kk >> shift) & (RS_RADIX - 1)] + j;
             okeys[pos] = kk; ovals[pos] = svals[j];
@@ -322,6 +325,7 @@ template <typename K> inline int radix_sort_pairs(pfp_ctx *c, K *k0, uint32_t *v
     static int os_grid = 0;    // persistent workgroups of the scatter kernel (default 3 per CU on a 256-CU device)
     if (!os_grid) { const char *e = getenv("PFP_OS_GRID"); os_grid = (e && atoi(e) > 0) ? atoi(e) : 768; }
     const unsigned grid = nb < (unsigned)os_grid ? nb : (unsigned)os_grid;
+    const int os_ablate = c->debug_ablate;   // only pfp_debug_sort sets this (timing experiments on throw-away data)
     OsShifts sh; sh.npass = 0;
     for (int r = 0; r < nranges; ++r) for (int s = ranges[r].lo; s < ranges[r].hi; s += 8) { if (sh.npass == OS_MAX_PASSES) return PFP_E_ARG; sh.shift[sh.npass++] = s; }
     for (int p = sh.npass; p < OS_MAX_PASSES; ++p) sh.shift[p] = 0;
@@ -336,8 +340,8 @@ template <typename K> inline int radix_sort_pairs(pfp_ctx *c, K *k0, uint32_t *v
     K *src = k0, *dst = k1; uint32_t *sv = v0, *dv = v1;
     for (int p = 0; p < sh.npass; ++p) {
         PFP_HIP(c, hipMemsetAsync(status, 0, sizeof(unsigned long long) * (size_t)nb * RS_RADIX, c->stream));
-        PFP_LAUNCH(c, K_RADIX_SCATTER, n * 2 * (sizeof(K) + 4), (k_radix_onesweep<K, 15>), grid, (const K *)src, (const uint32_t *)sv, dst, dv, n, sh.shift[p],
-                   (const unsigned long long *)(ghist + (size_t)p * RS_RADIX), status, ctl + p, ctl + 2 * OS_MAX_PASSES, nb);
+        PFP_LAUNCH(c, K_RADIX_SCATTER, n * 2 * (sizeof(K) + 4), (k_radix_onesweep<K, 15, 4>), grid, (const K *)src, (const uint32_t *)sv, dst, dv, n, sh.shift[p],
+                   (const unsigned long long *)(ghist + (size_t)p * RS_RADIX), status, ctl + p, ctl + 2 * OS_MAX_PASSES, nb, os_ablate & 15);
         K *tk = src; src = dst; dst = tk; uint32_t *tv = sv; sv = dv; dv = tv;
     }
     *rk = src; *rv = sv;
