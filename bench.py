@@ -8,8 +8,10 @@ A "step" = one complete build over one synthetic FASTA-equivalent text that is a
 HBM: parse (trigger scan, phrase de-duplication, dictionary suffix sort, ranks) -> BWT of the parse ->
 BWT + full SA emission, outputs left in HBM.  Workload at N=1: S-chr22 (SURVEY.md 8(d), configs[1] of
 BASELINE.json): one synthetic chromosome, L = 50 818 468, seed 22, two N-runs (10 Mbp + 1 Mbp),
--w 10 -p 100 -s, 32-bit mode.  N>1: every rank builds the index of its own S-chr22-sized text
-(weak scaling over independent texts, no data-path collective; see DESIGN.md "Multi-GPU").
+-w 10 -p 100 -s, 32-bit mode.  N>1 (weak scaling): rank r holds haplotype r of the same synthetic chromosome
+(S-chr22 shape per GPU); every rank parses its shard, ONE RCCL all-gather moves the per-rank dictionaries and
+parses, rank 0 merges them (pfp_merge_shards) and runs the single-GPU stages (parse BWT, dictionary suffix sort,
+emission) for the whole collection -- the design of SURVEY.md 8(e); value = total bases / step time.
 
 Rank 0 prints ONE JSON line with the contract fields plus `roofline` (dominant kernel, HIP-event timed
 inside the timed region) and `cpu_baseline` (oracle/pfbwt_oracle, single thread, same input).
@@ -120,17 +122,26 @@ def main():
     pfbwt_hip.load_library()  # raises if the gfx950 library is absent
 
     L, H, seed, nruns, w, p, u64 = WORKLOADS[a.workload]
-    # rank r builds the index of its own text: same shape, different seed (weak scaling)
-    seqs = synth_seqs(L, H, seed + 1000 * rank, nruns)
+    # rank r holds haplotypes [r*H, (r+1)*H) of the same synthetic collection (weak scaling: fixed bases per GPU)
+    seqs = synth_seqs(L, H, seed, nruns, h0=rank * H)
     d_seqs = [torch.from_numpy(s).to("cuda") for s in seqs]
-    n = sum(int(s.size) + w for s in seqs)
+    n_local = sum(int(s.size) + w for s in seqs)
+    n = n_local * world
     ctx = pfbwt_hip.PfpContext(w=w, p=p, u64=u64, sai=True, device=lrank)
+    dev = torch.device("cuda", lrank)
+
+    def feed_local(c):
+        for t in d_seqs:
+            c.feed_device(t.data_ptr(), t.numel(), True)
 
     def step():
-        for t in d_seqs:
-            ctx.feed_device(t.data_ptr(), t.numel(), True)
-        ctx.finalize(); ctx.parse_bwt()
-        return ctx.bwt_build(sa=True, rssa=False)
+        if world == 1:
+            feed_local(ctx)
+            ctx.finalize(); ctx.parse_bwt()
+            return ctx.bwt_build(sa=True, rssa=False)
+        import pfbwt_dist
+        out = pfbwt_dist.sharded_build(ctx, feed_local, w, dev, sa=True, rssa=False)
+        return out[1] if out is not None else None
 
     def sync():
         torch.cuda.synchronize()
@@ -148,6 +159,8 @@ def main():
             rows = ctx.profile(); ctx.profile_enable(False)
             dominant = max(rows, key=lambda r: r["ms"])["kernel"]
             warm_rows = rows
+            if dist is not None:   # every rank times the kernel that dominates on rank 0 (it runs the single-GPU stages)
+                obj = [dominant]; dist.broadcast_object_list(obj, src=0); dominant = obj[0]
     ctx.profile_select(dominant); ctx.profile_reset()
     sync()
     t0 = time.perf_counter()
@@ -163,9 +176,9 @@ def main():
     dt = float(tt.item())
 
     if rank == 0:
-        out = ctx.bwt_get() if not a.no_cpu_baseline else None
+        out = ctx.bwt_get() if (not a.no_cpu_baseline and world == 1) else None
         ms_per_step = 1e3 * dt / a.steps
-        value = (n * world) / (dt / a.steps) / 1e9
+        value = n / (dt / a.steps) / 1e9
         pr = prof[0]
         ach = pr["bytes"] / pr["launches"] / (pr["ms"] / pr["launches"] * 1e-3) / 1e9
         total_ms = sum(r["ms"] for r in warm_rows)
@@ -175,15 +188,16 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "u8 text / u32 indices / u64 hash", "data": "synthetic",
             "config": {"workload": a.workload, "L": L, "H": H, "seed": seed, "n_runs": list(nruns), "w": w, "p": p, "flags": "-s", "uint_t": 64 if u64 else 32,
                        "n": n, "r": int(b.r), "input": "text resident in HBM, outputs (.bwt, .sa) left in HBM",
-                       "per_rank": "independent text of this shape per rank" if world > 1 else "single GPU"},
+                       "per_rank": ("haplotype r of the collection per rank; parse sharded, one RCCL all-gather of dictionaries, "
+                                    "merge + parse-BWT + dictionary suffix sort + emission on rank 0") if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
                          "launches_per_step": pr["launches"] / a.steps, "avg_launch_us": 1e3 * pr["ms"] / pr["launches"],
                          "alg_bytes_per_launch": pr["bytes"] / pr["launches"],
                          "share_of_kernel_time": max(r["ms"] for r in warm_rows) / total_ms,
-                         "end_to_end_alg_GBps": (6 if not u64 else 10) * n * world / (dt / a.steps) / 1e9},
+                         "end_to_end_alg_GBps": (6 if not u64 else 10) * n / (dt / a.steps) / 1e9},
             "stage_ms": ctx.stage_ms(),
         }
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:
             cb, dig = cpu_baseline(seqs, w, p, u64, True)
             res["cpu_baseline"] = cb
             ok = (hashlib.sha256(out["bwt"].tobytes()).hexdigest() == dig["bwt"] and hashlib.sha256(out["sa"].tobytes()).hexdigest() == dig["sa"])

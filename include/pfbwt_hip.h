@@ -86,6 +86,25 @@ int pfp_parse_bwt(pfp_ctx *ctx);
 /* the three vectors handed to OutFn at pfparser.hpp:466: bwlast m+1 bytes, ilist / bwsai m+1 U-wide */
 int pfp_parse_bwt_get(pfp_ctx *ctx, uint8_t *bwlast, void *ilist, void *bwsai);
 
+/* ---- multi-GPU: sharded parse (semantics of PfParser::operator+=, pfparser.hpp:194-263) ---- */
+/* A shard is a run of whole sequences.  Shard r > 0 is fed the w 'A's that end shard r-1 first (pfp_parse_feed(ctx,
+ * "AAAA...", w, 0)) as left context, then its sequences; every shard is parsed with pfp_parse_finalize on its own GPU.
+ * pfp_shard_view_get exposes the device arrays of a finished local parse (to be copied into send buffers with
+ * pfp_device_copy and exchanged with one RCCL all-gather); pfp_merge_shards takes the N views -- device pointers on
+ * the calling context's GPU -- and leaves that context in the state pfp_parse_finalize would have produced on the
+ * concatenated text (then pfp_parse_get / pfp_parse_bwt / pfp_bwt_build as usual). */
+typedef struct pfp_shard_view {
+    uint64_t n, m, dwords, dsize;   /* n counts the w context bytes of a shard r > 0 */
+    const uint8_t *d_dict;          /* dsize bytes: distinct phrases, each + 0x01, then 0x00 (any order) */
+    const uint32_t *d_ws;           /* dwords+1 word starts in d_dict */
+    const uint32_t *d_pid;          /* m: word id of every phrase */
+    const uint32_t *d_ye;           /* m: 1-based end position of every phrase in the shard's text (= sai) */
+    const uint8_t *d_last;          /* m */
+} pfp_shard_view;
+int pfp_shard_view_get(pfp_ctx *ctx, pfp_shard_view *view);
+int pfp_device_copy(pfp_ctx *ctx, void *d_dst, const void *d_src, uint64_t bytes);
+int pfp_merge_shards(pfp_ctx *ctx, int nshards, const pfp_shard_view *views, pfp_parse_sizes *out);
+
 /* ---- stage 2: BWT / SA ------------------------------------------------------------------------- */
 /* PrefixFreeBWT ctor pfbwt.hpp:64-81, for --pfbwt-only: upload .dict .occ .bwlast .ilist [.bwsai]
  * images (host memory).  Not needed when pfp_parse_finalize + pfp_parse_bwt ran in this context.

@@ -144,21 +144,25 @@ __host__ __device__ __forceinline__ uint64_t powmod61(uint64_t b, uint64_t e)
     return r;
 }
 
-__device__ __forceinline__ void phrase_span(const uint32_t *ye, uint64_t j, int w, uint32_t *ys, uint32_t *len)
+// Where the byte strings to be de-duplicated live: string j = Y[ys_j .. ye[j]].  Text mode (ys == nullptr):
+// consecutive phrases overlap by w bytes, ys_j = ye[j-1] - w + 1, ys_0 = 0.  Word mode (ys != nullptr): explicit
+// starts (dictionary words of several shards laid out in one buffer, see pfp_merge_shards).
+struct Spans { const uint32_t *ye; const uint32_t *ys; int w; };
+__device__ __forceinline__ void phrase_span(const Spans &sp, uint64_t j, uint32_t *ys, uint32_t *len)
 {
-    const uint32_t s = j ? ye[j - 1] - (uint32_t)w + 1u : 0u;
-    *ys = s; *len = ye[j] - s + 1u;
+    const uint32_t s = sp.ys ? sp.ys[j] : (j ? sp.ye[j - 1] - (uint32_t)sp.w + 1u : 0u);
+    *ys = s; *len = sp.ye[j] - s + 1u;
 }
 
 constexpr uint32_t LONG_PHRASE = 2048; // phrases longer than this go to the workgroup-per-phrase kernels
 
 // one thread per phrase
-__global__ __launch_bounds__(BLOCK) void k_phrase_hash(const uint8_t *Y, const uint32_t *ye, uint64_t m, int w, uint64_t B,
+__global__ __launch_bounds__(BLOCK) void k_phrase_hash(const uint8_t *Y, Spans sp, uint64_t m, uint64_t B,
                                                        uint64_t *keys, uint32_t *vals, uint32_t *longlist, uint32_t *nlong)
 {
     const uint64_t j = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (j >= m) return;
-    uint32_t ys, len; phrase_span(ye, j, w, &ys, &len);
+    uint32_t ys, len; phrase_span(sp, j, &ys, &len);
     vals[j] = (uint32_t)j;
     if (len > LONG_PHRASE) { longlist[atomicAdd(nlong, 1u)] = (uint32_t)j; keys[j] = 0; return; }
     uint64_t h = 0;
@@ -173,22 +177,22 @@ constexpr uint32_t LONG_CHUNK = 16384;
 struct LongChunk { uint32_t item; uint32_t a_off, b_off; uint32_t len; }; // item index, two Y offsets of the chunk, chunk length
 
 // spans of listed phrases: out[2k] = ys, out[2k+1] = len
-__global__ __launch_bounds__(BLOCK) void k_list_spans(const uint32_t *ye, int w, const uint32_t *list, uint32_t cnt, uint32_t *out)
+__global__ __launch_bounds__(BLOCK) void k_list_spans(Spans sp, const uint32_t *list, uint32_t cnt, uint32_t *out)
 {
     const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
     if (k >= cnt) return;
-    uint32_t ys, len; phrase_span(ye, list[k], w, &ys, &len);
+    uint32_t ys, len; phrase_span(sp, list[k], &ys, &len);
     out[2 * k] = ys; out[2 * k + 1] = len;
 }
 // same for the two phrases of each listed sorted position i: (vals[i-1], vals[i]); out[3k..] = ys_a, ys_b, len
-__global__ __launch_bounds__(BLOCK) void k_pair_spans(const uint32_t *ye, int w, const uint32_t *vals, const uint32_t *list, uint32_t cnt, uint32_t *out)
+__global__ __launch_bounds__(BLOCK) void k_pair_spans(Spans sp, const uint32_t *vals, const uint32_t *list, uint32_t cnt, uint32_t *out)
 {
     const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
     if (k >= cnt) return;
     const uint32_t i = list[k];
     uint32_t sa_, la, sb, lb;
-    phrase_span(ye, vals[i - 1], w, &sa_, &la);
-    phrase_span(ye, vals[i], w, &sb, &lb);
+    phrase_span(sp, vals[i - 1], &sa_, &la);
+    phrase_span(sp, vals[i], &sb, &lb);
     out[3 * k] = sa_; out[3 * k + 1] = sb; out[3 * k + 2] = la;
 }
 // one workgroup per chunk: polynomial hash of Y[a_off .. a_off+len)
@@ -234,15 +238,15 @@ __global__ __launch_bounds__(BLOCK) void k_dedup_long(const uint8_t *Y, const Lo
 
 // After sorting (key, j): head[i] = 1 where a new distinct phrase starts.  Equal fingerprints are
 // verified byte-for-byte against the predecessor; a mismatch (fingerprint collision) raises *collide.
-__global__ __launch_bounds__(BLOCK) void k_dedup_heads(const uint8_t *Y, const uint32_t *ye, int w, const uint64_t *keys, const uint32_t *vals,
+__global__ __launch_bounds__(BLOCK) void k_dedup_heads(const uint8_t *Y, Spans sp, const uint64_t *keys, const uint32_t *vals,
                                                        uint64_t m, uint32_t *head, uint32_t *longpairs, uint32_t *nlongpairs, uint32_t *collide)
 {
     const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= m) return;
     if (i == 0 || keys[i] != keys[i - 1]) { head[i] = 1; return; }
     uint32_t sa_, la, sb, lb;
-    phrase_span(ye, vals[i - 1], w, &sa_, &la);
-    phrase_span(ye, vals[i], w, &sb, &lb);
+    phrase_span(sp, vals[i - 1], &sa_, &la);
+    phrase_span(sp, vals[i], &sb, &lb);
     if (la != lb) { head[i] = 1; atomicAdd(collide, 1u); return; }
     if (la > LONG_PHRASE) { head[i] = 0; longpairs[atomicAdd(nlongpairs, 1u)] = (uint32_t)i; return; }
     const uint8_t *a = Y + sa_, *b = Y + sb;
@@ -267,12 +271,12 @@ __global__ __launch_bounds__(BLOCK) void k_dedup_scatter(const uint32_t *vals, c
     if (head[i]) { rep[id] = vals[i]; headpos[id] = (uint32_t)i; }
 }
 // wlen1[id] = phrase length + 1 (EndOfWord); occ'[id] = class size
-__global__ __launch_bounds__(BLOCK) void k_word_lengths(const uint32_t *ye, int w, const uint32_t *rep, const uint32_t *headpos, uint64_t dwords, uint64_t m,
+__global__ __launch_bounds__(BLOCK) void k_word_lengths(Spans sp, const uint32_t *rep, const uint32_t *headpos, uint64_t dwords, uint64_t m,
                                                         uint32_t *wlen1, uint32_t *occw)
 {
     const uint64_t id = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (id >= dwords) return;
-    uint32_t ys, len; phrase_span(ye, rep[id], w, &ys, &len);
+    uint32_t ys, len; phrase_span(sp, rep[id], &ys, &len);
     wlen1[id] = len + 1;
     occw[id] = (id + 1 < dwords ? headpos[id + 1] : (uint32_t)m) - headpos[id];
 }
@@ -301,11 +305,11 @@ __global__ __launch_bounds__(BLOCK) void k_dict_build(const uint8_t *src, const 
         if (wordid) wordid[x] = id;
     }
 }
-__global__ __launch_bounds__(BLOCK) void k_rep_starts(const uint32_t *ye, int w, const uint32_t *rep, uint64_t dwords, uint32_t *srcstart)
+__global__ __launch_bounds__(BLOCK) void k_rep_starts(Spans sp, const uint32_t *rep, uint64_t dwords, uint32_t *srcstart)
 {
     const uint64_t id = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (id >= dwords) return;
-    uint32_t ys, len; phrase_span(ye, rep[id], w, &ys, &len);
+    uint32_t ys, len; phrase_span(sp, rep[id], &ys, &len);
     srcstart[id] = ys;
 }
 // last[j] = Y[ye[j] - w]   (pfparser.hpp:599)

@@ -176,11 +176,11 @@ static int sort_dict_suffixes(pfp_ctx *c)
 }
 
 // ---- long phrases: host-built chunk tables (phrases longer than LONG_PHRASE are rare) ----------------
-static int hash_long_phrases(pfp_ctx *c, const uint8_t *Y, const uint32_t *d_longlist, uint32_t nlong, uint64_t B, uint64_t *keys)
+static int hash_long_phrases(pfp_ctx *c, const uint8_t *Y, Spans sp, const uint32_t *d_longlist, uint32_t nlong, uint64_t B, uint64_t *keys)
 {
     const size_t mk = c->arena.mark_hi();
     uint32_t *d_spans; PFP_ALLOC_HI(c, d_spans, uint32_t, 2 * (size_t)nlong);
-    PFP_LAUNCH(c, K_MISC, nlong * 16, k_list_spans, nblocks(nlong, BLOCK), (const uint32_t *)c->d_ye, c->w, d_longlist, nlong, d_spans);
+    PFP_LAUNCH(c, K_MISC, nlong * 16, k_list_spans, nblocks(nlong, BLOCK), sp, d_longlist, nlong, d_spans);
     std::vector<uint32_t> spans(2 * (size_t)nlong);
     PFP_HIP(c, hipMemcpyAsync(spans.data(), d_spans, spans.size() * 4, hipMemcpyDeviceToHost, c->stream));
     PFP_HIP(c, hipStreamSynchronize(c->stream));
@@ -203,11 +203,11 @@ static int hash_long_phrases(pfp_ctx *c, const uint8_t *Y, const uint32_t *d_lon
     c->arena.release_hi(mk);
     return PFP_OK;
 }
-static int compare_long_pairs(pfp_ctx *c, const uint8_t *Y, const uint32_t *d_vals, const uint32_t *d_pairs, uint32_t np, uint32_t *d_collide)
+static int compare_long_pairs(pfp_ctx *c, const uint8_t *Y, Spans sp, const uint32_t *d_vals, const uint32_t *d_pairs, uint32_t np, uint32_t *d_collide)
 {
     const size_t mk = c->arena.mark_hi();
     uint32_t *d_spans; PFP_ALLOC_HI(c, d_spans, uint32_t, 3 * (size_t)np);
-    PFP_LAUNCH(c, K_MISC, np * 24, k_pair_spans, nblocks(np, BLOCK), (const uint32_t *)c->d_ye, c->w, d_vals, d_pairs, np, d_spans);
+    PFP_LAUNCH(c, K_MISC, np * 24, k_pair_spans, nblocks(np, BLOCK), sp, d_vals, d_pairs, np, d_spans);
     std::vector<uint32_t> spans(3 * (size_t)np);
     PFP_HIP(c, hipMemcpyAsync(spans.data(), d_spans, spans.size() * 4, hipMemcpyDeviceToHost, c->stream));
     PFP_HIP(c, hipStreamSynchronize(c->stream));
@@ -222,6 +222,104 @@ static int compare_long_pairs(pfp_ctx *c, const uint8_t *Y, const uint32_t *d_va
     PFP_LAUNCH(c, K_DEDUP_LONG, bytes, k_dedup_long, (unsigned)tab.size(), Y, (const LongChunk *)d_tab, d_collide);
     PFP_HIP(c, hipStreamSynchronize(c->stream));
     c->arena.release_hi(mk);
+    return PFP_OK;
+}
+
+// De-duplicates the m byte strings described by (Y, sp) -- the std::map of pfparser.hpp:69-70, 595-597:
+// fingerprints, stable sort by fingerprint, byte-for-byte verification of equal fingerprints (a collision
+// restarts with another multiplier).  Outputs: number of distinct strings, d_id[j] = id of string j
+// (ids follow fingerprint order), rep[id] = first string with that id, headpos[id] (scratch for class sizes).
+static int dedup_strings(pfp_ctx *c, const uint8_t *Y, Spans sp, uint64_t m, uint64_t total_bytes, uint32_t *d_id, uint64_t *ndistinct, uint32_t **rep_out, uint32_t **headpos_out)
+{
+    uint64_t *hk0, *hk1; uint32_t *hv0, *hv1, *longlist, *head, *ex, *longpairs, *d_u32;
+    PFP_ALLOC_HI(c, hk0, uint64_t, m); PFP_ALLOC_HI(c, hk1, uint64_t, m);
+    PFP_ALLOC_HI(c, hv0, uint32_t, m); PFP_ALLOC_HI(c, hv1, uint32_t, m);
+    const uint64_t maxlong = total_bytes / LONG_PHRASE + 2;
+    PFP_ALLOC_HI(c, longlist, uint32_t, maxlong);
+    PFP_ALLOC_HI(c, longpairs, uint32_t, maxlong);
+    PFP_ALLOC_HI(c, head, uint32_t, m);
+    PFP_ALLOC_HI(c, ex, uint32_t, m);
+    PFP_ALLOC_HI(c, d_u32, uint32_t, 8);
+    uint64_t *sk = nullptr; uint32_t *sv = nullptr;
+    const unsigned gm = nblocks(m, BLOCK);
+    for (int attempt = 0;; ++attempt) {
+        if (attempt == 8) return PFP_E_CORRUPT;
+        // multiplier in [2^32, P61): a fresh one per attempt
+        uint64_t B = (c->hash_seed + 0x9E3779B97F4A7C15ULL * (uint64_t)(attempt + 1));
+        B ^= B >> 31; B *= 0xD6E8FEB86659FD93ULL; B ^= B >> 29;
+        B = (B % (P61 - (1ULL << 32))) + (1ULL << 32);
+        PFP_HIP(c, hipMemsetAsync(d_u32, 0, 32, c->stream));
+        PFP_LAUNCH(c, K_PHRASE_HASH, total_bytes + m * 12, k_phrase_hash, gm, Y, sp, m, B, hk0, hv0, longlist, d_u32 + 1);
+        uint32_t nlong = 0; PFP_TRY(d2h_u32(c, d_u32 + 1, &nlong));
+        if (nlong) PFP_TRY(hash_long_phrases(c, Y, sp, longlist, nlong, B, hk0));
+        BitRange full = {0, 64};
+        PFP_TRY(radix_sort_pairs<uint64_t>(c, hk0, hv0, hk1, hv1, m, &full, 1, &sk, &sv));
+        PFP_LAUNCH(c, K_DEDUP_HEADS, total_bytes + m * 16, k_dedup_heads, gm, Y, sp, (const uint64_t *)sk, (const uint32_t *)sv, m, head, longpairs, d_u32 + 2, d_u32 + 3);
+        uint32_t nlp = 0; PFP_TRY(d2h_u32(c, d_u32 + 2, &nlp));
+        if (nlp) PFP_TRY(compare_long_pairs(c, Y, sp, sv, longpairs, nlp, d_u32 + 3));
+        uint32_t collide = 0; PFP_TRY(d2h_u32(c, d_u32 + 3, &collide));
+        if (!collide) break;
+    }
+    PFP_TRY((device_scan<uint32_t, 0>(c, head, ex, m, d_u32 + 4)));
+    uint32_t dw32 = 0; PFP_TRY(d2h_u32(c, d_u32 + 4, &dw32));
+    uint32_t *rep, *headpos;
+    PFP_ALLOC_HI(c, rep, uint32_t, dw32); PFP_ALLOC_HI(c, headpos, uint32_t, (size_t)dw32 + 1);
+    // ids[i] = ex[i] + head[i] - 1 (0-based id of the distinct string, in fingerprint order)
+    PFP_LAUNCH(c, K_MISC, m * 12, k_dedup_ids, gm, (const uint32_t *)head, ex, m);
+    PFP_LAUNCH(c, K_MISC, m * 20, k_dedup_scatter, gm, (const uint32_t *)sv, (const uint32_t *)head, (const uint32_t *)ex, m, d_id, rep, headpos);
+    *ndistinct = dw32; *rep_out = rep; *headpos_out = headpos;
+    return PFP_OK;
+}
+
+// The dictionary D' (distinct strings in id order, each + EndOfWord, then EndOfDict), its word starts and the
+// word id of every offset.  occw[id] = number of input strings with that id.
+static int build_dictionary(pfp_ctx *c, const uint8_t *Y, Spans sp, const uint32_t *rep, const uint32_t *headpos, uint64_t dwords, uint64_t m, uint32_t **occw_out)
+{
+    uint32_t *wlen1, *occw, *srcstart;
+    PFP_ALLOC_HI(c, wlen1, uint32_t, dwords); PFP_ALLOC_HI(c, occw, uint32_t, dwords); PFP_ALLOC_HI(c, srcstart, uint32_t, dwords);
+    const unsigned gd = nblocks(dwords, BLOCK);
+    PFP_LAUNCH(c, K_MISC, dwords * 16, k_word_lengths, gd, sp, rep, headpos, dwords, m, wlen1, occw);
+    PFP_ALLOC_LO(c, c->d_ws, uint32_t, dwords + 1);
+    PFP_TRY((device_scan<uint32_t, 0>(c, wlen1, c->d_ws, dwords, c->d_ws + dwords)));
+    uint32_t dsm1 = 0; PFP_TRY(d2h_u32(c, c->d_ws + dwords, &dsm1));
+    const uint64_t dsize = (uint64_t)dsm1 + 1;
+    c->dwords = dwords; c->dsize = dsize;
+    if (dsize + 64 >= 0xFFFFFFFFULL) return PFP_E_TOO_LARGE;
+    PFP_ALLOC_LO(c, c->d_dict, uint8_t, dsize + 16);
+    PFP_ALLOC_LO(c, c->d_wordid, uint32_t, dsize);
+    PFP_LAUNCH(c, K_MISC, dwords * 12, k_rep_starts, gd, sp, rep, dwords, srcstart);
+    PFP_LAUNCH(c, K_DICT_BUILD, dsize * 6, k_dict_build, nblocks(dsize, 16 * BLOCK), Y, (const uint32_t *)srcstart, (const uint32_t *)c->d_ws, (uint32_t)dwords, dsize, c->d_dict, c->d_wordid);
+    *occw_out = occw;
+    return PFP_OK;
+}
+
+// From the dictionary to ranks (sort_dict + generate_ranks, pfparser.hpp:494-517), occ (:471-480), the parse
+// and the sorted .dict image.  Needs c->m, d_pid, dwords/dsize/d_ws/d_dict/d_wordid; occw = occurrences per word id.
+static int finish_parse(pfp_ctx *c, const uint32_t *occw)
+{
+    const uint64_t m = c->m, dwords = c->dwords, dsize = c->dsize;
+    const unsigned gm = nblocks(m, BLOCK), gd = nblocks(dwords, BLOCK);
+    // suffix sort of the dictionary: gives word ranks now and the emission order later
+    PFP_TRY(sort_dict_suffixes(c));
+    uint32_t *wk0, *wk1, *wv0, *wv1, *idofrank, *len1, *srcstart;
+    PFP_ALLOC_HI(c, wk0, uint32_t, dwords); PFP_ALLOC_HI(c, wk1, uint32_t, dwords); PFP_ALLOC_HI(c, wv0, uint32_t, dwords); PFP_ALLOC_HI(c, wv1, uint32_t, dwords);
+    PFP_ALLOC_HI(c, idofrank, uint32_t, dwords); PFP_ALLOC_HI(c, len1, uint32_t, dwords + 1); PFP_ALLOC_HI(c, srcstart, uint32_t, dwords);
+    PFP_ALLOC_LO(c, c->d_wrank, uint32_t, dwords);
+    PFP_ALLOC_LO(c, c->d_occ, uint32_t, dwords);
+    PFP_ALLOC_LO(c, c->d_parse, uint32_t, m + 1);
+    PFP_ALLOC_LO(c, c->d_sdict, uint8_t, dsize + 16);
+    {
+        PFP_LAUNCH(c, K_WORD_RANK, dwords * 16, k_wordstart_keys, gd, (const uint32_t *)c->d_ws, (const uint32_t *)c->d_grank, dwords, wk0, wv0);
+        BitRange br = {0, bits_for(dsize)};
+        uint32_t *sk32, *sv32;
+        PFP_TRY(radix_sort_pairs<uint32_t>(c, wk0, wv0, wk1, wv1, dwords, &br, 1, &sk32, &sv32));
+        PFP_LAUNCH(c, K_WORD_RANK, dwords * 20, k_word_rank, gd, (const uint32_t *)sv32, dwords, occw, c->d_wrank, idofrank, c->d_occ);
+    }
+    PFP_LAUNCH(c, K_PARSE_RANKS, m * 12, k_parse_ranks, gm, (const uint32_t *)c->d_pid, (const uint32_t *)c->d_wrank, m, c->d_parse);
+    PFP_LAUNCH(c, K_DICT_SORTED, dwords * 12, k_sorted_lengths, gd, (const uint32_t *)c->d_ws, (const uint32_t *)idofrank, dwords, len1, srcstart);
+    PFP_TRY((device_scan<uint32_t, 0>(c, len1, len1, dwords, len1 + dwords)));
+    PFP_LAUNCH(c, K_DICT_SORTED, dsize * 2, k_dict_build, nblocks(dsize, 16 * BLOCK), (const uint8_t *)c->d_dict, (const uint32_t *)srcstart, (const uint32_t *)len1, (uint32_t)dwords, dsize,
+               c->d_sdict, (uint32_t *)nullptr);
     return PFP_OK;
 }
 
@@ -268,88 +366,167 @@ int pfp_parse_finalize(pfp_ctx *c, pfp_parse_sizes *out)
     PFP_LAUNCH(c, K_PHRASE_ENDS, n / 8 + m * 4, k_phrase_ends, gts, (const uint16_t *)mask16, (const uint32_t *)blockcnt, c->d_ye);
     PFP_LAUNCH(c, K_MISC, 4, k_set_u32, 1, c->d_ye, m - 1, (uint32_t)(n + (uint64_t)w));
 
-    // 2. fingerprints, sort, verified de-duplication
-    uint64_t *hk0, *hk1; uint32_t *hv0, *hv1, *longlist, *head, *ex, *longpairs;
-    PFP_ALLOC_HI(c, hk0, uint64_t, m); PFP_ALLOC_HI(c, hk1, uint64_t, m);
-    PFP_ALLOC_HI(c, hv0, uint32_t, m); PFP_ALLOC_HI(c, hv1, uint32_t, m);
-    const uint64_t maxlong = (n + w + 1) / LONG_PHRASE + 2;
-    PFP_ALLOC_HI(c, longlist, uint32_t, maxlong);
-    PFP_ALLOC_HI(c, longpairs, uint32_t, maxlong);
-    PFP_ALLOC_HI(c, head, uint32_t, m);
-    PFP_ALLOC_HI(c, ex, uint32_t, m);
-    uint64_t *sk = nullptr; uint32_t *sv = nullptr;
-    const unsigned gm = nblocks(m, BLOCK);
-    for (int attempt = 0;; ++attempt) {
-        if (attempt == 8) return PFP_E_CORRUPT;
-        // multiplier in [2^32, P61): a fresh one per attempt
-        uint64_t B = (c->hash_seed + 0x9E3779B97F4A7C15ULL * (uint64_t)(attempt + 1));
-        B ^= B >> 31; B *= 0xD6E8FEB86659FD93ULL; B ^= B >> 29;
-        B = (B % (P61 - (1ULL << 32))) + (1ULL << 32);
-        PFP_HIP(c, hipMemsetAsync(d_u32, 0, 32, c->stream));
-        PFP_LAUNCH(c, K_PHRASE_HASH, n + m * 12, k_phrase_hash, gm, Y, (const uint32_t *)c->d_ye, m, w, B, hk0, hv0, longlist, d_u32 + 1);
-        uint32_t nlong = 0; PFP_TRY(d2h_u32(c, d_u32 + 1, &nlong));
-        if (nlong) PFP_TRY(hash_long_phrases(c, Y, longlist, nlong, B, hk0));
-        BitRange full = {0, 64};
-        PFP_TRY(radix_sort_pairs<uint64_t>(c, hk0, hv0, hk1, hv1, m, &full, 1, &sk, &sv));
-        PFP_LAUNCH(c, K_DEDUP_HEADS, n + m * 16, k_dedup_heads, gm, Y, (const uint32_t *)c->d_ye, w, (const uint64_t *)sk, (const uint32_t *)sv, m, head, longpairs, d_u32 + 2, d_u32 + 3);
-        uint32_t nlp = 0; PFP_TRY(d2h_u32(c, d_u32 + 2, &nlp));
-        if (nlp) PFP_TRY(compare_long_pairs(c, Y, sv, longpairs, nlp, d_u32 + 3));
-        uint32_t collide = 0; PFP_TRY(d2h_u32(c, d_u32 + 3, &collide));
-        if (!collide) break;
-    }
-    PFP_TRY((device_scan<uint32_t, 0>(c, head, ex, m, d_u32 + 4)));
-    uint32_t dw32 = 0; PFP_TRY(d2h_u32(c, d_u32 + 4, &dw32));
-    const uint64_t dwords = dw32; c->dwords = dwords;
-    uint32_t *rep, *headpos, *wlen1, *occw, *srcstart;
+    // 2. distinct phrases, dictionary
+    Spans sp; sp.ye = c->d_ye; sp.ys = nullptr; sp.w = w;
+    uint64_t dwords = 0; uint32_t *rep, *headpos, *occw;
     PFP_ALLOC_LO(c, c->d_pid, uint32_t, m);
-    PFP_ALLOC_HI(c, rep, uint32_t, dwords); PFP_ALLOC_HI(c, headpos, uint32_t, dwords);
-    PFP_ALLOC_HI(c, wlen1, uint32_t, dwords); PFP_ALLOC_HI(c, occw, uint32_t, dwords); PFP_ALLOC_HI(c, srcstart, uint32_t, dwords);
-    // ids[i] = ex[i] + head[i] - 1 (0-based id of the distinct phrase, in fingerprint order)
-    PFP_LAUNCH(c, K_MISC, m * 12, k_dedup_ids, gm, (const uint32_t *)head, ex, m);
-    PFP_LAUNCH(c, K_MISC, m * 20, k_dedup_scatter, gm, (const uint32_t *)sv, (const uint32_t *)head, (const uint32_t *)ex, m, c->d_pid, rep, headpos);
-    const unsigned gd = nblocks(dwords, BLOCK);
-    PFP_LAUNCH(c, K_MISC, dwords * 16, k_word_lengths, gd, (const uint32_t *)c->d_ye, w, (const uint32_t *)rep, (const uint32_t *)headpos, dwords, m, wlen1, occw);
-    PFP_ALLOC_LO(c, c->d_ws, uint32_t, dwords + 1);
-    PFP_TRY((device_scan<uint32_t, 0>(c, wlen1, c->d_ws, dwords, c->d_ws + dwords)));
-    uint32_t dsm1 = 0; PFP_TRY(d2h_u32(c, c->d_ws + dwords, &dsm1));
-    const uint64_t dsize = (uint64_t)dsm1 + 1; c->dsize = dsize;
-    if (dsize + 64 >= 0xFFFFFFFFULL) return PFP_E_TOO_LARGE;
-    PFP_ALLOC_LO(c, c->d_dict, uint8_t, dsize + 16);
-    PFP_ALLOC_LO(c, c->d_wordid, uint32_t, dsize);
-    PFP_LAUNCH(c, K_MISC, dwords * 12, k_rep_starts, gd, (const uint32_t *)c->d_ye, w, (const uint32_t *)rep, dwords, srcstart);
-    PFP_LAUNCH(c, K_DICT_BUILD, dsize * 6, k_dict_build, nblocks(dsize, 16 * BLOCK), Y, (const uint32_t *)srcstart, (const uint32_t *)c->d_ws, (uint32_t)dwords, dsize, c->d_dict, c->d_wordid);
-
-    // 3. suffix sort of the dictionary: gives word ranks now and the emission order later
-    PFP_TRY(sort_dict_suffixes(c));
-
-    // 4. ranks, occ, last, sorted .dict image
-    uint32_t *wk0, *wk1, *wv0, *wv1, *idofrank, *len1;
-    PFP_ALLOC_HI(c, wk0, uint32_t, dwords); PFP_ALLOC_HI(c, wk1, uint32_t, dwords); PFP_ALLOC_HI(c, wv0, uint32_t, dwords); PFP_ALLOC_HI(c, wv1, uint32_t, dwords);
-    PFP_ALLOC_HI(c, idofrank, uint32_t, dwords); PFP_ALLOC_HI(c, len1, uint32_t, dwords + 1);
-    PFP_ALLOC_LO(c, c->d_wrank, uint32_t, dwords);
-    PFP_ALLOC_LO(c, c->d_occ, uint32_t, dwords);
-    PFP_ALLOC_LO(c, c->d_parse, uint32_t, m + 1);
     PFP_ALLOC_LO(c, c->d_last, uint8_t, m);
-    PFP_ALLOC_LO(c, c->d_sdict, uint8_t, dsize + 16);
-    {
-        PFP_LAUNCH(c, K_WORD_RANK, dwords * 16, k_wordstart_keys, gd, (const uint32_t *)c->d_ws, (const uint32_t *)c->d_grank, dwords, wk0, wv0);
-        BitRange br = {0, bits_for(dsize)};
-        uint32_t *sk32, *sv32;
-        PFP_TRY(radix_sort_pairs<uint32_t>(c, wk0, wv0, wk1, wv1, dwords, &br, 1, &sk32, &sv32));
-        PFP_LAUNCH(c, K_WORD_RANK, dwords * 20, k_word_rank, gd, (const uint32_t *)sv32, dwords, (const uint32_t *)occw, c->d_wrank, idofrank, c->d_occ);
-    }
-    PFP_LAUNCH(c, K_PARSE_RANKS, m * 12, k_parse_ranks, gm, (const uint32_t *)c->d_pid, (const uint32_t *)c->d_wrank, m, c->d_parse);
-    PFP_LAUNCH(c, K_MISC, m * 6, k_last_chars, gm, Y, (const uint32_t *)c->d_ye, m, w, c->d_last);
-    PFP_LAUNCH(c, K_DICT_SORTED, dwords * 12, k_sorted_lengths, gd, (const uint32_t *)c->d_ws, (const uint32_t *)idofrank, dwords, len1, srcstart);
-    PFP_TRY((device_scan<uint32_t, 0>(c, len1, len1, dwords, len1 + dwords)));
-    PFP_LAUNCH(c, K_DICT_SORTED, dsize * 2, k_dict_build, nblocks(dsize, 16 * BLOCK), (const uint8_t *)c->d_dict, (const uint32_t *)srcstart, (const uint32_t *)len1, (uint32_t)dwords, dsize,
-               c->d_sdict, (uint32_t *)nullptr);
+    PFP_TRY(dedup_strings(c, Y, sp, m, n + (uint64_t)w + 1 + m * (uint64_t)w, c->d_pid, &dwords, &rep, &headpos));
+    PFP_TRY(build_dictionary(c, Y, sp, rep, headpos, dwords, m, &occw));
+    PFP_LAUNCH(c, K_MISC, m * 6, k_last_chars, nblocks(m, BLOCK), Y, (const uint32_t *)c->d_ye, m, w, c->d_last);
+    // 3. dictionary suffix sort, ranks, occ, parse, sorted .dict image
+    PFP_TRY(finish_parse(c, occw));
     PFP_HIP(c, hipStreamSynchronize(c->stream));
     c->arena.release_hi(mk);
     c->stage = 1;
     c->lo_after_parse = c->arena.mark_lo();
     c->stage_ms[0] = timer.ms();
-    if (out) { out->n = n; out->m = m; out->dwords = dwords; out->dsize = dsize; }
+    if (out) { out->n = n; out->m = m; out->dwords = c->dwords; out->dsize = c->dsize; }
+    return PFP_OK;
+}
+
+// ---- multi-GPU: merge of shard parses (semantics of PfParser::operator+=, pfparser.hpp:194-263) -----
+// Shard r > 0 was parsed as the text  A^w + X_r  (the w 'A's that end shard r-1, pfparser.hpp:335-337, as left
+// context), so its closed phrases are exactly the phrases of the whole text; only its first phrase (Dollar +
+// context + head) and, for r < N-1, its last phrase (tail + w Dollars) are fragments: tail_r + head_{r+1} is
+// the phrase that straddles the boundary.  All dictionaries are laid out in one buffer, the two fragment
+// words of a boundary are re-pointed at the junction word, and the union is de-duplicated like phrases are.
+__global__ __launch_bounds__(BLOCK) void k_merge_spans(const uint32_t *ws, uint32_t dwords, uint32_t ubase, uint32_t coff, uint32_t frag0, uint32_t frag0_ys, uint32_t frag0_ye,
+                                                       uint32_t fragl, uint32_t fragl_ys, uint32_t fragl_ye, uint32_t *ys, uint32_t *ye)
+{
+    const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
+    if (k >= dwords) return;
+    uint32_t a = ubase + ws[k], b = ubase + ws[k + 1] - 2u;   // word bytes without its EndOfWord
+    if (k == frag0) { a = frag0_ys; b = frag0_ye; }
+    if (k == fragl) { a = fragl_ys; b = fragl_ye; }
+    ys[coff + k] = a; ye[coff + k] = b;
+}
+__global__ __launch_bounds__(BLOCK) void k_merge_phrases(const uint32_t *pid, const uint32_t *ye, const uint8_t *last, uint32_t m, uint32_t j0, uint32_t goff, uint32_t coff, uint32_t shift,
+                                                         const uint32_t *cand_id, uint32_t junction_ye, uint32_t junction_last, int has_junction,
+                                                         uint32_t *gpid, uint32_t *gye, uint8_t *glast, uint32_t *occw)
+{
+    const uint32_t j = j0 + blockIdx.x * BLOCK + threadIdx.x;
+    if (j >= m) return;
+    const uint32_t g = goff + j - j0;
+    const uint32_t id = cand_id[coff + pid[j]];
+    gpid[g] = id;
+    atomicAdd(&occw[id], 1u);
+    if (has_junction && j + 1 == m) { gye[g] = junction_ye; glast[g] = (uint8_t)junction_last; }   // the phrase that ends in the next shard
+    else { gye[g] = ye[j] + shift; glast[g] = last[j]; }
+}
+
+int pfp_shard_view_get(pfp_ctx *c, pfp_shard_view *v)
+{
+    if (!c || !v) return PFP_E_ARG;
+    if (c->stage < 1 || !c->d_pid || !c->d_last) return PFP_E_STATE;
+    v->n = c->n; v->m = c->m; v->dwords = c->dwords; v->dsize = c->dsize;
+    v->d_dict = c->d_dict; v->d_ws = c->d_ws; v->d_pid = c->d_pid; v->d_ye = c->d_ye; v->d_last = c->d_last;
+    return PFP_OK;
+}
+
+int pfp_device_copy(pfp_ctx *c, void *d_dst, const void *d_src, uint64_t bytes)
+{
+    if (!c || (!d_dst && bytes) || (!d_src && bytes)) return PFP_E_ARG;
+    PFP_HIP(c, hipSetDevice(c->device));
+    if (bytes) PFP_HIP(c, hipMemcpyAsync(d_dst, d_src, (size_t)bytes, hipMemcpyDeviceToDevice, c->stream));
+    PFP_HIP(c, hipStreamSynchronize(c->stream));
+    return PFP_OK;
+}
+
+int pfp_merge_shards(pfp_ctx *c, int nshards, const pfp_shard_view *v, pfp_parse_sizes *out)
+{
+    if (!c || nshards < 1 || !v) return PFP_E_ARG;
+    PFP_HIP(c, hipSetDevice(c->device));
+    HostTimer timer;
+    const uint32_t w = (uint32_t)c->w;
+    uint64_t ntot = 0, mtot = 0, dtot = 0, ctot = 0;
+    for (int r = 0; r < nshards; ++r) {
+        if (v[r].m < 2 || v[r].n < (r ? w + 1 : 1) || !v[r].d_dict || !v[r].d_ws || !v[r].d_pid || !v[r].d_ye || !v[r].d_last) return PFP_E_ARG;
+        ntot += v[r].n - (r ? w : 0); mtot += v[r].m - (r ? 1 : 0); dtot += v[r].dsize; ctot += v[r].dwords;
+    }
+    if (ntot + w + 64 >= 0xFFFFFFFFULL || dtot + ntot / 8 + 64 >= 0xFFFFFFFFULL) return PFP_E_TOO_LARGE;
+    reset_results(c);
+    PFP_TRY(ensure_arena(c, ntot + dtot));
+    c->arena.reset();
+    PFP_HIP(c, hipStreamSynchronize(c->stream));
+    const size_t mk = c->arena.mark_hi();
+    // ---- host: the two fragment words of every boundary -> junction words
+    struct Frag { uint32_t id0 = 0xFFFFFFFFu, idl = 0xFFFFFFFFu; uint32_t ye0 = 0, last0 = 0; std::vector<uint8_t> w0, wl; };
+    std::vector<Frag> fr((size_t)nshards);
+    auto fetch_word = [&](const pfp_shard_view &sv, uint32_t id, std::vector<uint8_t> &dst) -> int {
+        uint32_t se[2];
+        PFP_HIP(c, hipMemcpy(se, sv.d_ws + id, 8, hipMemcpyDeviceToHost));
+        dst.resize(se[1] - se[0] - 1);
+        if (!dst.empty()) PFP_HIP(c, hipMemcpy(dst.data(), sv.d_dict + se[0], dst.size(), hipMemcpyDeviceToHost));
+        return PFP_OK;
+    };
+    for (int r = 0; r < nshards; ++r) {
+        if (r > 0) {
+            PFP_HIP(c, hipMemcpy(&fr[r].id0, v[r].d_pid, 4, hipMemcpyDeviceToHost));
+            PFP_HIP(c, hipMemcpy(&fr[r].ye0, v[r].d_ye, 4, hipMemcpyDeviceToHost));
+            uint8_t l0 = 0; PFP_HIP(c, hipMemcpy(&l0, v[r].d_last, 1, hipMemcpyDeviceToHost)); fr[r].last0 = l0;
+            PFP_TRY(fetch_word(v[r], fr[r].id0, fr[r].w0));
+            if (fr[r].w0.size() < 1 + (size_t)w) return PFP_E_CORRUPT;
+        }
+        if (r + 1 < nshards) {
+            PFP_HIP(c, hipMemcpy(&fr[r].idl, v[r].d_pid + (v[r].m - 1), 4, hipMemcpyDeviceToHost));
+            PFP_TRY(fetch_word(v[r], fr[r].idl, fr[r].wl));
+            if (fr[r].wl.size() < (size_t)w) return PFP_E_CORRUPT;
+        }
+    }
+    std::vector<uint8_t> junc; std::vector<uint32_t> jstart((size_t)nshards + 1, 0);
+    for (int r = 0; r + 1 < nshards; ++r) {
+        jstart[r] = (uint32_t)junc.size();
+        junc.insert(junc.end(), fr[r].wl.begin(), fr[r].wl.end() - w);                 // tail of shard r without its w Dollars
+        junc.insert(junc.end(), fr[r + 1].w0.begin() + 1 + w, fr[r + 1].w0.end());     // head of shard r+1 without Dollar + context
+        jstart[r + 1] = (uint32_t)junc.size();
+    }
+    // ---- device: one buffer with all dictionaries + junction words, candidate spans
+    uint8_t *U; uint32_t *cys, *cye, *cand_id;
+    PFP_ALLOC_HI(c, U, uint8_t, dtot + junc.size() + 16);
+    PFP_ALLOC_HI(c, cys, uint32_t, ctot); PFP_ALLOC_HI(c, cye, uint32_t, ctot); PFP_ALLOC_HI(c, cand_id, uint32_t, ctot);
+    std::vector<uint32_t> ubase((size_t)nshards), coff((size_t)nshards);
+    { uint64_t ub = 0, co = 0; for (int r = 0; r < nshards; ++r) { ubase[r] = (uint32_t)ub; coff[r] = (uint32_t)co; ub += v[r].dsize; co += v[r].dwords; } }
+    for (int r = 0; r < nshards; ++r) PFP_HIP(c, hipMemcpyAsync(U + ubase[r], v[r].d_dict, (size_t)v[r].dsize, hipMemcpyDeviceToDevice, c->stream));
+    if (!junc.empty()) PFP_HIP(c, hipMemcpyAsync(U + dtot, junc.data(), junc.size(), hipMemcpyHostToDevice, c->stream));
+    for (int r = 0; r < nshards; ++r) {
+        const uint32_t jb = (uint32_t)dtot;
+        const uint32_t f0s = r > 0 ? jb + jstart[r - 1] : 0, f0e = r > 0 ? jb + jstart[r] - 1 : 0;
+        const uint32_t fls = r + 1 < nshards ? jb + jstart[r] : 0, fle = r + 1 < nshards ? jb + jstart[r + 1] - 1 : 0;
+        PFP_LAUNCH(c, K_MISC, v[r].dwords * 12, k_merge_spans, nblocks(v[r].dwords, BLOCK), v[r].d_ws, (uint32_t)v[r].dwords, ubase[r], coff[r],
+                   fr[r].id0, f0s, f0e, fr[r].idl, fls, fle, cys, cye);
+    }
+    // ---- global distinct words, dictionary
+    Spans sp; sp.ye = cye; sp.ys = cys; sp.w = 0;
+    uint64_t dwords = 0; uint32_t *rep, *headpos, *occ_cand, *occw;
+    PFP_TRY(dedup_strings(c, U, sp, ctot, dtot + junc.size(), cand_id, &dwords, &rep, &headpos));
+    PFP_TRY(build_dictionary(c, U, sp, rep, headpos, dwords, ctot, &occ_cand));
+    // ---- global phrase sequence
+    c->n = ntot; c->m = mtot;
+    PFP_ALLOC_LO(c, c->d_pid, uint32_t, mtot); PFP_ALLOC_LO(c, c->d_ye, uint32_t, mtot); PFP_ALLOC_LO(c, c->d_last, uint8_t, mtot);
+    PFP_ALLOC_HI(c, occw, uint32_t, dwords);
+    PFP_HIP(c, hipMemsetAsync(occw, 0, dwords * 4, c->stream));
+    {
+        uint64_t goff = 0, gtext = 0;
+        std::vector<uint32_t> shift((size_t)nshards);
+        { uint64_t g = 0; for (int r = 0; r < nshards; ++r) { shift[r] = r ? (uint32_t)(g - w) : 0u; g += v[r].n - (r ? w : 0); } }
+        (void)gtext;
+        for (int r = 0; r < nshards; ++r) {
+            const uint32_t j0 = r ? 1u : 0u, cnt = (uint32_t)v[r].m - j0;
+            const int hj = r + 1 < nshards;
+            const uint32_t jye = hj ? fr[r + 1].ye0 + shift[r + 1] : 0u, jl = hj ? fr[r + 1].last0 : 0u;
+            PFP_LAUNCH(c, K_MISC, cnt * 24, k_merge_phrases, nblocks(cnt, BLOCK), v[r].d_pid, v[r].d_ye, v[r].d_last, (uint32_t)v[r].m, j0, (uint32_t)goff, coff[r], shift[r],
+                       (const uint32_t *)cand_id, jye, jl, hj, c->d_pid, c->d_ye, c->d_last, occw);
+            goff += cnt;
+        }
+    }
+    PFP_TRY(finish_parse(c, occw));
+    PFP_HIP(c, hipStreamSynchronize(c->stream));
+    c->arena.release_hi(mk);
+    c->stage = 1;
+    c->lo_after_parse = c->arena.mark_lo();
+    c->stage_ms[0] = timer.ms();
+    if (out) { out->n = ntot; out->m = mtot; out->dwords = c->dwords; out->dsize = c->dsize; }
     return PFP_OK;
 }
 

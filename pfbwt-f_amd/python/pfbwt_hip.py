@@ -30,6 +30,15 @@ class BwtSizes(C.Structure):
     _fields_ = [("nout", C.c_uint64), ("r", C.c_uint64), ("easy_cases", C.c_uint64), ("hard_cases", C.c_uint64)]
 
 
+class ShardView(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("m", C.c_uint64), ("dwords", C.c_uint64), ("dsize", C.c_uint64),
+                ("d_dict", C.c_void_p), ("d_ws", C.c_void_p), ("d_pid", C.c_void_p), ("d_ye", C.c_void_p), ("d_last", C.c_void_p)]
+
+    def nbytes(self):
+        """byte sizes of the five device arrays, in field order"""
+        return [self.dsize, 4 * (self.dwords + 1), 4 * self.m, 4 * self.m, self.m]
+
+
 _libs = {}
 
 
@@ -61,6 +70,9 @@ def load_library(path=None):
     L.pfp_bwt_build.argtypes = [vp, i32, i32, C.POINTER(BwtSizes)]
     L.pfp_bwt_get.argtypes = [vp, vp, vp, vp, vp]
     L.pfp_bwt_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    L.pfp_shard_view_get.argtypes = [vp, C.POINTER(ShardView)]
+    L.pfp_device_copy.argtypes = [vp, vp, vp, u64]
+    L.pfp_merge_shards.argtypes = [vp, i32, C.POINTER(ShardView), C.POINTER(ParseSizes)]
     L.pfp_sacak_int_u32.argtypes = [vp, vp, C.c_uint32, C.c_uint32]
     L.pfp_sacak_int_u64.argtypes = [vp, vp, u64, u64]
     L.pfp_profile_enable.argtypes = [vp, i32]
@@ -138,6 +150,26 @@ class PfpContext:
         out = {"bwlast": np.empty(nr, np.uint8), "ilist": np.empty(nr, self.udt), "bwsai": np.empty(nr, self.udt) if self.sai else None}
         self._check(self.L.pfp_parse_bwt_get(self.h, _ptr(out["bwlast"]), _ptr(out["ilist"]), _ptr(out["bwsai"])))
         return out
+
+    # ---- multi-GPU sharding
+    def feed_left_context(self, w):
+        """shard r > 0: the w 'A's that end the previous shard (pfparser.hpp:335-337)"""
+        self.feed(b"A" * w, end_of_seq=False)
+
+    def shard_view(self):
+        v = ShardView()
+        self._check(self.L.pfp_shard_view_get(self.h, C.byref(v)))
+        return v
+
+    def device_copy(self, dst_ptr, src_ptr, nbytes):
+        self._check(self.L.pfp_device_copy(self.h, C.c_void_p(int(dst_ptr)), C.c_void_p(int(src_ptr)), int(nbytes)))
+
+    def merge_shards(self, views):
+        arr = (ShardView * len(views))(*views)
+        s = ParseSizes()
+        self._check(self.L.pfp_merge_shards(self.h, len(views), arr, C.byref(s)))
+        self.sizes = s
+        return s
 
     # ---- stage 2
     def bwt_load(self, dict_, occ, bwlast, ilist, bwsai=None, n_hint=0):

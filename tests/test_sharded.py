@@ -1,0 +1,100 @@
+"""Sharded parse + merge (semantics of PfParser::operator+= / merge_pfp): N local parses merged
+must equal the single parse bit for bit, hence also every later file.
+* CPU: through tests/emu (single process) and through pfbwt_dist with torch.distributed gloo, world size 2.
+* GPU: N contexts on one MI355X (single process)."""
+import ctypes as C
+import os
+import subprocess
+import sys
+import numpy as np
+import pytest
+from pfp_testlib import EMU_SO, ROOT, compare, oracle_run
+
+
+def synth(seed, L, H, nruns=(0, 0, 0, 0)):
+    lib = C.CDLL(os.path.join(ROOT, "pfbwt-f_amd", "lib", "libpfpsynth.so"))
+    lib.pfp_synth_haplotype.argtypes = [C.c_uint64] * 7 + [C.c_void_p]
+    out = []
+    for h in range(H):
+        a = np.empty(L, np.uint8); lib.pfp_synth_haplotype(seed, L, h, *nruns, a.ctypes.data_as(C.c_void_p)); out.append(a.tobytes())
+    return out
+
+
+def sharded_single_process(factory, seqs, shards, w, p, U):
+    ctxs, views = [], []
+    for r, grp in enumerate(shards):
+        c = factory(w=w, p=p, u64=(U == 8), sai=True)
+        if r > 0:
+            c.feed_left_context(w)
+        for i in grp:
+            c.feed(seqs[i], True)
+        c.finalize(); ctxs.append(c); views.append(c.shard_view())
+    g = factory(w=w, p=p, u64=(U == 8), sai=True)
+    sz = g.merge_shards(views)
+    res = {"n": sz.n, "m": sz.m, "dwords": sz.dwords, "dsize": sz.dsize}
+    res.update(g.parse_get()); g.parse_bwt(); res.update(g.parse_bwt_get())
+    b = g.bwt_build(sa=True, rssa=True); res.update(g.bwt_get()); res["r"] = b.r
+    for c in ctxs + [g]:
+        c.close()
+    return res
+
+
+@pytest.fixture(scope="module")
+def emu_factory():
+    subprocess.run(["make", "-C", os.path.join(ROOT, "pfbwt-f_amd"), "emu"], check=True, stdout=subprocess.DEVNULL)
+    import pfbwt_hip
+    return lambda **kw: pfbwt_hip.PfpContext(lib=EMU_SO, **kw)
+
+
+def test_sharded_merge_emu(emu_factory):
+    seqs = synth(5, 4000, 4)
+    for w, p, shards in ((10, 100, [[0], [1], [2], [3]]), (4, 7, [[0, 1], [2, 3]]), (4, 7, [[0], [1, 2, 3]])):
+        ref = oracle_run(seqs, w=w, p=p, U=4)
+        assert compare(sharded_single_process(emu_factory, seqs, shards, w, p, 4), ref, 4) == []
+
+
+WORKER = r'''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.path.join(sys.argv[1], "tests")); sys.path.insert(0, os.path.join(sys.argv[1], "pfbwt-f_amd", "python"))
+from pfp_testlib import EMU_SO, compare, oracle_run
+from test_sharded import synth
+import pfbwt_hip, pfbwt_dist
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+seqs = synth(7, 3000, 2 * world)
+mine = seqs[2 * rank: 2 * rank + 2]
+ctx = pfbwt_hip.PfpContext(lib=EMU_SO, w=6, p=11, u64=False, sai=True)
+out = pfbwt_dist.sharded_build(ctx, lambda c: [c.feed(s, True) for s in mine], 6, torch.device("cpu"), sa=True, rssa=True)
+ok = 1
+if rank == 0:
+    sz, b = out
+    res = {"n": sz.n, "m": sz.m, "dwords": sz.dwords, "dsize": sz.dsize, "r": b.r}
+    res.update(ctx.parse_get()); res.update(ctx.parse_bwt_get()); res.update(ctx.bwt_get())
+    bad = compare(res, oracle_run(seqs, w=6, p=11, U=4), 4)
+    ok = 0 if bad else 1
+    if bad: print("MISMATCH", bad, flush=True)
+t = torch.tensor([ok]); dist.all_reduce(t, op=dist.ReduceOp.MIN)
+dist.barrier(); dist.destroy_process_group()
+sys.exit(0 if int(t) == 1 else 1)
+'''
+
+
+def test_sharded_build_gloo_world2(emu_factory, tmp_path):
+    """the N > 1 path of bench.py (pfbwt_dist.sharded_build: all-gather of dictionaries + merge on rank 0), gloo, 2 ranks"""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    pr = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29641",
+                         str(script), ROOT], capture_output=True, text=True, env=env, timeout=600)
+    assert pr.returncode == 0, pr.stdout[-2000:] + pr.stderr[-3000:]
+
+
+@pytest.mark.gpu
+def test_sharded_merge_gpu(gpu_ctx_factory):
+    seqs = synth(9, 300000, 6, (50000, 40000, 200000, 500))
+    ref = oracle_run(seqs, w=10, p=100, U=4)
+    for shards in ([[0, 1], [2, 3], [4, 5]], [[0], [1], [2], [3], [4], [5]], [[0, 1, 2, 3, 4], [5]]):
+        assert compare(sharded_single_process(gpu_ctx_factory, seqs, shards, 10, 100, 4), ref, 4) == []
+    seqs = synth(10, 60000, 4)
+    ref = oracle_run(seqs, w=4, p=7, U=8)
+    assert compare(sharded_single_process(gpu_ctx_factory, seqs, [[0], [1, 2], [3]], 4, 7, 8), ref, 8) == []
