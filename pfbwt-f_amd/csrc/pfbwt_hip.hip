@@ -810,10 +810,9 @@ int pfp_debug_sort(pfp_ctx *c, uint64_t n, int bits, int reps, int ablate, doubl
     for (int r = 0; r < reps; ++r) {
         PFP_LAUNCH(c, K_MISC, n * 12, k_debug_fill, nblocks(n, BLOCK), k0, v0, n, bits, (uint64_t)r * 7919);
         PFP_HIP(c, hipStreamSynchronize(c->stream));
-        c->debug_ablate = ablate;
+        (void)ablate;
         HostTimer t;
         int rc = radix_sort_pairs<uint64_t>(c, k0, v0, k1, v1, n, &br, 1, &sk, &sv);
-        c->debug_ablate = 0;
         if (rc != PFP_OK) return rc;
         PFP_HIP(c, hipStreamSynchronize(c->stream));
         const double ms = t.ms();

@@ -158,76 +158,87 @@ template <typename T, int OP> inline int device_scan(pfp_ctx *c, const T *in, T 
 // ------------------------------------------------------------------------------------------------
 // LSD radix sort, 8-bit digits, stable.  Tile = 4 waves x 16 rounds x 64 lanes = 4096 pairs; every
 // wave owns a contiguous 1024-pair slice so that order inside the tile is wave-major.
-constexpr int RS_ITEMS = 16;
+constexpr int RS_ITEMS = 15;   // 3840-pair tiles: 52 KiB of LDS in the scatter kernel -> three workgroups per CU
 constexpr int RS_TILE = BLOCK * RS_ITEMS;
 constexpr int RS_RADIX = 256;
 
 struct BitRange { int lo, hi; };
 
-// ---- single-pass ("onesweep") variant: chained scan with decoupled look-back -------------------------
-// One upfront kernel histograms every digit position (keys read once); then each pass is ONE kernel:
-// a workgroup takes a ticket (tile id in arrival order, so a tile only ever waits for tiles that are
-// already running), counts its digits, publishes the tile aggregate, walks back over its predecessors'
-// status words until it meets an inclusive prefix, publishes its own inclusive prefix and scatters.
-// Status word = flag (2 bits) | count (62 bits) in ONE 8-byte word written by one agent-scope relaxed
-// atomic store and read by agent-scope relaxed atomic loads (L1-bypassing): flag and value travel
-// together, so no fence is needed (MI355X_MICROARCH.md "Valid forms": granule needs no ordering).
-constexpr int OS_MAX_PASSES = 8;
-constexpr unsigned long long OS_FLAG_AGG = 1ULL << 62, OS_FLAG_PREFIX = 2ULL << 62, OS_VAL_MASK = (1ULL << 62) - 1ULL;
-struct OsShifts { int shift[OS_MAX_PASSES]; int npass; };
+// One pass = four launches, no inter-workgroup waiting:
+//   k_seg_hist     G workgroups, workgroup b counts the digits of its SEGMENT (a contiguous run of tiles)
+//   k_seg_colscan  256 workgroups: exclusive scan down every digit column of the G x 256 table, column totals
+//   k_seg_dbase    1 workgroup: exclusive scan of the 256 totals
+//   k_seg_scatter  G workgroups: workgroup b walks its segment tile by tile with running per-digit cursors
+//                  (first output index of digit d in segment b = dbase[d] + column prefix[b][d]); every tile is
+//                  put in digit order in LDS first so that the global stores are contiguous runs.
+// A single-pass chained-scan ("onesweep") variant was measured slower on MI355X at this tile size: the
+// look-back over 256 digit counters per tile costs as much as the data movement.
+constexpr int SEG_MAX_GRID = 1024;
 
-template <typename K> __global__ __launch_bounds__(BLOCK) void k_radix_hist_all(const K *keys, uint64_t n, OsShifts sh, unsigned long long *ghist /*[npass][256]*/)
+template <typename K> __global__ __launch_bounds__(BLOCK) void k_seg_hist(const K *keys, uint64_t n, int shift, uint32_t tiles_per_seg, uint32_t *seg /*[G][256]*/)
 {
-    __shared__ uint32_t h[OS_MAX_PASSES][RS_RADIX];
-    for (int p = 0; p < sh.npass; ++p) h[p][threadIdx.x] = 0;
+    __shared__ uint32_t h[RS_RADIX];
+    h[threadIdx.x] = 0;
     __syncthreads();
-    const uint64_t base = (uint64_t)blockIdx.x * RS_TILE + threadIdx.x;
-#pragma unroll 4
-    for (int it = 0; it < RS_ITEMS; ++it) {
-        const uint64_t i = base + (uint64_t)it * BLOCK;
-        if (i < n) { const K k = keys[i]; for (int p = 0; p < sh.npass; ++p) atomicAdd(&h[p][(unsigned)(k >> sh.shift[p]) & (RS_RADIX - 1)], 1u); }
+    const uint64_t s0 = (uint64_t)blockIdx.x * tiles_per_seg * RS_TILE;
+    uint64_t s1 = s0 + (uint64_t)tiles_per_seg * RS_TILE; if (s1 > n) s1 = n;
+    constexpr int U = 8;                                  // independent loads in flight per thread
+    uint64_t i = s0 + threadIdx.x;
+    for (; i + (uint64_t)(U - 1) * BLOCK < s1; i += (uint64_t)U * BLOCK) {
+        K kk[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) kk[u] = keys[i + (uint64_t)u * BLOCK];
+#pragma unroll
+        for (int u = 0; u < U; ++u) atomicAdd(&h[(unsigned)(kk[u] >> shift) & (RS_RADIX - 1)], 1u);
     }
+    for (; i < s1; i += BLOCK) atomicAdd(&h[(unsigned)(keys[i] >> shift) & (RS_RADIX - 1)], 1u);
     __syncthreads();
-    for (int p = 0; p < sh.npass; ++p) { const uint32_t v = h[p][threadIdx.x]; if (v) atomicAdd(&ghist[(size_t)p * RS_RADIX + threadIdx.x], (unsigned long long)v); }
+    seg[(size_t)blockIdx.x * RS_RADIX + threadIdx.x] = h[threadIdx.x];
 }
-// exclusive scan of each pass' 256 global counts -> first output index of every digit value
-__global__ __launch_bounds__(BLOCK) void k_radix_bases(unsigned long long *ghist, int npass)
+// workgroup d: seg[b][d] := sum_{b' < b} seg[b'][d];  total[d] = column sum
+__global__ __launch_bounds__(BLOCK) void k_seg_colscan(uint32_t *seg, uint32_t G, unsigned long long *total)
+{
+    __shared__ uint32_t red[4];
+    const unsigned d = blockIdx.x;
+    uint32_t carry = 0;
+    for (uint32_t b0 = 0; b0 < G; b0 += BLOCK) {
+        const uint32_t b = b0 + threadIdx.x;
+        const uint32_t v = b < G ? seg[(size_t)b * RS_RADIX + d] : 0u;
+        uint32_t tot;
+        const uint32_t e = block_excl_sum(v, red, &tot);
+        if (b < G) seg[(size_t)b * RS_RADIX + d] = carry + e;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) total[d] = carry;
+}
+__global__ __launch_bounds__(BLOCK) void k_seg_dbase(unsigned long long *total)
 {
     __shared__ unsigned long long lds[4];
-    for (int p = 0; p < npass; ++p) {
-        unsigned long long tot;
-        const unsigned long long v = ghist[(size_t)p * RS_RADIX + threadIdx.x];
-        const unsigned long long e = block_excl_sum(v, lds, &tot);
-        ghist[(size_t)p * RS_RADIX + threadIdx.x] = e;
-    }
+    unsigned long long tot;
+    const unsigned long long e = block_excl_sum(total[threadIdx.x], lds, &tot);
+    total[threadIdx.x] = e;
 }
 
-template <typename K, int ITEMS, int WIN> __global__ __launch_bounds__(BLOCK) void k_radix_onesweep(const K *keys, const uint32_t *vals, K *okeys, uint32_t *ovals, uint64_t n, int shift,
-                                                                              const unsigned long long *gbase /*[256]*/, unsigned long long *status /*[tiles][256]*/,
-                                                                              uint32_t *ticket, uint32_t *stuck, uint32_t ntiles, int ablate /*timing experiments only*/)
+template <typename K> __global__ __launch_bounds__(BLOCK) void k_seg_scatter(const K *keys, const uint32_t *vals, K *okeys, uint32_t *ovals, uint64_t n, int shift,
+                                                                           uint32_t tiles_per_seg, const uint32_t *seg /*[G][256] column prefixes*/, const unsigned long long *dbase)
 {
-    constexpr int TILE = BLOCK * ITEMS;
-    uint32_t static_tile = blockIdx.x;
+    constexpr int ITEMS = RS_ITEMS, TILE = RS_TILE;
     __shared__ uint32_t wh[BLOCK / WAVE][RS_RADIX];      // per-wave digit counts, then per-wave local cursors
     __shared__ unsigned long long gdelta[RS_RADIX];      // global index of tile-sorted element j with digit d = gdelta[d] + j
-    __shared__ K skeys[TILE];                            // the tile in digit order: global stores become contiguous runs
+    __shared__ K skeys[TILE];
     __shared__ uint32_t svals[TILE];
     __shared__ uint32_t red[4];
-    __shared__ uint32_t s_tile;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;
-    // Persistent workgroups: each takes tiles by ticket until none is left.
-    for (;;) {
-        if (threadIdx.x == 0) { if (ablate & 4) { s_tile = static_tile; } else s_tile = atomicAdd(ticket, 1u); }
-        static_tile += gridDim.x;
+    unsigned long long cursor = dbase[threadIdx.x] + seg[(size_t)blockIdx.x * RS_RADIX + threadIdx.x];   // thread d: next output index of digit d
+    for (uint32_t tl = 0; tl < tiles_per_seg; ++tl) {
+        const uint64_t tbase = ((uint64_t)blockIdx.x * tiles_per_seg + tl) * TILE;
+        if (tbase >= n) break;                            // uniform
+        const uint32_t tile_n = (n - tbase) < (uint64_t)TILE ? (uint32_t)(n - tbase) : (uint32_t)TILE;
 #pragma unroll
         for (int w = 0; w < BLOCK / WAVE; ++w) wh[w][threadIdx.x] = 0;
         __syncthreads();
-        const uint32_t tile = s_tile;
-        if (tile >= ntiles) break;                       // uniform: every wave leaves here
         K k[ITEMS]; uint32_t v[ITEMS];
-        const uint64_t tbase = (uint64_t)tile * TILE;
-        const uint32_t tile_n = (n - tbase) < (uint64_t)TILE ? (uint32_t)(n - tbase) : (uint32_t)TILE;
         const uint64_t base = tbase + (uint64_t)wave * (ITEMS * WAVE) + lane;
 #pragma unroll
         for (int it = 0; it < ITEMS; ++it) {
@@ -241,40 +252,10 @@ template <typename K, int ITEMS, int WIN> __global__ __launch_bounds__(BLOCK) vo
             uint32_t cw[BLOCK / WAVE]; uint32_t total = 0;
 #pragma unroll
             for (int w = 0; w < BLOCK / WAVE; ++w) { cw[w] = wh[w][d]; total += cw[w]; }
-            unsigned long long *mine = status + (size_t)tile * RS_RADIX + d;
-            unsigned long long excl = 0;
-            if (tile == 0 || (ablate & 1)) {
-                __hip_atomic_store(mine, OS_FLAG_PREFIX | (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                __hip_atomic_store(mine, OS_FLAG_AGG | (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                uint32_t t = tile; bool done = false;
-                while (t > 0 && !done) {
-                    unsigned long long sv[WIN];
-                    const int cntw = t < (uint32_t)WIN ? (int)t : WIN;
-#pragma unroll
-                    for (int j = 0; j < WIN; ++j)
-                        sv[j] = j < cntw ? __hip_atomic_load(status + (size_t)(t - 1 - j) * RS_RADIX + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ULL;
-#pragma unroll
-                    for (int j = 0; j < WIN; ++j) {
-                        if (j < cntw && !done) {
-                            unsigned long long x = sv[j];
-                            uint32_t spins = 0;
-                            while ((x >> 62) == 0) {      // predecessor holds a ticket but has not published yet
-                                __builtin_amdgcn_s_sleep(8);
-                                x = __hip_atomic_load(status + (size_t)(t - 1 - j) * RS_RADIX + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                if (++spins > (1u << 22)) { atomicAdd(stuck, 1u); x = OS_FLAG_PREFIX; break; }   // never expected; bounds the wait
-                            }
-                            excl += x & OS_VAL_MASK;
-                            if ((x >> 62) != 1) done = true;   // inclusive prefix met
-                        }
-                    }
-                    t -= (uint32_t)cntw;
-                }
-                __hip_atomic_store(mine, OS_FLAG_PREFIX | (excl + (unsigned long long)total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
             uint32_t tt;
             const uint32_t locbase = block_excl_sum(total, red, &tt);     // first tile-sorted index of digit d
-            gdelta[d] = gbase[d] + excl - (unsigned long long)locbase;
+            gdelta[d] = cursor - (unsigned long long)locbase;
+            cursor += total;
             uint32_t run = locbase;
 #pragma unroll
             for (int w = 0; w < BLOCK / WAVE; ++w) { wh[w][d] = run; run += cw[w]; }
@@ -282,7 +263,6 @@ template <typename K, int ITEMS, int WIN> __global__ __launch_bounds__(BLOCK) vo
         __syncthreads();
 #pragma unroll
         for (int it = 0; it < ITEMS; ++it) {
-            if (ablate & 8) break;
             const uint64_t i = base + (uint64_t)it * WAVE;
             const bool valid = i < n;
             const unsigned d = (unsigned)(k[it] >> shift) & (RS_RADIX - 1);
@@ -300,7 +280,6 @@ template <typename K, int ITEMS, int WIN> __global__ __launch_bounds__(BLOCK) vo
         }
         __syncthreads();
         for (uint32_t j = threadIdx.x; j < tile_n; j += BLOCK) {
-            if (ablate & 2) break;
             const K kk = skeys[j];
             const unsigned long long pos = gdelta[(unsigned)(kk >> shift) & (RS_RADIX - 1)] + j;
             okeys[pos] = kk; ovals[pos] = svals[j];
@@ -317,32 +296,24 @@ template <typename K> inline int radix_sort_pairs(pfp_ctx *c, K *k0, uint32_t *v
     *rk = k0; *rv = v0;
     if (n <= 1) return PFP_OK;
     const size_t mk = c->arena.mark_hi();
-    static int os_items = 0;   // pairs per thread of the scatter tile: 16 (4096-pair tiles) or 32 (8192)
-    if (!os_items) { const char *e = getenv("PFP_OS_ITEMS"); os_items = 15; (void)e; }
-    const int items = 15;   // 3840-pair tiles: 52 KiB of LDS -> three workgroups per CU
-    const unsigned nb = nblocks(n, (uint64_t)BLOCK * items);
-    const unsigned nbh = nblocks(n, RS_TILE);
-    static int os_grid = 0;    // persistent workgroups of the scatter kernel (default 3 per CU on a 256-CU device)
-    if (!os_grid) { const char *e = getenv("PFP_OS_GRID"); os_grid = (e && atoi(e) > 0) ? atoi(e) : 768; }
-    const unsigned grid = nb < (unsigned)os_grid ? nb : (unsigned)os_grid;
-    const int os_ablate = c->debug_ablate;   // only pfp_debug_sort sets this (timing experiments on throw-away data)
-    OsShifts sh; sh.npass = 0;
-    for (int r = 0; r < nranges; ++r) for (int s = ranges[r].lo; s < ranges[r].hi; s += 8) { if (sh.npass == OS_MAX_PASSES) return PFP_E_ARG; sh.shift[sh.npass++] = s; }
-    for (int p = sh.npass; p < OS_MAX_PASSES; ++p) sh.shift[p] = 0;
-    unsigned long long *ghist, *status; uint32_t *ctl;
-    PFP_ALLOC_HI(c, ghist, unsigned long long, (size_t)OS_MAX_PASSES * RS_RADIX);
-    PFP_ALLOC_HI(c, status, unsigned long long, (size_t)nb * RS_RADIX);
-    PFP_ALLOC_HI(c, ctl, uint32_t, 2 * OS_MAX_PASSES + 2);   // ticket per pass, then the shared "stuck" counter
-    PFP_HIP(c, hipMemsetAsync(ghist, 0, sizeof(unsigned long long) * OS_MAX_PASSES * RS_RADIX, c->stream));
-    PFP_HIP(c, hipMemsetAsync(ctl, 0, sizeof(uint32_t) * (2 * OS_MAX_PASSES + 2), c->stream));
-    PFP_LAUNCH(c, K_RADIX_HIST, n * sizeof(K), (k_radix_hist_all<K>), nbh, (const K *)k0, n, sh, ghist);
-    PFP_LAUNCH(c, K_SCAN_SPINE, sh.npass * 4096, k_radix_bases, 1, ghist, sh.npass);
+    const uint32_t ntiles = nblocks(n, RS_TILE);
+    static int seg_grid = 0;   // workgroups per pass (segments); default 3 per CU of a 256-CU device
+    if (!seg_grid) { const char *e = getenv("PFP_SEG_GRID"); seg_grid = (e && atoi(e) > 0 && atoi(e) <= SEG_MAX_GRID) ? atoi(e) : 768; }
+    const uint32_t tps = (ntiles + (uint32_t)seg_grid - 1) / (uint32_t)seg_grid;   // tiles per segment
+    const uint32_t G = (ntiles + tps - 1) / tps;
+    uint32_t *seg; unsigned long long *total;
+    PFP_ALLOC_HI(c, seg, uint32_t, (size_t)G * RS_RADIX);
+    PFP_ALLOC_HI(c, total, unsigned long long, RS_RADIX);
     K *src = k0, *dst = k1; uint32_t *sv = v0, *dv = v1;
-    for (int p = 0; p < sh.npass; ++p) {
-        PFP_HIP(c, hipMemsetAsync(status, 0, sizeof(unsigned long long) * (size_t)nb * RS_RADIX, c->stream));
-        PFP_LAUNCH(c, K_RADIX_SCATTER, n * 2 * (sizeof(K) + 4), (k_radix_onesweep<K, 15, 4>), grid, (const K *)src, (const uint32_t *)sv, dst, dv, n, sh.shift[p],
-                   (const unsigned long long *)(ghist + (size_t)p * RS_RADIX), status, ctl + p, ctl + 2 * OS_MAX_PASSES, nb, os_ablate & 15);
-        K *tk = src; src = dst; dst = tk; uint32_t *tv = sv; sv = dv; dv = tv;
+    for (int r = 0; r < nranges; ++r) {
+        for (int shift = ranges[r].lo; shift < ranges[r].hi; shift += 8) {
+            PFP_LAUNCH(c, K_RADIX_HIST, n * sizeof(K), (k_seg_hist<K>), G, (const K *)src, n, shift, tps, seg);
+            PFP_LAUNCH(c, K_SCAN_SPINE, (uint64_t)G * RS_RADIX * 8, k_seg_colscan, RS_RADIX, seg, G, total);
+            PFP_LAUNCH(c, K_SCAN_SPINE, RS_RADIX * 16, k_seg_dbase, 1, total);
+            PFP_LAUNCH(c, K_RADIX_SCATTER, n * 2 * (sizeof(K) + 4), (k_seg_scatter<K>), G, (const K *)src, (const uint32_t *)sv, dst, dv, n, shift, tps,
+                       (const uint32_t *)seg, (const unsigned long long *)total);
+            K *tk = src; src = dst; dst = tk; uint32_t *tv = sv; sv = dv; dv = tv;
+        }
     }
     *rk = src; *rv = sv;
     c->arena.release_hi(mk);
