@@ -219,6 +219,17 @@ __global__ __launch_bounds__(BLOCK) void k_seg_dbase(unsigned long long *total)
     total[threadIdx.x] = e;
 }
 
+// few segments (small sorts): one workgroup does the column prefixes and the digit bases
+__global__ __launch_bounds__(BLOCK) void k_seg_small(uint32_t *seg, uint32_t G, unsigned long long *total)
+{
+    __shared__ unsigned long long lds[4];
+    const unsigned d = threadIdx.x;
+    uint32_t run = 0;
+    for (uint32_t b = 0; b < G; ++b) { const uint32_t v = seg[(size_t)b * RS_RADIX + d]; seg[(size_t)b * RS_RADIX + d] = run; run += v; }
+    unsigned long long tot;
+    total[d] = block_excl_sum((unsigned long long)run, lds, &tot);
+}
+
 template <typename K> __global__ __launch_bounds__(BLOCK) void k_seg_scatter(const K *keys, const uint32_t *vals, K *okeys, uint32_t *ovals, uint64_t n, int shift,
                                                                            uint32_t tiles_per_seg, const uint32_t *seg /*[G][256] column prefixes*/, const unsigned long long *dbase)
 {
@@ -308,8 +319,11 @@ template <typename K> inline int radix_sort_pairs(pfp_ctx *c, K *k0, uint32_t *v
     for (int r = 0; r < nranges; ++r) {
         for (int shift = ranges[r].lo; shift < ranges[r].hi; shift += 8) {
             PFP_LAUNCH(c, K_RADIX_HIST, n * sizeof(K), (k_seg_hist<K>), G, (const K *)src, n, shift, tps, seg);
-            PFP_LAUNCH(c, K_SCAN_SPINE, (uint64_t)G * RS_RADIX * 8, k_seg_colscan, RS_RADIX, seg, G, total);
-            PFP_LAUNCH(c, K_SCAN_SPINE, RS_RADIX * 16, k_seg_dbase, 1, total);
+            if (G <= 64) PFP_LAUNCH(c, K_SCAN_SPINE, (uint64_t)G * RS_RADIX * 8, k_seg_small, 1, seg, G, total);
+            else {
+                PFP_LAUNCH(c, K_SCAN_SPINE, (uint64_t)G * RS_RADIX * 8, k_seg_colscan, RS_RADIX, seg, G, total);
+                PFP_LAUNCH(c, K_SCAN_SPINE, RS_RADIX * 16, k_seg_dbase, 1, total);
+            }
             PFP_LAUNCH(c, K_RADIX_SCATTER, n * 2 * (sizeof(K) + 4), (k_seg_scatter<K>), G, (const K *)src, (const uint32_t *)sv, dst, dv, n, shift, tps,
                        (const uint32_t *)seg, (const unsigned long long *)total);
             K *tk = src; src = dst; dst = tk; uint32_t *tv = sv; sv = dv; dv = tv;
