@@ -83,6 +83,7 @@ struct EmitArgs {
     const uint8_t *D; uint64_t dsize; uint32_t dwords; int w;
     const uint32_t *SA, *ws, *wrank /*nullable*/, *occ, *F, *ilist, *bwsai /*nullable*/;
     const uint2 *posinfo;
+    const uint4 *winfo;     // per word id: { first byte, offset of its EndOfWord, first ilist index F[rank], occ[rank] }
     const uint8_t *bwlast;
     const uint32_t *EB;     // exclusive scan of cnt over slots
     const uint32_t *s_sl;   // per slot: suffix length
@@ -97,6 +98,13 @@ constexpr uint8_t SF_MULTI = 1, SF_FULL = 2;
 constexpr uint32_t WID_MASK = 0x0FFFFFFFu;
 __device__ __forceinline__ uint32_t dict_code4(uint32_t c) { return c <= 2 ? c : (c == '-') ? 3u : (c == 'A') ? 4u : (c == 'C') ? 5u : (c == 'G') ? 6u : (c == 'N') ? 7u : 8u; }
 __device__ __forceinline__ uint8_t dict_byte4(uint32_t code) { return code <= 2 ? (uint8_t)code : code == 3 ? (uint8_t)'-' : code == 4 ? (uint8_t)'A' : code == 5 ? (uint8_t)'C' : code == 6 ? (uint8_t)'G' : code == 7 ? (uint8_t)'N' : (uint8_t)'T'; }
+__global__ __launch_bounds__(BLOCK) void k_pack_winfo(const uint32_t *ws, const uint32_t *wrank /*nullable*/, const uint32_t *occ, const uint32_t *F, uint64_t dwords, uint4 *winfo)
+{
+    const uint64_t id = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (id >= dwords) return;
+    const uint32_t rk = wrank ? wrank[id] : (uint32_t)id;
+    winfo[id] = make_uint4(ws[id], ws[id + 1] - 1u, F[rk], occ[rk]);
+}
 __global__ __launch_bounds__(BLOCK) void k_pack_posinfo(const uint8_t *D, const uint32_t *wordid, const uint32_t *grank, uint64_t dsize, uint2 *posinfo)
 {
     const uint64_t x = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -126,11 +134,11 @@ __global__ __launch_bounds__(BLOCK) void k_emit_slots(EmitArgs a, uint32_t *cnt,
     const uint32_t id = P.x & WID_MASK;
     uint32_t c = 0, sl = 0, fb = 0; uint8_t fl = 0, pc = 0;
     if (valid && id < a.dwords) {
-        const uint32_t wsid = a.ws[id];
-        sl = a.ws[id + 1] - 1u - x;
+        const uint4 W = a.winfo[id];
+        const uint32_t wsid = W.x;
+        sl = W.y - x;
         if (sl > (uint32_t)a.w) {
-            const uint32_t rk = word_rank_of(a, id);
-            c = a.occ[rk]; fb = a.F[rk];
+            c = W.w; fb = W.z;
             if (!hd[threadIdx.x] || (i + 1 < a.dsize && !hd[threadIdx.x + 1])) fl |= SF_MULTI;   // group of >= 2 equal suffixes (pfbwt.hpp:137)
             if (x == wsid) fl |= SF_FULL;
             else { pc = dict_byte4(P.x >> 28); if (pc == Dollar && x - 1 == wsid) pc = 0; }   // pfbwt.hpp:132 "gsa[i]-1 ? dict[..] : 0"
@@ -160,7 +168,7 @@ __device__ __forceinline__ uint64_t multi_group_pos(const EmitArgs &a, uint32_t 
     const uint32_t g0 = P.y;
     const uint32_t rk = word_rank_of(a, P.x & WID_MASK);
     uint64_t before = 0;
-    uint32_t first_rk = rk, first_before = 0, first_occ = a.occ[rk]; bool first_full = self_full;
+    uint32_t first_rk = rk, first_before = 0, first_occ = a.winfo[P.x & WID_MASK].w; bool first_full = self_full;
     for (uint32_t s = g0; s < a.dsize; ++s) {
         const uint32_t xs = a.SA[s];
         const uint2 Ps = a.posinfo[xs];
@@ -168,10 +176,11 @@ __device__ __forceinline__ uint64_t multi_group_pos(const EmitArgs &a, uint32_t 
         if (s == i) continue;
         const uint32_t ids = Ps.x & WID_MASK;
         const uint32_t rs = word_rank_of(a, ids);
-        const uint32_t oc = a.occ[rs];
-        const uint32_t lb = lower_bound_u32(a.ilist + a.F[rs], oc, q);
+        const uint4 Ws = a.winfo[ids];
+        const uint32_t oc = Ws.w;
+        const uint32_t lb = lower_bound_u32(a.ilist + Ws.z, oc, q);
         before += lb;
-        if (rs < first_rk) { first_rk = rs; first_before = lb; first_occ = oc; first_full = (xs == a.ws[ids]); }
+        if (rs < first_rk) { first_rk = rs; first_before = lb; first_occ = oc; first_full = (xs == Ws.x); }
     }
     const uint64_t gb = a.EB[g0];
     *full_emits_eow = false;

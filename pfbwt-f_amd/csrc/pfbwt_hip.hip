@@ -717,7 +717,7 @@ int pfp_bwt_build(pfp_ctx *c, int want_sa, int want_rssa, pfp_bwt_sizes *out)
     const size_t mk = c->arena.mark_hi();
     if (!c->gsa_valid) { PFP_TRY(sort_dict_suffixes(c)); c->lo_after_pbwt = c->arena.mark_lo(); }   // gsacak, pfbwt.hpp:211
     const uint64_t dsize = c->dsize, dwords = c->dwords;
-    uint32_t *F, *cnt, *EB, *d_tot, *s_sl, *s_fb; uint8_t *s_fl, *s_pc; uint2 *posinfo; unsigned long long *d_hard;
+    uint32_t *F, *cnt, *EB, *d_tot, *s_sl, *s_fb; uint8_t *s_fl, *s_pc; uint2 *posinfo; uint4 *winfo; unsigned long long *d_hard;
     if (dwords > WID_MASK) return PFP_E_TOO_LARGE;
     PFP_ALLOC_HI(c, posinfo, uint2, dsize);
     PFP_LAUNCH(c, K_EMIT_COUNT, dsize * 17, k_pack_posinfo, nblocks(dsize, BLOCK), (const uint8_t *)c->d_dict, (const uint32_t *)c->d_wordid, (const uint32_t *)c->d_grank, dsize, posinfo);
@@ -734,6 +734,9 @@ int pfp_bwt_build(pfp_ctx *c, int want_sa, int want_rssa, pfp_bwt_sizes *out)
     ea.D = c->d_dict; ea.dsize = dsize; ea.dwords = (uint32_t)dwords; ea.w = c->w;
     ea.SA = c->d_gsa; ea.posinfo = posinfo; ea.ws = c->d_ws; ea.wrank = c->d_wrank;
     ea.occ = c->d_occ; ea.F = F; ea.ilist = c->d_ilist; ea.bwsai = c->d_bwsai; ea.bwlast = c->d_bwlast;
+    PFP_ALLOC_HI(c, winfo, uint4, dwords);
+    PFP_LAUNCH(c, K_MISC, dwords * 32, k_pack_winfo, nblocks(dwords, BLOCK), (const uint32_t *)c->d_ws, (const uint32_t *)c->d_wrank, (const uint32_t *)c->d_occ, (const uint32_t *)F, dwords, winfo);
+    ea.winfo = winfo;
     ea.EB = EB; ea.s_sl = s_sl; ea.s_fb = s_fb; ea.s_fl = s_fl; ea.s_pc = s_pc; ea.nout = 0; ea.n = 0;
     PFP_LAUNCH(c, K_EMIT_COUNT, dsize * 34, k_emit_slots, nblocks(dsize, BLOCK), ea, cnt, d_hard, s_sl, s_fb, s_fl, s_pc);
     PFP_TRY((device_scan<uint32_t, 0>(c, cnt, EB, dsize, d_tot)));
