@@ -182,6 +182,14 @@ def main():
         pr = prof[0]
         ach = pr["bytes"] / pr["launches"] / (pr["ms"] / pr["launches"] * 1e-3) / 1e9
         total_ms = sum(r["ms"] for r in warm_rows)
+        traffic = None
+        try:   # HBM bytes per launch from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/)
+            pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")))
+            for kname, rec in pt.items():
+                if dominant.replace("radix_scatter", "k_seg_scatter").replace("emit_count", "k_emit_slots") in kname or dominant in kname:
+                    traffic = rec["hbm_bytes_per_launch_corrected"]
+        except (OSError, ValueError, KeyError):
+            pass
         res = {
             "metric": "Gbases/s end-to-end BWT+SA build; bit-exact .bwt/.sa vs reference", "value": value, "unit": "Gbases/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
@@ -190,7 +198,7 @@ def main():
                        "n": n, "r": int(b.r), "input": "text resident in HBM, outputs (.bwt, .sa) left in HBM",
                        "per_rank": ("haplotype r of the collection per rank; parse sharded, one RCCL all-gather of dictionaries, "
                                     "merge + parse-BWT + dictionary suffix sort + emission on rank 0") if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": traffic,
                          "launches_per_step": pr["launches"] / a.steps, "avg_launch_us": 1e3 * pr["ms"] / pr["launches"],
                          "alg_bytes_per_launch": pr["bytes"] / pr["launches"],
                          "share_of_kernel_time": max(r["ms"] for r in warm_rows) / total_ms,
