@@ -219,13 +219,18 @@ __global__ __launch_bounds__(BLOCK) void k_seg_dbase(unsigned long long *total)
     total[threadIdx.x] = e;
 }
 
+constexpr uint32_t SEG_SMALL_MAX = 32;
 // few segments (small sorts): one workgroup does the column prefixes and the digit bases
 __global__ __launch_bounds__(BLOCK) void k_seg_small(uint32_t *seg, uint32_t G, unsigned long long *total)
 {
     __shared__ unsigned long long lds[4];
     const unsigned d = threadIdx.x;
+    uint32_t v[SEG_SMALL_MAX];                           // all loads first: the stores below must not serialise them
+#pragma unroll
+    for (uint32_t b = 0; b < SEG_SMALL_MAX; ++b) v[b] = b < G ? seg[(size_t)b * RS_RADIX + d] : 0u;
     uint32_t run = 0;
-    for (uint32_t b = 0; b < G; ++b) { const uint32_t v = seg[(size_t)b * RS_RADIX + d]; seg[(size_t)b * RS_RADIX + d] = run; run += v; }
+#pragma unroll
+    for (uint32_t b = 0; b < SEG_SMALL_MAX; ++b) { if (b < G) seg[(size_t)b * RS_RADIX + d] = run; run += v[b]; }
     unsigned long long tot;
     total[d] = block_excl_sum((unsigned long long)run, lds, &tot);
 }
@@ -299,6 +304,69 @@ template <typename K> __global__ __launch_bounds__(BLOCK) void k_seg_scatter(con
     }
 }
 
+// ---- one tile or less: every pass inside ONE workgroup, the pairs never leave LDS/registers -----------------
+// (late doubling rounds and small parses sort a few hundred to a few thousand pairs; four launches per
+// pass would be pure launch latency)
+constexpr int SMALL_MAX_PASSES = 8;
+struct PassList { int shift[SMALL_MAX_PASSES]; int npass; };
+template <typename K> __global__ __launch_bounds__(BLOCK) void k_small_sort(const K *keys, const uint32_t *vals, K *okeys, uint32_t *ovals, uint32_t n, PassList pl)
+{
+    constexpr int ITEMS = RS_ITEMS, TILE = RS_TILE;
+    __shared__ uint32_t wh[BLOCK / WAVE][RS_RADIX];
+    __shared__ K skeys[TILE];
+    __shared__ uint32_t svals[TILE];
+    __shared__ uint32_t red[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;
+    const uint32_t base = (uint32_t)wave * (ITEMS * WAVE) + lane;
+    for (uint32_t j = threadIdx.x; j < n; j += BLOCK) { skeys[j] = keys[j]; svals[j] = vals[j]; }
+    __syncthreads();
+    for (int p = 0; p < pl.npass; ++p) {
+        const int shift = pl.shift[p];
+        K k[ITEMS]; uint32_t v[ITEMS];
+#pragma unroll
+        for (int w = 0; w < BLOCK / WAVE; ++w) wh[w][threadIdx.x] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            const uint32_t i = base + (uint32_t)it * WAVE;
+            if (i < n) { k[it] = skeys[i]; v[it] = svals[i]; atomicAdd(&wh[wave][(unsigned)(k[it] >> shift) & (RS_RADIX - 1)], 1u); }
+            else { k[it] = 0; v[it] = 0; }
+        }
+        __syncthreads();
+        {
+            const unsigned d = threadIdx.x;
+            uint32_t cw[BLOCK / WAVE]; uint32_t total = 0;
+#pragma unroll
+            for (int w = 0; w < BLOCK / WAVE; ++w) { cw[w] = wh[w][d]; total += cw[w]; }
+            uint32_t tt;
+            uint32_t run = block_excl_sum(total, red, &tt);
+#pragma unroll
+            for (int w = 0; w < BLOCK / WAVE; ++w) { wh[w][d] = run; run += cw[w]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            const uint32_t i = base + (uint32_t)it * WAVE;
+            const bool valid = i < n;
+            const unsigned d = (unsigned)(k[it] >> shift) & (RS_RADIX - 1);
+            unsigned long long peers = __ballot(valid);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                unsigned long long m = __ballot((d >> b) & 1);
+                peers &= ((d >> b) & 1) ? m : ~m;
+            }
+            const int leader = valid ? (__ffsll((long long)peers) - 1) : lane;
+            uint32_t old = 0;
+            if (valid && lane == leader) { old = wh[wave][d]; wh[wave][d] = old + (uint32_t)__popcll(peers); }
+            old = __shfl(old, leader);
+            if (valid) { const uint32_t li = old + (uint32_t)__popcll(peers & lt); skeys[li] = k[it]; svals[li] = v[it]; }
+        }
+        __syncthreads();
+    }
+    for (uint32_t j = threadIdx.x; j < n; j += BLOCK) { okeys[j] = skeys[j]; ovals[j] = svals[j]; }
+}
+
 // Sorts n pairs by the key bits in `ranges` (least significant range first).  Buffers (k0,v0) hold
 // the input; (k1,v1) are scratch of the same size.  On return *rk,*rv point at the sorted arrays.
 template <typename K> inline int radix_sort_pairs(pfp_ctx *c, K *k0, uint32_t *v0, K *k1, uint32_t *v1, uint64_t n,
@@ -306,6 +374,14 @@ template <typename K> inline int radix_sort_pairs(pfp_ctx *c, K *k0, uint32_t *v
 {
     *rk = k0; *rv = v0;
     if (n <= 1) return PFP_OK;
+    if (n <= (uint64_t)RS_TILE) {
+        PassList pl; pl.npass = 0;
+        for (int r = 0; r < nranges; ++r) for (int s = ranges[r].lo; s < ranges[r].hi; s += 8) { if (pl.npass == SMALL_MAX_PASSES) return PFP_E_ARG; pl.shift[pl.npass++] = s; }
+        for (int p = pl.npass; p < SMALL_MAX_PASSES; ++p) pl.shift[p] = 0;
+        PFP_LAUNCH(c, K_RADIX_SCATTER, n * 2 * (sizeof(K) + 4), (k_small_sort<K>), 1, (const K *)k0, (const uint32_t *)v0, k1, v1, (uint32_t)n, pl);
+        *rk = k1; *rv = v1;
+        return PFP_OK;
+    }
     const size_t mk = c->arena.mark_hi();
     const uint32_t ntiles = nblocks(n, RS_TILE);
     static int seg_grid = 0;   // workgroups per pass (segments); default 3 per CU of a 256-CU device
@@ -319,7 +395,7 @@ template <typename K> inline int radix_sort_pairs(pfp_ctx *c, K *k0, uint32_t *v
     for (int r = 0; r < nranges; ++r) {
         for (int shift = ranges[r].lo; shift < ranges[r].hi; shift += 8) {
             PFP_LAUNCH(c, K_RADIX_HIST, n * sizeof(K), (k_seg_hist<K>), G, (const K *)src, n, shift, tps, seg);
-            if (G <= 64) PFP_LAUNCH(c, K_SCAN_SPINE, (uint64_t)G * RS_RADIX * 8, k_seg_small, 1, seg, G, total);
+            if (G <= SEG_SMALL_MAX) PFP_LAUNCH(c, K_SCAN_SPINE, (uint64_t)G * RS_RADIX * 8, k_seg_small, 1, seg, G, total);
             else {
                 PFP_LAUNCH(c, K_SCAN_SPINE, (uint64_t)G * RS_RADIX * 8, k_seg_colscan, RS_RADIX, seg, G, total);
                 PFP_LAUNCH(c, K_SCAN_SPINE, RS_RADIX * 16, k_seg_dbase, 1, total);

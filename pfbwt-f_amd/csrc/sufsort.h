@@ -195,7 +195,9 @@ inline int suffix_sort_doubling(pfp_ctx *c, uint64_t N, uint64_t *k0, uint32_t *
             PFP_TRY((device_scan<uint32_t, 1>(c, M, M, N, nullptr)));
         }
     }
+    static const bool verbose = getenv("PFP_VERBOSE") != nullptr;
     while (na > 0) {
+        if (verbose) fprintf(stderr, "[pfbwt_hip] suffix sort N=%llu round %d: %u active\n", (unsigned long long)N, rounds, na);
         if (rounds > 64) return PFP_E_CORRUPT; // cannot happen on well-formed input
         const unsigned ga = nblocks(na, BLOCK);
         const bool run_round = (M != nullptr && rounds == 1);
