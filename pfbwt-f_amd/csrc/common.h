@@ -85,7 +85,7 @@ struct pfp_ctx {
     uint32_t *d_occ = nullptr;      // dwords, by rank
     uint8_t *d_sdict = nullptr;     // sorted .dict image (dsize), by rank
     uint32_t *d_gsa = nullptr;      // dsize: suffix array of D'
-    uint32_t *d_grank = nullptr;    // dsize: class-head slot of each D' offset
+    uint2 *d_grank = nullptr;       // dsize: { class-head slot, covered-prefix end } of each D' offset (sufsort.h)
     bool gsa_valid = false;
     // --- parse-BWT results
     uint64_t nrows = 0;

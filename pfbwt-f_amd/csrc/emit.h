@@ -38,11 +38,11 @@ __global__ __launch_bounds__(BLOCK) void k_u32_add_store(const uint32_t *in, uin
 // Word ranks (sort_dict + generate_ranks, pfparser.hpp:494-517) from the dictionary suffix sort: the
 // class-head slot of a word's first byte orders the words (two distinct words are never byte-identical,
 // so their whole-word suffixes sit in different classes).  keys = grank[ws[id]], sorted -> rank.
-__global__ __launch_bounds__(BLOCK) void k_wordstart_keys(const uint32_t *ws, const uint32_t *grank, uint64_t dwords, uint32_t *keys, uint32_t *vals)
+__global__ __launch_bounds__(BLOCK) void k_wordstart_keys(const uint32_t *ws, const uint2 *grank, uint64_t dwords, uint32_t *keys, uint32_t *vals)
 {
     const uint64_t id = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (id >= dwords) return;
-    keys[id] = grank[ws[id]]; vals[id] = (uint32_t)id;
+    keys[id] = grank[ws[id]].x; vals[id] = (uint32_t)id;
 }
 __global__ __launch_bounds__(BLOCK) void k_word_rank(const uint32_t *sorted_ids, uint64_t dwords, const uint32_t *occw, uint32_t *wrank, uint32_t *idofrank, uint32_t *occ)
 {
@@ -105,11 +105,11 @@ __global__ __launch_bounds__(BLOCK) void k_pack_winfo(const uint32_t *ws, const 
     const uint32_t rk = wrank ? wrank[id] : (uint32_t)id;
     winfo[id] = make_uint4(ws[id], ws[id + 1] - 1u, F[rk], occ[rk]);
 }
-__global__ __launch_bounds__(BLOCK) void k_pack_posinfo(const uint8_t *D, const uint32_t *wordid, const uint32_t *grank, uint64_t dsize, uint2 *posinfo)
+__global__ __launch_bounds__(BLOCK) void k_pack_posinfo(const uint8_t *D, const uint32_t *wordid, const uint2 *grank, uint64_t dsize, uint2 *posinfo)
 {
     const uint64_t x = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (x >= dsize) return;
-    posinfo[x] = make_uint2(wordid[x] | (dict_code4(x ? D[x - 1] : 0u) << 28), grank[x]);
+    posinfo[x] = make_uint2(wordid[x] | (dict_code4(x ? D[x - 1] : 0u) << 28), grank[x].x);
 }
 
 __device__ __forceinline__ uint32_t word_rank_of(const EmitArgs &a, uint32_t id) { return a.wrank ? a.wrank[id] : id; }

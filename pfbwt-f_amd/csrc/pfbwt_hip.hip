@@ -163,7 +163,7 @@ static int sort_dict_suffixes(pfp_ctx *c)
     const size_t mk = c->arena.mark_hi();
     uint64_t *k0, *k1; uint32_t *v0, *v1;
     PFP_ALLOC_LO(c, c->d_gsa, uint32_t, N);
-    PFP_ALLOC_LO(c, c->d_grank, uint32_t, N);
+    PFP_ALLOC_LO(c, c->d_grank, uint2, N);
     PFP_ALLOC_HI(c, k0, uint64_t, N); PFP_ALLOC_HI(c, k1, uint64_t, N);
     PFP_ALLOC_HI(c, v0, uint32_t, N); PFP_ALLOC_HI(c, v1, uint32_t, N);
     PFP_LAUNCH(c, K_SS_INIT_KEYS, N * 13, k_dict_init_keys, nblocks(N, DK_TILE), (const uint8_t *)c->d_dict, N, k0, v0);
@@ -309,7 +309,7 @@ static int finish_parse(pfp_ctx *c, const uint32_t *occw)
     PFP_ALLOC_LO(c, c->d_parse, uint32_t, m + 1);
     PFP_ALLOC_LO(c, c->d_sdict, uint8_t, dsize + 16);
     {
-        PFP_LAUNCH(c, K_WORD_RANK, dwords * 16, k_wordstart_keys, gd, (const uint32_t *)c->d_ws, (const uint32_t *)c->d_grank, dwords, wk0, wv0);
+        PFP_LAUNCH(c, K_WORD_RANK, dwords * 16, k_wordstart_keys, gd, (const uint32_t *)c->d_ws, (const uint2 *)c->d_grank, dwords, wk0, wv0);
         BitRange br = {0, bits_for(dsize)};
         uint32_t *sk32, *sv32;
         PFP_TRY(radix_sort_pairs<uint32_t>(c, wk0, wv0, wk1, wv1, dwords, &br, 1, &sk32, &sv32));
@@ -558,7 +558,7 @@ int pfp_parse_get(pfp_ctx *c, uint8_t *dict, void *occ, uint32_t *parse, uint8_t
 }
 
 // suffix array of S[0..N) (S[N-1] == 0 unique smallest), integer alphabet with values <= maxsym
-static int sort_int_suffixes(pfp_ctx *c, const uint32_t *dS, uint64_t N, uint64_t maxsym, uint32_t *SA, uint32_t *rank, int *rounds)
+static int sort_int_suffixes(pfp_ctx *c, const uint32_t *dS, uint64_t N, uint64_t maxsym, uint32_t *SA, uint2 *rank, int *rounds)
 {
     const size_t mk = c->arena.mark_hi();
     uint64_t *k0, *k1; uint32_t *v0, *v1;
@@ -583,12 +583,12 @@ int pfp_parse_bwt(pfp_ctx *c)
     const uint64_t m = c->m, N = m + 1;
     const size_t mk = c->arena.mark_hi();
     PFP_LAUNCH(c, K_MISC, 4, k_set_u32, 1, c->d_parse, m, 0u);  // :407-410 (d_parse has m+1 slots)
-    uint32_t *SAP, *rk, *W, *rowid, *W2, *rowid2;
+    uint32_t *SAP, *W, *rowid, *W2, *rowid2; uint2 *rk;
     PFP_ALLOC_LO(c, c->d_bwlast, uint8_t, N);
     PFP_ALLOC_LO(c, c->d_ilist, uint32_t, N);
     const bool sai = (c->flags & PFP_FLAG_SAI) != 0;
     if (sai) PFP_ALLOC_LO(c, c->d_bwsai, uint32_t, N); else c->d_bwsai = nullptr;
-    PFP_ALLOC_HI(c, SAP, uint32_t, N); PFP_ALLOC_HI(c, rk, uint32_t, N);
+    PFP_ALLOC_HI(c, SAP, uint32_t, N); PFP_ALLOC_HI(c, rk, uint2, N);
     PFP_ALLOC_HI(c, W, uint32_t, N); PFP_ALLOC_HI(c, rowid, uint32_t, N);
     PFP_ALLOC_HI(c, W2, uint32_t, N); PFP_ALLOC_HI(c, rowid2, uint32_t, N);
     int rounds = 0;
@@ -720,7 +720,7 @@ int pfp_bwt_build(pfp_ctx *c, int want_sa, int want_rssa, pfp_bwt_sizes *out)
     uint32_t *F, *cnt, *EB, *d_tot, *s_sl, *s_fb; uint8_t *s_fl, *s_pc; uint2 *posinfo; uint4 *winfo; unsigned long long *d_hard;
     if (dwords > WID_MASK) return PFP_E_TOO_LARGE;
     PFP_ALLOC_HI(c, posinfo, uint2, dsize);
-    PFP_LAUNCH(c, K_EMIT_COUNT, dsize * 17, k_pack_posinfo, nblocks(dsize, BLOCK), (const uint8_t *)c->d_dict, (const uint32_t *)c->d_wordid, (const uint32_t *)c->d_grank, dsize, posinfo);
+    PFP_LAUNCH(c, K_EMIT_COUNT, dsize * 17, k_pack_posinfo, nblocks(dsize, BLOCK), (const uint8_t *)c->d_dict, (const uint32_t *)c->d_wordid, (const uint2 *)c->d_grank, dsize, posinfo);
     PFP_ALLOC_HI(c, F, uint32_t, dwords + 1);
     PFP_ALLOC_HI(c, cnt, uint32_t, dsize); PFP_ALLOC_HI(c, EB, uint32_t, dsize); PFP_ALLOC_HI(c, d_hard, unsigned long long, 2);
     PFP_HIP(c, hipMemsetAsync(d_hard, 0, 16, c->stream));
@@ -841,7 +841,7 @@ static int sacak_int_impl(const uint32_t *s, void *SA, uint64_t n, uint64_t k, b
     int rounds = -1;
     do {
         if (ensure_arena(c, n) != PFP_OK) break;
-        uint32_t *dS = (uint32_t *)c->arena.alloc_lo(n * 4), *dSA = (uint32_t *)c->arena.alloc_lo(n * 4), *dR = (uint32_t *)c->arena.alloc_lo(n * 4);
+        uint32_t *dS = (uint32_t *)c->arena.alloc_lo(n * 4), *dSA = (uint32_t *)c->arena.alloc_lo(n * 4); uint2 *dR = (uint2 *)c->arena.alloc_lo(n * 8);
         if (!dS || !dSA || !dR) break;
         if (hipMemcpy(dS, s, n * 4, hipMemcpyHostToDevice) != hipSuccess) break;
         int r = 0;

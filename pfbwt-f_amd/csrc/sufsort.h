@@ -79,15 +79,24 @@ __global__ __launch_bounds__(BLOCK) void k_ss_heads(const uint64_t *keys, const 
     head[a] = hd;
     headslot[a] = hd ? slot : 0u;
 }
-__global__ __launch_bounds__(BLOCK) void k_ss_write_rank(const uint32_t *vals, const uint32_t *newrank, uint64_t na, uint32_t *rank)
+// rj[x] = { rank: slot of the class head of suffix x, jump: end of its covered prefix } -- one 8-byte record so
+// that the doubling step costs two random gathers (x and jump[x]) instead of four
+__global__ __launch_bounds__(BLOCK) void k_ss_write_rank(const uint32_t *vals, const uint32_t *newrank, uint64_t na, uint2 *rj)
 {
     const uint64_t a = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (a < na) rank[vals[a]] = newrank[a];
+    if (a < na) reinterpret_cast<uint32_t *>(rj)[2 * (uint64_t)vals[a]] = newrank[a];
+}
+__global__ __launch_bounds__(BLOCK) void k_ss_init_rj(const uint32_t *vals, const uint32_t *newrank, uint64_t N, uint32_t h0, uint2 *rj)
+{
+    const uint64_t a = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (a >= N) return;
+    const uint64_t x = vals[a];
+    rj[x] = make_uint2(newrank[a], (uint32_t)(x + h0 < N ? x + h0 : N));
 }
 // keep[a] = 1 while the class of element a still has to be refined.
 // ws/wordid != nullptr selects dictionary semantics: a class whose covered prefix [x, jump[x]) already
 // contains the terminator is a group of byte-identical suffixes and is final.
-__global__ __launch_bounds__(BLOCK) void k_ss_flag_active(const uint32_t *vals, const uint32_t *head, uint64_t na, const uint32_t *jump,
+__global__ __launch_bounds__(BLOCK) void k_ss_flag_active(const uint32_t *vals, const uint32_t *head, uint64_t na, const uint2 *rj,
                                                           const uint32_t *ws, const uint32_t *wordid, uint32_t *keep)
 {
     const uint64_t a = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -97,14 +106,9 @@ __global__ __launch_bounds__(BLOCK) void k_ss_flag_active(const uint32_t *vals, 
     if (!fin && ws) {
         const uint32_t x = vals[a];
         const uint32_t term = ws[wordid[x] + 1] - 1u;     // offset of the EndOfWord of x's word
-        fin = jump[x] > term;
+        fin = reinterpret_cast<const uint32_t *>(rj)[2 * (uint64_t)x + 1] > term;
     }
     keep[a] = fin ? 0u : 1u;
-}
-__global__ __launch_bounds__(BLOCK) void k_ss_init_jump(uint32_t *jump, uint64_t N, uint32_t h0)
-{
-    const uint64_t x = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (x < N) jump[x] = (uint32_t)(x + h0 < N ? x + h0 : N);
 }
 // Doubling with pointer jumping: rank[x] orders suffix x by its covered prefix [x, jump[x]); the next
 // key is (rank[x], rank[jump[x]]) and the covered prefix grows to [x, jump[jump[x]]).
@@ -114,12 +118,13 @@ __global__ __launch_bounds__(BLOCK) void k_ss_init_jump(uint32_t *jump, uint64_t
 // whole run is consumed at once: c^d a... is ordered among the suffixes starting with c by
 // t = d if a < c, 2^32-1-d if a > c  (a = first character after the run), and jump = x + d.
 constexpr uint32_t RUN_MIN = DK_CHARS;
-__global__ __launch_bounds__(BLOCK) void k_ss_make_keys(const uint32_t *slots, const uint32_t *SA, const uint32_t *rank, const uint32_t *jump, uint64_t na, uint64_t N,
+__global__ __launch_bounds__(BLOCK) void k_ss_make_keys(const uint32_t *slots, const uint32_t *SA, const uint2 *rj, uint64_t na, uint64_t N,
                                                         const uint8_t *D, const uint32_t *M, uint64_t *keys, uint32_t *vals, uint32_t *nj)
 {
     const uint64_t a = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (a >= na) return;
     const uint32_t x = SA[slots[a]];
+    const uint2 P = rj[x];
     uint32_t low, nx;
     bool run = false;
     if (M) {
@@ -134,18 +139,18 @@ __global__ __launch_bounds__(BLOCK) void k_ss_make_keys(const uint32_t *slots, c
         }
     }
     if (!run) {
-        const uint32_t y = jump[x];
-        low = y < N ? rank[y] : 0u;
-        nx = y < N ? jump[y] : (uint32_t)N;
+        const uint32_t y = P.y;
+        const uint2 Q = y < N ? rj[y] : make_uint2(0u, (uint32_t)N);
+        low = Q.x; nx = Q.y;
     }
-    keys[a] = ((uint64_t)rank[x] << 32) | low;
+    keys[a] = ((uint64_t)P.x << 32) | low;
     vals[a] = x;
     nj[a] = nx;
 }
-__global__ __launch_bounds__(BLOCK) void k_ss_apply_jump(const uint32_t *vals, const uint32_t *nj, uint64_t na, uint32_t *jump)
+__global__ __launch_bounds__(BLOCK) void k_ss_apply_jump(const uint32_t *vals, const uint32_t *nj, uint64_t na, uint2 *rj)
 {
     const uint64_t a = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (a < na) jump[vals[a]] = nj[a];
+    if (a < na) reinterpret_cast<uint32_t *>(rj)[2 * (uint64_t)vals[a] + 1] = nj[a];
 }
 // i' = N-1-x: g[i'] = i' where x is the last position of a run of equal bytes, else 0.  The inclusive
 // max-scan M of g gives, for every x, the nearest run end at or after x: runlen(x) = i' - M[i'] + 1.
@@ -163,26 +168,24 @@ __global__ __launch_bounds__(BLOCK) void k_ss_runend_marks(const uint8_t *D, uin
 // keys/vals and their twins k1/v1 (N entries each) are scratch owned by the caller.
 inline int suffix_sort_doubling(pfp_ctx *c, uint64_t N, uint64_t *k0, uint32_t *v0, uint64_t *k1, uint32_t *v1,
                                 const BitRange *init_ranges, int n_init_ranges, uint32_t h0,
-                                const uint32_t *ws, const uint32_t *wordid, const uint8_t *D, uint32_t *SA, uint32_t *rank, int *rounds_out)
+                                const uint32_t *ws, const uint32_t *wordid, const uint8_t *D, uint32_t *SA, uint2 *rj, int *rounds_out)
 {
     const size_t mk = c->arena.mark_hi();
-    uint32_t *head, *aux, *slots, *slots2, *d_cnt, *jump, *nj, *M = nullptr;
+    uint32_t *head, *aux, *slots, *slots2, *d_cnt, *nj, *M = nullptr;
     PFP_ALLOC_HI(c, head, uint32_t, N);
     PFP_ALLOC_HI(c, aux, uint32_t, N);
     PFP_ALLOC_HI(c, slots, uint32_t, N);
     PFP_ALLOC_HI(c, slots2, uint32_t, N);
-    PFP_ALLOC_HI(c, jump, uint32_t, N);
     PFP_ALLOC_HI(c, d_cnt, uint32_t, 1);
     uint64_t *sk; uint32_t *sv;
     PFP_TRY(radix_sort_pairs<uint64_t>(c, k0, v0, k1, v1, N, init_ranges, n_init_ranges, &sk, &sv));
     const unsigned gN = nblocks(N, BLOCK);
     PFP_LAUNCH(c, K_SS_HEADS, N * 24, k_ss_heads, gN, (const uint64_t *)sk, (const uint32_t *)sv, (const uint32_t *)nullptr, N, SA, head, aux);
     PFP_TRY((device_scan<uint32_t, 1>(c, aux, aux, N, nullptr)));
-    PFP_LAUNCH(c, K_SS_WRITE_RANK, N * 12, k_ss_write_rank, gN, (const uint32_t *)sv, (const uint32_t *)aux, N, rank);
-    PFP_LAUNCH(c, K_SS_WRITE_RANK, N * 4, k_ss_init_jump, gN, jump, N, h0);
+    PFP_LAUNCH(c, K_SS_WRITE_RANK, N * 16, k_ss_init_rj, gN, (const uint32_t *)sv, (const uint32_t *)aux, N, h0, rj);
     // first active list
     uint32_t *keep = aux; // aux is free again after write_rank
-    PFP_LAUNCH(c, K_SS_FLAG_ACTIVE, N * 16, k_ss_flag_active, gN, (const uint32_t *)sv, (const uint32_t *)head, N, (const uint32_t *)jump, ws, wordid, keep);
+    PFP_LAUNCH(c, K_SS_FLAG_ACTIVE, N * 16, k_ss_flag_active, gN, (const uint32_t *)sv, (const uint32_t *)head, N, (const uint2 *)rj, ws, wordid, keep);
     PFP_TRY(device_compact(c, nullptr, keep, N, slots, slots2, d_cnt));
     uint32_t na = 0; PFP_TRY(d2h_u32(c, d_cnt, &na));
     int rounds = 1;
@@ -202,16 +205,16 @@ inline int suffix_sort_doubling(pfp_ctx *c, uint64_t N, uint64_t *k0, uint32_t *
         const unsigned ga = nblocks(na, BLOCK);
         const bool run_round = (M != nullptr && rounds == 1);
         // build keys for the active list into k0/v0 (previous contents are dead: SA/rank/jump hold the state)
-        PFP_LAUNCH(c, K_SS_MAKE_KEYS, (uint64_t)na * 36, k_ss_make_keys, ga, (const uint32_t *)slots, (const uint32_t *)SA, (const uint32_t *)rank, (const uint32_t *)jump, (uint64_t)na, N,
+        PFP_LAUNCH(c, K_SS_MAKE_KEYS, (uint64_t)na * 36, k_ss_make_keys, ga, (const uint32_t *)slots, (const uint32_t *)SA, (const uint2 *)rj, (uint64_t)na, N,
                    run_round ? D : (const uint8_t *)nullptr, run_round ? (const uint32_t *)M : (const uint32_t *)nullptr, k0, v0, nj);
-        PFP_LAUNCH(c, K_SS_MAKE_KEYS, (uint64_t)na * 12, k_ss_apply_jump, ga, (const uint32_t *)v0, (const uint32_t *)nj, (uint64_t)na, jump);
+        PFP_LAUNCH(c, K_SS_MAKE_KEYS, (uint64_t)na * 12, k_ss_apply_jump, ga, (const uint32_t *)v0, (const uint32_t *)nj, (uint64_t)na, rj);
         BitRange rr[2] = {{0, run_round ? 32 : rbits}, {32, 32 + rbits}};
         PFP_TRY(radix_sort_pairs<uint64_t>(c, k0, v0, k1, v1, na, rr, 2, &sk, &sv));
         PFP_LAUNCH(c, K_SS_HEADS, (uint64_t)na * 28, k_ss_heads, ga, (const uint64_t *)sk, (const uint32_t *)sv, (const uint32_t *)slots, (uint64_t)na, SA, head, aux);
         PFP_TRY((device_scan<uint32_t, 1>(c, aux, aux, na, nullptr)));
-        PFP_LAUNCH(c, K_SS_WRITE_RANK, (uint64_t)na * 12, k_ss_write_rank, ga, (const uint32_t *)sv, (const uint32_t *)aux, (uint64_t)na, rank);
+        PFP_LAUNCH(c, K_SS_WRITE_RANK, (uint64_t)na * 12, k_ss_write_rank, ga, (const uint32_t *)sv, (const uint32_t *)aux, (uint64_t)na, rj);
         ++rounds;
-        PFP_LAUNCH(c, K_SS_FLAG_ACTIVE, (uint64_t)na * 16, k_ss_flag_active, ga, (const uint32_t *)sv, (const uint32_t *)head, (uint64_t)na, (const uint32_t *)jump, ws, wordid, keep);
+        PFP_LAUNCH(c, K_SS_FLAG_ACTIVE, (uint64_t)na * 16, k_ss_flag_active, ga, (const uint32_t *)sv, (const uint32_t *)head, (uint64_t)na, (const uint2 *)rj, ws, wordid, keep);
         PFP_TRY(device_compact(c, slots, keep, na, slots2, head /*pos scratch*/, d_cnt));
         uint32_t *t = slots; slots = slots2; slots2 = t;
         PFP_TRY(d2h_u32(c, d_cnt, &na));
