@@ -167,7 +167,7 @@ static int sort_dict_suffixes(pfp_ctx *c)
     PFP_ALLOC_HI(c, k0, uint64_t, N); PFP_ALLOC_HI(c, k1, uint64_t, N);
     PFP_ALLOC_HI(c, v0, uint32_t, N); PFP_ALLOC_HI(c, v1, uint32_t, N);
     PFP_LAUNCH(c, K_SS_INIT_KEYS, N * 13, k_dict_init_keys, nblocks(N, DK_TILE), (const uint8_t *)c->d_dict, N, k0, v0);
-    BitRange full = {0, 64};
+    BitRange full = {0, DK_KEY_BITS};
     int rounds = 0;
     PFP_TRY(suffix_sort_doubling(c, N, k0, v0, k1, v1, &full, 1, DK_CHARS, c->d_ws, c->d_wordid, c->d_dict, c->d_gsa, c->d_grank, &rounds));
     c->arena.release_hi(mk);

@@ -23,7 +23,9 @@ constexpr int DK_CHARS = 16;          // characters per initial key
 constexpr int DK_PER_THREAD = 16;     // suffixes per thread
 constexpr int DK_TILE = BLOCK * DK_PER_THREAD;
 
-// keys[x] = first 16 characters of suffix x packed 4 bits each, zero after the terminator.
+// keys[x] = the first 16 characters of suffix x read as a 16-digit base-9 number (digits = dict_code, 0 after
+// the terminator): order-preserving like 4-bit packing, but 9^16 < 2^51, i.e. 7 radix passes instead of 8.
+constexpr int DK_KEY_BITS = 51;
 __global__ __launch_bounds__(BLOCK) void k_dict_init_keys(const uint8_t *D, uint64_t dsize, uint64_t *keys, uint32_t *vals)
 {
     __shared__ uint8_t tile[DK_TILE + DK_CHARS];
@@ -33,28 +35,19 @@ __global__ __launch_bounds__(BLOCK) void k_dict_init_keys(const uint8_t *D, uint
         tile[i] = x < dsize ? (uint8_t)dict_code(D[x]) : (uint8_t)0;
     }
     __syncthreads();
-    const uint32_t l0 = threadIdx.x * DK_PER_THREAD;
-    // raw rolling window over [l, l+16) and distance to the first terminator at or after l
-    uint64_t raw = 0;
+    // consecutive threads take consecutive positions (conflict-free LDS reads, coalesced stores)
+#pragma unroll 1
+    for (int k = 0; k < DK_PER_THREAD; ++k) {
+        const uint32_t l = (uint32_t)k * BLOCK + threadIdx.x;
+        uint64_t key = 0; bool stop = false;
 #pragma unroll
-    for (int k = 0; k < DK_CHARS - 1; ++k) raw = (raw << 4) | tile[l0 + DK_PER_THREAD + k];
-    // raw now holds the 15 codes of positions l0+16 .. l0+30 (used as the window slides backwards)
-    int dt = DK_CHARS; // distance from position (l0+16) to its first terminator, capped
-#pragma unroll
-    for (int k = DK_CHARS - 1; k >= 0; --k) if (tile[l0 + DK_PER_THREAD + k] <= 1) dt = k;
-    // slide backwards: position l = l0+15 .. l0
-    uint64_t win = raw; // 15 codes: positions l+1 .. l+15 (for l = l0+15), in the low 60 bits
-#pragma unroll
-    for (int k = DK_PER_THREAD - 1; k >= 0; --k) {
-        const uint32_t l = l0 + k;
-        const uint32_t c = tile[l];
-        const uint64_t full = ((uint64_t)c << 60) | win;         // codes of l .. l+15
-        dt = (c <= 1) ? 0 : (dt + 1 > DK_CHARS ? DK_CHARS : dt + 1);
-        // keep characters 0..dt (terminator included), zero the rest
-        const uint64_t key = dt >= DK_CHARS - 1 ? full : (full & ~((1ULL << (4 * (DK_CHARS - 1 - dt))) - 1ULL));
+        for (int j = 0; j < DK_CHARS; ++j) {
+            const uint32_t cc = tile[l + j];
+            key = key * 9u + (stop ? 0u : cc);
+            stop = stop || cc <= 1;                      // the terminator itself is part of the key, nothing after it
+        }
         const uint64_t x = t0 + l;
         if (x < dsize) { keys[x] = key; vals[x] = (uint32_t)x; }
-        win = full >> 4;
     }
 }
 
@@ -119,7 +112,7 @@ __global__ __launch_bounds__(BLOCK) void k_ss_flag_active(const uint32_t *vals, 
 // t = d if a < c, 2^32-1-d if a > c  (a = first character after the run), and jump = x + d.
 constexpr uint32_t RUN_MIN = DK_CHARS;
 __global__ __launch_bounds__(BLOCK) void k_ss_make_keys(const uint32_t *slots, const uint32_t *SA, const uint2 *rj, uint64_t na, uint64_t N,
-                                                        const uint8_t *D, const uint32_t *M, uint64_t *keys, uint32_t *vals, uint32_t *nj)
+                                                        const uint8_t *D, const uint32_t *M, int lowbits, uint64_t *keys, uint32_t *vals, uint32_t *nj)
 {
     const uint64_t a = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (a >= na) return;
@@ -143,7 +136,7 @@ __global__ __launch_bounds__(BLOCK) void k_ss_make_keys(const uint32_t *slots, c
         const uint2 Q = y < N ? rj[y] : make_uint2(0u, (uint32_t)N);
         low = Q.x; nx = Q.y;
     }
-    keys[a] = ((uint64_t)P.x << 32) | low;
+    keys[a] = ((uint64_t)P.x << lowbits) | low;      // (rank, refinement) packed tightly: 2*bits(N) key bits
     vals[a] = x;
     nj[a] = nx;
 }
@@ -206,10 +199,10 @@ inline int suffix_sort_doubling(pfp_ctx *c, uint64_t N, uint64_t *k0, uint32_t *
         const bool run_round = (M != nullptr && rounds == 1);
         // build keys for the active list into k0/v0 (previous contents are dead: SA/rank/jump hold the state)
         PFP_LAUNCH(c, K_SS_MAKE_KEYS, (uint64_t)na * 36, k_ss_make_keys, ga, (const uint32_t *)slots, (const uint32_t *)SA, (const uint2 *)rj, (uint64_t)na, N,
-                   run_round ? D : (const uint8_t *)nullptr, run_round ? (const uint32_t *)M : (const uint32_t *)nullptr, k0, v0, nj);
+                   run_round ? D : (const uint8_t *)nullptr, run_round ? (const uint32_t *)M : (const uint32_t *)nullptr, run_round ? 32 : rbits, k0, v0, nj);
         PFP_LAUNCH(c, K_SS_MAKE_KEYS, (uint64_t)na * 12, k_ss_apply_jump, ga, (const uint32_t *)v0, (const uint32_t *)nj, (uint64_t)na, rj);
-        BitRange rr[2] = {{0, run_round ? 32 : rbits}, {32, 32 + rbits}};
-        PFP_TRY(radix_sort_pairs<uint64_t>(c, k0, v0, k1, v1, na, rr, 2, &sk, &sv));
+        BitRange rr = {0, (run_round ? 32 : rbits) + rbits};
+        PFP_TRY(radix_sort_pairs<uint64_t>(c, k0, v0, k1, v1, na, &rr, 1, &sk, &sv));
         PFP_LAUNCH(c, K_SS_HEADS, (uint64_t)na * 28, k_ss_heads, ga, (const uint64_t *)sk, (const uint32_t *)sv, (const uint32_t *)slots, (uint64_t)na, SA, head, aux);
         PFP_TRY((device_scan<uint32_t, 1>(c, aux, aux, na, nullptr)));
         PFP_LAUNCH(c, K_SS_WRITE_RANK, (uint64_t)na * 12, k_ss_write_rank, ga, (const uint32_t *)sv, (const uint32_t *)aux, (uint64_t)na, rj);
