@@ -158,7 +158,10 @@ template <typename T, int OP> inline int device_scan(pfp_ctx *c, const T *in, T 
 // ------------------------------------------------------------------------------------------------
 // LSD radix sort, 8-bit digits, stable.  Tile = 4 waves x 16 rounds x 64 lanes = 4096 pairs; every
 // wave owns a contiguous 1024-pair slice so that order inside the tile is wave-major.
-constexpr int RS_ITEMS = 15;   // 3840-pair tiles: 52 KiB of LDS in the scatter kernel -> three workgroups per CU
+#ifndef PFP_RS_ITEMS
+#define PFP_RS_ITEMS 15
+#endif
+constexpr int RS_ITEMS = PFP_RS_ITEMS;   // 15: 3840-pair tiles, 52 KiB of LDS in the scatter kernel -> three workgroups per CU
 constexpr int RS_TILE = BLOCK * RS_ITEMS;
 constexpr int RS_RADIX = 256;
 
@@ -173,7 +176,7 @@ struct BitRange { int lo, hi; };
 //                  put in digit order in LDS first so that the global stores are contiguous runs.
 // A single-pass chained-scan ("onesweep") variant was measured slower on MI355X at this tile size: the
 // look-back over 256 digit counters per tile costs as much as the data movement.
-constexpr int SEG_MAX_GRID = 1024;
+constexpr int SEG_MAX_GRID = 4096;
 
 template <typename K> __global__ __launch_bounds__(BLOCK) void k_seg_hist(const K *keys, uint64_t n, int shift, uint32_t tiles_per_seg, uint32_t *seg /*[G][256]*/)
 {
@@ -235,18 +238,25 @@ __global__ __launch_bounds__(BLOCK) void k_seg_small(uint32_t *seg, uint32_t G, 
     total[d] = block_excl_sum((unsigned long long)run, lds, &tot);
 }
 
-template <typename K> __global__ __launch_bounds__(BLOCK) void k_seg_scatter(const K *keys, const uint32_t *vals, K *okeys, uint32_t *ovals, uint64_t n, int shift,
+template <typename K, bool STAGE> __global__ __launch_bounds__(BLOCK) void k_seg_scatter(const K *keys, const uint32_t *vals, K *okeys, uint32_t *ovals, uint64_t n, int shift,
                                                                            uint32_t tiles_per_seg, const uint32_t *seg /*[G][256] column prefixes*/, const unsigned long long *dbase)
 {
     constexpr int ITEMS = RS_ITEMS, TILE = RS_TILE;
     __shared__ uint32_t wh[BLOCK / WAVE][RS_RADIX];      // per-wave digit counts, then per-wave local cursors
     __shared__ unsigned long long gdelta[RS_RADIX];      // global index of tile-sorted element j with digit d = gdelta[d] + j
-    __shared__ K skeys[TILE];
-    __shared__ uint32_t svals[TILE];
+    __shared__ K skeys[STAGE ? TILE : 1];
+    __shared__ uint32_t svals[STAGE ? TILE : 1];
     __shared__ uint32_t red[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;
     unsigned long long cursor = dbase[threadIdx.x] + seg[(size_t)blockIdx.x * RS_RADIX + threadIdx.x];   // thread d: next output index of digit d
+    // software pipeline: the pairs of tile t+1 are requested while tile t is ranked, staged and stored
+    K kn[ITEMS]; uint32_t vn[ITEMS];
+    {
+        const uint64_t b0 = (uint64_t)blockIdx.x * tiles_per_seg * TILE + (uint64_t)wave * (ITEMS * WAVE) + lane;
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) { const uint64_t i = b0 + (uint64_t)it * WAVE; if (i < n) { kn[it] = keys[i]; vn[it] = vals[i]; } else { kn[it] = 0; vn[it] = 0; } }
+    }
     for (uint32_t tl = 0; tl < tiles_per_seg; ++tl) {
         const uint64_t tbase = ((uint64_t)blockIdx.x * tiles_per_seg + tl) * TILE;
         if (tbase >= n) break;                            // uniform
@@ -259,8 +269,13 @@ template <typename K> __global__ __launch_bounds__(BLOCK) void k_seg_scatter(con
 #pragma unroll
         for (int it = 0; it < ITEMS; ++it) {
             const uint64_t i = base + (uint64_t)it * WAVE;
-            if (i < n) { k[it] = keys[i]; v[it] = vals[i]; atomicAdd(&wh[wave][(unsigned)(k[it] >> shift) & (RS_RADIX - 1)], 1u); }
-            else { k[it] = 0; v[it] = 0; }
+            k[it] = kn[it]; v[it] = vn[it];
+            if (i < n) atomicAdd(&wh[wave][(unsigned)(k[it] >> shift) & (RS_RADIX - 1)], 1u);
+        }
+        if (tl + 1 < tiles_per_seg) {
+            const uint64_t nb = base + TILE;
+#pragma unroll
+            for (int it = 0; it < ITEMS; ++it) { const uint64_t i = nb + (uint64_t)it * WAVE; if (i < n) { kn[it] = keys[i]; vn[it] = vals[i]; } else { kn[it] = 0; vn[it] = 0; } }
         }
         __syncthreads();
         {   // thread d owns digit value d
@@ -292,15 +307,21 @@ template <typename K> __global__ __launch_bounds__(BLOCK) void k_seg_scatter(con
             uint32_t old = 0;
             if (valid && lane == leader) { old = wh[wave][d]; wh[wave][d] = old + (uint32_t)__popcll(peers); }
             old = __shfl(old, leader);
-            if (valid) { const uint32_t li = old + (uint32_t)__popcll(peers & lt); skeys[li] = k[it]; svals[li] = v[it]; }
+            if (valid) {
+                const uint32_t li = old + (uint32_t)__popcll(peers & lt);
+                if (STAGE) { skeys[li] = k[it]; svals[li] = v[it]; }
+                else { const unsigned long long pos = gdelta[d] + li; okeys[pos] = k[it]; ovals[pos] = v[it]; }
+            }
         }
         __syncthreads();
-        for (uint32_t j = threadIdx.x; j < tile_n; j += BLOCK) {
-            const K kk = skeys[j];
-            const unsigned long long pos = gdelta[(unsigned)(kk >> shift) & (RS_RADIX - 1)] + j;
-            okeys[pos] = kk; ovals[pos] = svals[j];
+        if (STAGE) {
+            for (uint32_t j = threadIdx.x; j < tile_n; j += BLOCK) {
+                const K kk = skeys[j];
+                const unsigned long long pos = gdelta[(unsigned)(kk >> shift) & (RS_RADIX - 1)] + j;
+                okeys[pos] = kk; ovals[pos] = svals[j];
+            }
+            __syncthreads();                              // LDS is reused by the next tile
         }
-        __syncthreads();                                  // LDS is reused by the next tile
     }
 }
 
@@ -386,6 +407,8 @@ template <typename K> inline int radix_sort_pairs(pfp_ctx *c, K *k0, uint32_t *v
     const uint32_t ntiles = nblocks(n, RS_TILE);
     static int seg_grid = 0;   // workgroups per pass (segments); default 3 per CU of a 256-CU device
     if (!seg_grid) { const char *e = getenv("PFP_SEG_GRID"); seg_grid = (e && atoi(e) > 0 && atoi(e) <= SEG_MAX_GRID) ? atoi(e) : 768; }
+    static int seg_stage = -1;
+    if (seg_stage < 0) { const char *e = getenv("PFP_SEG_STAGE"); seg_stage = e ? atoi(e) : 1; }
     const uint32_t tps = (ntiles + (uint32_t)seg_grid - 1) / (uint32_t)seg_grid;   // tiles per segment
     const uint32_t G = (ntiles + tps - 1) / tps;
     uint32_t *seg; unsigned long long *total;
@@ -400,7 +423,9 @@ template <typename K> inline int radix_sort_pairs(pfp_ctx *c, K *k0, uint32_t *v
                 PFP_LAUNCH(c, K_SCAN_SPINE, (uint64_t)G * RS_RADIX * 8, k_seg_colscan, RS_RADIX, seg, G, total);
                 PFP_LAUNCH(c, K_SCAN_SPINE, RS_RADIX * 16, k_seg_dbase, 1, total);
             }
-            PFP_LAUNCH(c, K_RADIX_SCATTER, n * 2 * (sizeof(K) + 4), (k_seg_scatter<K>), G, (const K *)src, (const uint32_t *)sv, dst, dv, n, shift, tps,
+            if (seg_stage) PFP_LAUNCH(c, K_RADIX_SCATTER, n * 2 * (sizeof(K) + 4), (k_seg_scatter<K, true>), G, (const K *)src, (const uint32_t *)sv, dst, dv, n, shift, tps,
+                       (const uint32_t *)seg, (const unsigned long long *)total);
+            else PFP_LAUNCH(c, K_RADIX_SCATTER, n * 2 * (sizeof(K) + 4), (k_seg_scatter<K, false>), G, (const K *)src, (const uint32_t *)sv, dst, dv, n, shift, tps,
                        (const uint32_t *)seg, (const unsigned long long *)total);
             K *tk = src; src = dst; dst = tk; uint32_t *tv = sv; sv = dv; dv = tv;
         }

@@ -7,7 +7,7 @@ import pfbwt_hip
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 55_000_000
 bits = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 abl = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0]
-ctx = pfbwt_hip.PfpContext()
+ctx = pfbwt_hip.PfpContext(lib=os.environ.get("PFP_LIB"))
 L = ctx.L
 L.pfp_debug_sort.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
 for a in abl:
