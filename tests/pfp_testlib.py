@@ -186,3 +186,34 @@ def compare(res, ref, U, names=("dict", "occ", "parse", "last", "sai", "bwlast",
             i = int(np.flatnonzero(a != b)[0])
             bad.append("%s: first diff at %d: got %d want %d (%d diffs)" % (k, i, a[i], b[i], int((a != b).sum())))
     return bad
+
+
+def ragged_cases(seed=11):
+    """Edge inputs (empty records, records shorter than w, hundreds of tiny records, one short record, only A)."""
+    rng = np.random.default_rng(seed)
+    rnd = lambda n: bytes(rng.choice(list(b"ACGT"), n).astype(np.uint8))
+    return {
+        "empty_records": [b"", rnd(300), b"", b"", rnd(50), b""],
+        "short_records": [rnd(1), rnd(3), rnd(9), rnd(10), rnd(11), rnd(500)],
+        "many_tiny": [rnd(int(rng.integers(0, 25))) for _ in range(400)],
+        "single_short": [rnd(37)],
+        "all_A": [b"A" * 2000, b"A" * 100],
+        "only_pad_first": [b"", rnd(200)],
+    }
+
+
+def check_ragged(factory):
+    """Every ragged case, two (w, p) settings: engine == oracle, or both report 'only one dict word'."""
+    import pfbwt_hip
+    for name, seqs in ragged_cases().items():
+        for w, p in ((10, 100), (4, 5)):
+            ref = oracle_run(seqs, w=w, p=p, U=4)
+            if ref.get("err") == "one_word":
+                try:
+                    engine_run(factory, seqs, w, p, 4)
+                    raise AssertionError("%s: engine accepted a one-word parse" % name)
+                except pfbwt_hip.PfpError as e:
+                    assert e.status == pfbwt_hip.E_ONE_WORD, (name, e)
+                continue
+            bad = compare(engine_run(factory, seqs, w, p, 4), ref, 4)
+            assert bad == [], (name, w, p, bad)

@@ -59,3 +59,8 @@ def test_emu_error_paths(emu_factory):
         ctx.parse_bwt()
     assert e.value.status == pfbwt_hip.E_ONE_WORD
     ctx.close()
+
+
+def test_emu_ragged_inputs(emu_factory):
+    from pfp_testlib import check_ragged
+    check_ragged(emu_factory)

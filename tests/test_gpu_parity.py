@@ -142,3 +142,9 @@ def test_full_size_properties(gpu_ctx_factory):
     assert res["r"] == starts.size
     assert np.array_equal(res["ssa"].reshape(-1, 2)[:, 0].astype(np.int64), starts)
     assert np.array_equal(res["ssa"].reshape(-1, 2)[:, 1].astype(np.int64), sa[starts])
+
+
+def test_engine_ragged_inputs(gpu_ctx_factory):
+    """empty records, records shorter than w, hundreds of tiny records, one-word parses"""
+    from pfp_testlib import check_ragged
+    check_ragged(gpu_ctx_factory)
