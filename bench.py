@@ -10,8 +10,8 @@ BWT + full SA emission, outputs left in HBM.  Workload at N=1: S-chr22 (SURVEY.m
 BASELINE.json): one synthetic chromosome, L = 50 818 468, seed 22, two N-runs (10 Mbp + 1 Mbp),
 -w 10 -p 100 -s, 32-bit mode.  N>1 (weak scaling): rank r holds haplotype r of the same synthetic chromosome
 (S-chr22 shape per GPU); every rank parses its shard, ONE RCCL all-gather moves the per-rank dictionaries and
-parses, rank 0 merges them (pfp_merge_shards) and runs the single-GPU stages (parse BWT, dictionary suffix sort,
-emission) for the whole collection -- the design of SURVEY.md 8(e); value = total bases / step time.
+parses to every rank, every rank merges them and sorts the merged dictionary and the parse (identical, redundant work),
+and emits its own slice of the BWT/SA rows, which stay distributed in HBM; value = total bases / step time.
 
 Rank 0 prints ONE JSON line with the contract fields plus `roofline` (dominant kernel, HIP-event timed
 inside the timed region) and `cpu_baseline` (oracle/pfbwt_oracle, single thread, same input).
@@ -140,8 +140,7 @@ def main():
             ctx.finalize(); ctx.parse_bwt()
             return ctx.bwt_build(sa=True, rssa=False)
         import pfbwt_dist
-        out = pfbwt_dist.sharded_build(ctx, feed_local, w, dev, sa=True, rssa=False)
-        return out[1] if out is not None else None
+        return pfbwt_dist.sharded_build(ctx, feed_local, w, dev, sa=True)[1]
 
     def sync():
         torch.cuda.synchronize()
@@ -171,9 +170,11 @@ def main():
     prof = [r for r in ctx.profile() if r["kernel"] == dominant]
     ctx.profile_enable(False)
     tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    rt = torch.tensor([int(b.r)], dtype=torch.int64, device="cuda")   # runs that start in this rank's slice
     if dist is not None:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    dt = float(tt.item())
+        dist.all_reduce(rt, op=dist.ReduceOp.SUM)
+    dt = float(tt.item()); r_total = int(rt.item())
 
     if rank == 0:
         out = ctx.bwt_get() if (not a.no_cpu_baseline and world == 1) else None
@@ -195,9 +196,9 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8 text / u32 indices / u64 hash", "data": "synthetic",
             "config": {"workload": a.workload, "L": L, "H": H, "seed": seed, "n_runs": list(nruns), "w": w, "p": p, "flags": "-s", "uint_t": 64 if u64 else 32,
-                       "n": n, "r": int(b.r), "input": "text resident in HBM, outputs (.bwt, .sa) left in HBM",
+                       "n": n, "r": r_total, "input": "text resident in HBM, outputs (.bwt, .sa) left in HBM",
                        "per_rank": ("haplotype r of the collection per rank; parse sharded, one RCCL all-gather of dictionaries, "
-                                    "merge + parse-BWT + dictionary suffix sort + emission on rank 0") if world > 1 else "single GPU"},
+                                    "merge + dictionary/parse suffix sorts on every rank, emission sliced over the ranks") if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": traffic,
                          "launches_per_step": pr["launches"] / a.steps, "avg_launch_us": 1e3 * pr["ms"] / pr["launches"],
                          "alg_bytes_per_launch": pr["bytes"] / pr["launches"],

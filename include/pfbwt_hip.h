@@ -114,6 +114,10 @@ int pfp_bwt_load(pfp_ctx *ctx, const uint8_t *dict, uint64_t dsize, const void *
 /* PrefixFreeBWT::generate_bwt_lcp pfbwt.hpp:96-194 (sort_dict_suffixes :206-223 = gsacak included)
  * fused with the CLI's out_fn src/pfbwt-f.cpp:298-328: BWT bytes, SA (row 0 := n), run samples. */
 int pfp_bwt_build(pfp_ctx *ctx, int want_sa, int want_rssa, pfp_bwt_sizes *out);
+/* Multi-GPU emission: every rank holds the same parse state (after pfp_merge_shards + pfp_parse_bwt) and emits
+ * only output rows [nout*slice/nslices, nout*(slice+1)/nslices).  out->r counts the runs that START in the slice
+ * (the sum over slices is r); pfp_bwt_get / pfp_bwt_device_ptrs then refer to the slice (slice_rows entries). */
+int pfp_bwt_build_slice(pfp_ctx *ctx, int want_sa, int slice, int nslices, pfp_bwt_sizes *out, uint64_t *slice_begin, uint64_t *slice_rows);
 /* copy results to host (NULL skips): bwt nout bytes; sa nout U-wide; ssa/esa 2*r U-wide each */
 int pfp_bwt_get(pfp_ctx *ctx, uint8_t *bwt, void *sa, void *ssa, void *esa);
 /* device pointers of the same results (valid until the next pfp_* call that rebuilds them) */

@@ -91,6 +91,8 @@ struct EmitArgs {
     const uint8_t *s_fl;    // per slot: SF_* flags
     const uint8_t *s_pc;    // per slot: BWT byte of a proper-suffix slot (preceding dictionary byte, 0 after the first Dollar)
     uint64_t nout, n;
+    uint64_t e0, e1;        // rows (in enumeration order) this launch walks
+    uint64_t w0, w1;        // output positions this launch may write: [w0, w1) -> buffer index pos - w0 (multi-GPU slices)
 };
 constexpr uint8_t SF_MULTI = 1, SF_FULL = 2;
 // posinfo[x] = { word id of dictionary offset x | 4-bit code of D[x-1] << 28 , class-head slot of x }: one 8-byte
@@ -200,8 +202,8 @@ template <typename SAT> __global__ __launch_bounds__(BLOCK) void k_emit(EmitArgs
 {
     __shared__ uint32_t eb[EMIT_LDS_SLOTS];
     __shared__ uint32_t range[2];
-    const uint64_t o0 = (uint64_t)blockIdx.x * EMIT_TILE;
-    const uint64_t o1 = (o0 + EMIT_TILE < a.nout) ? o0 + EMIT_TILE : a.nout;   // exclusive
+    const uint64_t o0 = a.e0 + (uint64_t)blockIdx.x * EMIT_TILE;
+    const uint64_t o1 = (o0 + EMIT_TILE < a.e1) ? o0 + EMIT_TILE : a.e1;   // exclusive
     if (threadIdx.x < 2) {
         const uint64_t o = threadIdx.x == 0 ? o0 : o1 - 1;
         range[threadIdx.x] = upper_bound_u32(a.EB, (uint32_t)a.dsize, (uint32_t)o) - 1u;   // last slot with EB <= o
@@ -228,11 +230,12 @@ template <typename SAT> __global__ __launch_bounds__(BLOCK) void k_emit(EmitArgs
         bool full_emits_eow = false;
         if (fl & SF_MULTI) pos = multi_group_pos(a, i, r, q, self_full, &full_emits_eow);
         const uint8_t c = self_full ? (full_emits_eow ? (uint8_t)EndOfWord : a.bwlast[q]) : a.s_pc[i];   // pfbwt.hpp:116-128 / :132
-        bwt[pos] = c;
+        if (pos < a.w0 || pos >= a.w1) continue;                    // row of a boundary group that lands in another slice
+        bwt[pos - a.w0] = c;
         if (sa) {
             SAT v = (SAT)((SAT)(a.bwsai[q]) - (SAT)sl);             // UPDATE_SA, pfbwt.hpp:87-89
             if (pos == 0) v = (SAT)a.n;                             // src/pfbwt-f.cpp:301
-            sa[pos] = v;
+            sa[pos - a.w0] = v;
         }
     }
 }
@@ -243,14 +246,30 @@ __global__ __launch_bounds__(BLOCK) void k_run_flags(const uint8_t *bwt, uint64_
     const uint64_t o = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (o < nout) flag[o] = bwt[o] != (o ? bwt[o - 1] : (uint8_t)0) ? 1u : 0u;
 }
-// run count only (no samples wanted): workgroup reduction + one atomic per workgroup
-__global__ __launch_bounds__(BLOCK) void k_run_count(const uint8_t *bwt, uint64_t nout, unsigned long long *runs)
+// Multi-GPU slices: a slice owns output rows [w0', w1); rows of a group of equal suffixes that straddles a slice
+// boundary are enumerated by both neighbours, each keeps what lands in its window.  out[0] = first enumeration row
+// (start of the group containing row lo), out[1] = end of the group containing row hi-1.
+__global__ __launch_bounds__(BLOCK) void k_slice_bounds(EmitArgs a, uint64_t lo, uint64_t hi, unsigned long long *out)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    const uint32_t il = upper_bound_u32(a.EB, (uint32_t)a.dsize, (uint32_t)lo) - 1u;
+    out[0] = a.EB[a.posinfo[a.SA[il]].y];
+    if (hi >= a.nout) { out[1] = a.nout; return; }
+    uint32_t s = upper_bound_u32(a.EB, (uint32_t)a.dsize, (uint32_t)(hi - 1)) - 1u;
+    const uint32_t g = a.posinfo[a.SA[s]].y;
+    while (s < a.dsize && a.posinfo[a.SA[s]].y == g) ++s;
+    while (s < a.dsize && a.EB[s] < hi) ++s;               // slots that produce no rows keep EB unchanged
+    out[1] = s < a.dsize ? a.EB[s] : a.nout;
+}
+// run count only (no samples wanted): workgroup reduction + one atomic per workgroup.  `bwt` points at the first
+// row to count; has_prev says whether bwt[-1] holds the row in front of it (slices > 0).
+__global__ __launch_bounds__(BLOCK) void k_run_count(const uint8_t *bwt, uint64_t nout, int has_prev, unsigned long long *runs)
 {
     __shared__ uint32_t red[4];
     const uint64_t o0 = ((uint64_t)blockIdx.x * BLOCK + threadIdx.x) * 16;
     uint32_t cntr = 0;
     if (o0 < nout) {
-        uint8_t prev = o0 ? bwt[o0 - 1] : (uint8_t)0;
+        uint8_t prev = (o0 || has_prev) ? *(bwt + o0 - 1) : (uint8_t)0;
         for (int k = 0; k < 16 && o0 + k < nout; ++k) { const uint8_t cc = bwt[o0 + k]; cntr += cc != prev; prev = cc; }
     }
     uint32_t tot;

@@ -671,21 +671,36 @@ int pfp_bwt_load(pfp_ctx *c, const uint8_t *dict, uint64_t dsize, const void *oc
 }
 
 extern "C++" {
-template <typename SAT> static int emit_and_sample(pfp_ctx *c, const EmitArgs &ea, bool want_sa, bool want_rssa)
+template <typename SAT> static int emit_and_sample(pfp_ctx *c, EmitArgs ea, bool want_sa, bool want_rssa, int slice, int nslices)
 {
-    const uint64_t nout = ea.nout;
+    const uint64_t total = ea.nout;
     const bool any_sa = want_sa || want_rssa;
-    PFP_ALLOC_LO(c, c->d_bwt, uint8_t, nout);
-    SAT *sa = nullptr;
-    if (any_sa) { PFP_ALLOC_LO(c, sa, SAT, nout); }
+    // output rows of this slice, plus the row in front of it (run detection needs its BWT byte)
+    const uint64_t s0 = total * (uint64_t)slice / (uint64_t)nslices, s1 = total * (uint64_t)(slice + 1) / (uint64_t)nslices;
+    const uint64_t lead = s0 ? 1 : 0;
+    const uint64_t nout = s1 - s0;
+    c->slice_begin = s0; c->slice_rows = nout;
+    uint8_t *bwtbuf; PFP_ALLOC_LO(c, bwtbuf, uint8_t, nout + lead + 16);
+    c->d_bwt = bwtbuf + lead;
+    SAT *sabuf = nullptr, *sa = nullptr;
+    if (any_sa) { PFP_ALLOC_LO(c, sabuf, SAT, nout + lead); sa = sabuf + lead; }
     c->d_sa = sa;
-    PFP_LAUNCH(c, K_EMIT, nout * (1 + (any_sa ? sizeof(SAT) : 0)) + c->nrows * 9 + c->dsize * 9, (k_emit<SAT>), nblocks(nout, EMIT_TILE), ea, c->d_bwt, sa);
+    ea.w0 = s0 - lead; ea.w1 = s1; ea.e0 = 0; ea.e1 = total;
+    if (nslices > 1) {
+        unsigned long long *d_b; PFP_ALLOC_HI(c, d_b, unsigned long long, 2);
+        PFP_LAUNCH(c, K_MISC, 64, k_slice_bounds, 1, ea, ea.w0, ea.w1, d_b);
+        unsigned long long hb[2];
+        PFP_HIP(c, hipMemcpyAsync(hb, d_b, 16, hipMemcpyDeviceToHost, c->stream));
+        PFP_HIP(c, hipStreamSynchronize(c->stream));
+        ea.e0 = hb[0]; ea.e1 = hb[1];
+    }
+    PFP_LAUNCH(c, K_EMIT, nout * (1 + (any_sa ? sizeof(SAT) : 0)) + c->nrows * 9 + c->dsize * 9, (k_emit<SAT>), nblocks(ea.e1 - ea.e0, EMIT_TILE), ea, bwtbuf, sabuf);
     // runs (src/pfbwt-f.cpp:304-305); the samples need the index of every run start, the count alone does not
     c->d_ssa = c->d_esa = nullptr;
     if (!want_rssa) {
         unsigned long long *d_runs; PFP_ALLOC_HI(c, d_runs, unsigned long long, 1);
         PFP_HIP(c, hipMemsetAsync(d_runs, 0, 8, c->stream));
-        PFP_LAUNCH(c, K_RUNS, nout, k_run_count, nblocks(nout, 16 * BLOCK), (const uint8_t *)c->d_bwt, nout, d_runs);
+        PFP_LAUNCH(c, K_RUNS, nout, k_run_count, nblocks(nout, 16 * BLOCK), (const uint8_t *)c->d_bwt, nout, (int)lead, d_runs);
         unsigned long long r = 0;
         PFP_HIP(c, hipMemcpyAsync(&r, d_runs, 8, hipMemcpyDeviceToHost, c->stream));
         PFP_HIP(c, hipStreamSynchronize(c->stream));
@@ -706,9 +721,9 @@ template <typename SAT> static int emit_and_sample(pfp_ctx *c, const EmitArgs &e
 }
 } // extern "C++"
 
-int pfp_bwt_build(pfp_ctx *c, int want_sa, int want_rssa, pfp_bwt_sizes *out)
+static int bwt_build_impl(pfp_ctx *c, int want_sa, int want_rssa, int slice, int nslices, pfp_bwt_sizes *out)
 {
-    if (!c) return PFP_E_ARG;
+    if (!c || nslices < 1 || slice < 0 || slice >= nslices || (want_rssa && nslices > 1)) return PFP_E_ARG;
     if (c->stage < 2) return PFP_E_STATE;
     if ((want_sa || want_rssa) && !c->d_bwsai) return PFP_E_STATE;
     PFP_HIP(c, hipSetDevice(c->device));
@@ -751,8 +766,8 @@ int pfp_bwt_build(pfp_ctx *c, int want_sa, int want_rssa, pfp_bwt_sizes *out)
     c->nout = nout; c->hard = hardrows; c->easy = nout - hardrows;
     c->have_sa = want_sa != 0; c->have_rssa = want_rssa != 0;
     int rc;
-    if (c->flags & PFP_FLAG_U64) rc = emit_and_sample<uint64_t>(c, ea, want_sa != 0, want_rssa != 0);
-    else rc = emit_and_sample<uint32_t>(c, ea, want_sa != 0, want_rssa != 0);
+    if (c->flags & PFP_FLAG_U64) rc = emit_and_sample<uint64_t>(c, ea, want_sa != 0, want_rssa != 0, slice, nslices);
+    else rc = emit_and_sample<uint32_t>(c, ea, want_sa != 0, want_rssa != 0, slice, nslices);
     if (rc != PFP_OK) return rc;
     PFP_HIP(c, hipStreamSynchronize(c->stream));
     c->arena.release_hi(mk);
@@ -762,14 +777,24 @@ int pfp_bwt_build(pfp_ctx *c, int want_sa, int want_rssa, pfp_bwt_sizes *out)
     return PFP_OK;
 }
 
+int pfp_bwt_build(pfp_ctx *c, int want_sa, int want_rssa, pfp_bwt_sizes *out) { return bwt_build_impl(c, want_sa, want_rssa, 0, 1, out); }
+int pfp_bwt_build_slice(pfp_ctx *c, int want_sa, int slice, int nslices, pfp_bwt_sizes *out, uint64_t *slice_begin, uint64_t *slice_rows)
+{
+    int rc = bwt_build_impl(c, want_sa, 0, slice, nslices, out);
+    if (rc != PFP_OK) return rc;
+    if (slice_begin) *slice_begin = c->slice_begin;
+    if (slice_rows) *slice_rows = c->slice_rows;
+    return PFP_OK;
+}
+
 int pfp_bwt_get(pfp_ctx *c, uint8_t *bwt, void *sa, void *ssa, void *esa)
 {
     if (!c) return PFP_E_ARG;
     if (c->stage < 3) return PFP_E_STATE;
     PFP_HIP(c, hipSetDevice(c->device));
     const size_t U = (c->flags & PFP_FLAG_U64) ? 8 : 4;
-    if (bwt) PFP_HIP(c, hipMemcpy(bwt, c->d_bwt, c->nout, hipMemcpyDeviceToHost));
-    if (sa) { if (!c->d_sa) return PFP_E_STATE; PFP_HIP(c, hipMemcpy(sa, c->d_sa, c->nout * U, hipMemcpyDeviceToHost)); }
+    if (bwt) PFP_HIP(c, hipMemcpy(bwt, c->d_bwt, c->slice_rows, hipMemcpyDeviceToHost));
+    if (sa) { if (!c->d_sa) return PFP_E_STATE; PFP_HIP(c, hipMemcpy(sa, c->d_sa, c->slice_rows * U, hipMemcpyDeviceToHost)); }
     if (ssa) { if (!c->d_ssa) return PFP_E_STATE; PFP_HIP(c, hipMemcpy(ssa, c->d_ssa, c->runs * 2 * U, hipMemcpyDeviceToHost)); }
     if (esa) { if (!c->d_esa) return PFP_E_STATE; PFP_HIP(c, hipMemcpy(esa, c->d_esa, c->runs * 2 * U, hipMemcpyDeviceToHost)); }
     return PFP_OK;

@@ -1,7 +1,8 @@
 """Sharded parse across GPUs: one process per GPU, torch.distributed (backend "nccl" = RCCL over
 xGMI; "gloo" in the CPU tests).  Every rank parses a run of whole sequences on its own GPU, the per-rank phrase
 dictionaries and parses travel in ONE all-gather (padded to the largest rank: all_gather needs equal sizes, this is
-the all-gather-v of the design), and rank 0 merges them (pfp_merge_shards) and runs the single-GPU stages.
+the all-gather-v of the design); every rank then merges them, sorts the merged dictionary and the parse, and emits
+its own slice of the BWT/SA rows (see sharded_build).
 torch is plumbing here: device buffers + the collective."""
 import torch
 import torch.distributed as dist
@@ -49,18 +50,22 @@ def allgather_shards(ctx, device, group=None):
     return views, recv
 
 
-def sharded_build(ctx, feed_local, w, device, sa=True, rssa=False, group=None):
-    """feed_local(ctx) feeds this rank's sequences.  Rank 0 returns (parse sizes, bwt sizes); other ranks None."""
-    rank = dist.get_rank(group)
+def sharded_build(ctx, feed_local, w, device, sa=True, group=None):
+    """SPMD build over the ranks of `group`.
+    1. every rank parses its own run of whole sequences (rank r > 0 with the w 'A's of the previous shard as context);
+    2. ONE all-gather moves every rank's dictionary + parse to every rank;
+    3. every rank merges them (pfp_merge_shards) and suffix-sorts the merged dictionary and the parse -- redundant but
+       identical work (≈ constant for a haplotype panel), which saves broadcasting ≈ 15 B per dictionary byte;
+    4. every rank emits its own slice of the output rows (pfp_bwt_build_slice): .bwt / .sa stay distributed in HBM.
+    feed_local(ctx) feeds this rank's sequences.  Returns (parse sizes, bwt sizes of the slice, first row, rows)."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
     if rank > 0:
         ctx.feed_left_context(w)
     feed_local(ctx)
     ctx.finalize()
     views, keep = allgather_shards(ctx, device, group)
-    if rank != 0:
-        return None
-    sz = ctx.merge_shards(views)     # the local parse of rank 0 is consumed through its view in `keep`
+    sz = ctx.merge_shards(views)     # the local parse is consumed through its copy in `keep`
+    del keep, views
     ctx.parse_bwt()
-    b = ctx.bwt_build(sa=sa, rssa=rssa)
-    del keep
-    return sz, b
+    b, begin, rows = ctx.bwt_build_slice(rank, world, sa=sa)
+    return sz, b, begin, rows

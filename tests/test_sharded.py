@@ -64,13 +64,18 @@ rank, world = dist.get_rank(), dist.get_world_size()
 seqs = synth(7, 3000, 2 * world)
 mine = seqs[2 * rank: 2 * rank + 2]
 ctx = pfbwt_hip.PfpContext(lib=EMU_SO, w=6, p=11, u64=False, sai=True)
-out = pfbwt_dist.sharded_build(ctx, lambda c: [c.feed(s, True) for s in mine], 6, torch.device("cpu"), sa=True, rssa=True)
+sz, b, begin, rows = pfbwt_dist.sharded_build(ctx, lambda c: [c.feed(s, True) for s in mine], 6, torch.device("cpu"), sa=True)
+o = ctx.bwt_get()
+parts = [None] * world
+dist.all_gather_object(parts, (begin, rows, int(b.r), o["bwt"], o["sa"]))
 ok = 1
 if rank == 0:
-    sz, b = out
-    res = {"n": sz.n, "m": sz.m, "dwords": sz.dwords, "dsize": sz.dsize, "r": b.r}
-    res.update(ctx.parse_get()); res.update(ctx.parse_bwt_get()); res.update(ctx.bwt_get())
-    bad = compare(res, oracle_run(seqs, w=6, p=11, U=4), 4)
+    parts.sort(key=lambda t: t[0])
+    assert parts[0][0] == 0 and all(parts[i][0] + parts[i][1] == parts[i + 1][0] for i in range(world - 1))
+    res = {"n": sz.n, "m": sz.m, "dwords": sz.dwords, "dsize": sz.dsize, "r": sum(t[2] for t in parts)}
+    res.update(ctx.parse_get()); res.update(ctx.parse_bwt_get())
+    res["bwt"] = np.concatenate([t[3] for t in parts]); res["sa"] = np.concatenate([t[4] for t in parts])
+    bad = compare(res, oracle_run(seqs, w=6, p=11, U=4), 4, names=("dict", "occ", "parse", "last", "sai", "bwlast", "ilist", "bwsai", "bwt", "sa"))
     ok = 0 if bad else 1
     if bad: print("MISMATCH", bad, flush=True)
 t = torch.tensor([ok]); dist.all_reduce(t, op=dist.ReduceOp.MIN)
@@ -80,13 +85,46 @@ sys.exit(0 if int(t) == 1 else 1)
 
 
 def test_sharded_build_gloo_world2(emu_factory, tmp_path):
-    """the N > 1 path of bench.py (pfbwt_dist.sharded_build: all-gather of dictionaries + merge on rank 0), gloo, 2 ranks"""
+    """the N > 1 path of bench.py (pfbwt_dist.sharded_build: all-gather of dictionaries, merge, sliced emission), gloo, 2 ranks"""
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     pr = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29641",
                          str(script), ROOT], capture_output=True, text=True, env=env, timeout=600)
     assert pr.returncode == 0, pr.stdout[-2000:] + pr.stderr[-3000:]
+
+
+def sliced_emission(factory, seqs, w, p, U, nslices):
+    bwt, sa, r = [], [], 0
+    for sl in range(nslices):
+        c = factory(w=w, p=p, u64=(U == 8), sai=True)
+        for s in seqs:
+            c.feed(s, True)
+        c.finalize(); c.parse_bwt()
+        b, beg, rows = c.bwt_build_slice(sl, nslices, sa=True)
+        o = c.bwt_get(); c.close()
+        assert beg == sum(len(x) for x in bwt) and rows == len(o["bwt"])
+        bwt.append(o["bwt"]); sa.append(o["sa"]); r += b.r
+    return np.concatenate(bwt), np.concatenate(sa), r
+
+
+def test_sliced_emission_emu(emu_factory):
+    seqs = synth(5, 4000, 3)
+    ref = oracle_run(seqs, w=4, p=7, U=4)       # many multi-word groups straddle the slice boundaries
+    for ns in (2, 5):
+        bwt, sa, r = sliced_emission(emu_factory, seqs, 4, 7, 4, ns)
+        assert np.array_equal(bwt, ref["bwt"]) and np.array_equal(sa.astype(np.uint64), ref["sa"] & np.uint64(0xFFFFFFFF)) and r == ref["r"]
+
+
+@pytest.mark.gpu
+def test_sliced_emission_gpu(gpu_ctx_factory):
+    for seed, L, H, w, p, U in ((5, 200000, 4, 10, 100, 4), (6, 60000, 3, 4, 7, 8)):
+        seqs = synth(seed, L, H)
+        ref = oracle_run(seqs, w=w, p=p, U=U)
+        for ns in (2, 3, 8):
+            bwt, sa, r = sliced_emission(gpu_ctx_factory, seqs, w, p, U, ns)
+            want = ref["sa"] & np.uint64(0xFFFFFFFF) if U == 4 else ref["sa"]
+            assert np.array_equal(bwt, ref["bwt"]) and np.array_equal(sa.astype(np.uint64), want) and r == ref["r"]
 
 
 @pytest.mark.gpu
