@@ -17,6 +17,14 @@ using namespace pfp;
 static int ensure_arena(pfp_ctx *c, uint64_t n_hint)
 {
     size_t want = c->arena_request ? c->arena_request : (size_t)(96ULL * n_hint + (64ULL << 20));
+    if (!c->arena_request) {   // never ask for more than the device can give (large inputs run with what there is)
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
+            const size_t avail = fr + (c->arena.base ? c->arena.cap : 0);
+            const size_t cap = avail - avail / 16;
+            if (want > cap) want = cap;
+        }
+    }
     if (c->arena.base && c->arena.cap >= want) return PFP_OK;
     if (c->arena.base) { PFP_HIP(c, hipStreamSynchronize(c->stream)); PFP_HIP(c, hipFree(c->arena.base)); c->arena.base = nullptr; c->arena.cap = 0; }
     void *p = nullptr;
