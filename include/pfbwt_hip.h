@@ -98,7 +98,7 @@ typedef struct pfp_shard_view {
     const uint8_t *d_dict;          /* dsize bytes: distinct phrases, each + 0x01, then 0x00 (any order) */
     const uint32_t *d_ws;           /* dwords+1 word starts in d_dict */
     const uint32_t *d_pid;          /* m: word id of every phrase */
-    const uint32_t *d_ye;           /* m: 1-based end position of every phrase in the shard's text (= sai) */
+    const uint64_t *d_ye;           /* m: 1-based end position of every phrase in the shard's text (= sai) */
     const uint8_t *d_last;          /* m */
 } pfp_shard_view;
 int pfp_shard_view_get(pfp_ctx *ctx, pfp_shard_view *view);

@@ -74,7 +74,7 @@ struct pfp_ctx {
     // --- parse results (device, arena low end)
     int stage = 0;             // 0 feeding, 1 parsed, 2 parse-bwt done
     uint64_t m = 0, dwords = 0, dsize = 0;
-    uint32_t *d_ye = nullptr;       // m: Y-coordinate of each phrase's last byte (= sai)
+    uint64_t *d_ye = nullptr;       // m: Y-coordinate of each phrase's last byte (= sai); text positions are 64-bit
     uint32_t *d_pid = nullptr;      // m: phrase -> dictionary word id (D' order)
     uint32_t *d_parse = nullptr;    // m: 1-based ranks
     uint8_t *d_last = nullptr;      // m
@@ -89,7 +89,7 @@ struct pfp_ctx {
     bool gsa_valid = false;
     // --- parse-BWT results
     uint64_t nrows = 0;
-    uint8_t *d_bwlast = nullptr; uint32_t *d_ilist = nullptr; uint32_t *d_bwsai = nullptr;
+    uint8_t *d_bwlast = nullptr; uint32_t *d_ilist = nullptr; uint64_t *d_bwsai = nullptr;
     // --- BWT results
     uint64_t nout = 0, runs = 0, easy = 0, hard = 0, slice_begin = 0, slice_rows = 0;
     uint8_t *d_bwt = nullptr; void *d_sa = nullptr; void *d_ssa = nullptr; void *d_esa = nullptr;

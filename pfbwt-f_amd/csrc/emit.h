@@ -16,8 +16,8 @@
 namespace pfp {
 
 // pfparser.hpp:430-451.  SAP = suffix array of ranks+[0] (m+1 entries), P = 1-based ranks, sai = ye.
-__global__ __launch_bounds__(BLOCK) void k_pbwt_rows(const uint32_t *SAP, const uint32_t *P, const uint8_t *last, const uint32_t *sai, uint64_t m,
-                                                     uint8_t *bwlast, uint32_t *bwsai, uint32_t *W, uint32_t *rowid)
+__global__ __launch_bounds__(BLOCK) void k_pbwt_rows(const uint32_t *SAP, const uint32_t *P, const uint8_t *last, const tpos_t *sai, uint64_t m,
+                                                     uint8_t *bwlast, tpos_t *bwsai, uint32_t *W, uint32_t *rowid)
 {
     const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i > m) return;
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(BLOCK) void k_parse_ranks(const uint32_t *pid, cons
     const uint64_t j = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (j < m) parse[j] = wrank[pid[j]] + 1u;    // generate_ranks, pfparser.hpp:504-517 (1-based)
 }
-__global__ __launch_bounds__(BLOCK) void k_sorted_lengths(const uint32_t *ws, const uint32_t *idofrank, uint64_t dwords, uint32_t *len1, uint32_t *srcstart)
+__global__ __launch_bounds__(BLOCK) void k_sorted_lengths(const uint32_t *ws, const uint32_t *idofrank, uint64_t dwords, uint32_t *len1, tpos_t *srcstart)
 {
     const uint64_t r = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (r >= dwords) return;
@@ -81,7 +81,8 @@ __global__ __launch_bounds__(BLOCK) void k_ws_from_flags(const uint8_t *D, uint6
 // ---- emission -----------------------------------------------------------------------------------
 struct EmitArgs {
     const uint8_t *D; uint64_t dsize; uint32_t dwords; int w;
-    const uint32_t *SA, *ws, *wrank /*nullable*/, *occ, *F, *ilist, *bwsai /*nullable*/;
+    const uint32_t *SA, *ws, *wrank /*nullable*/, *occ, *F, *ilist;
+    const tpos_t *bwsai;    // nullable
     const uint2 *posinfo;
     const uint4 *winfo;     // per word id: { first byte, offset of its EndOfWord, first ilist index F[rank], occ[rank] }
     const uint8_t *bwlast;

@@ -12,6 +12,8 @@
 
 namespace pfp {
 
+typedef uint64_t tpos_t;   // text positions (see Spans below)
+
 // include/hash.hpp:12-21
 __device__ __forceinline__ uint64_t wang_hash(uint64_t key)
 {
@@ -113,13 +115,13 @@ __global__ __launch_bounds__(BLOCK) void k_trigger_scan(uint8_t *X, uint64_t n, 
 }
 
 // ye[j] = (trigger position e_j) + 1 for every trigger, in text order
-__global__ __launch_bounds__(BLOCK) void k_phrase_ends(const uint16_t *mask16, const uint32_t *blockoff, uint32_t *ye)
+__global__ __launch_bounds__(BLOCK) void k_phrase_ends(const uint16_t *mask16, const uint32_t *blockoff, tpos_t *ye)
 {
     __shared__ uint32_t red[4];
     const uint64_t t = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     uint32_t m = mask16[t], tot;
     uint32_t o = blockoff[blockIdx.x] + block_excl_sum((uint32_t)__popc(m), red, &tot);
-    while (m) { int b = __ffs((int)m) - 1; m &= m - 1; ye[o++] = (uint32_t)(t * 16 + b + 1); }
+    while (m) { int b = __ffs((int)m) - 1; m &= m - 1; ye[o++] = (tpos_t)(t * 16 + b + 1); }
 }
 
 // ---- phrase fingerprints: polynomial hash modulo the Mersenne prime 2^61-1 ---------------------
@@ -147,11 +149,14 @@ __host__ __device__ __forceinline__ uint64_t powmod61(uint64_t b, uint64_t e)
 // Where the byte strings to be de-duplicated live: string j = Y[ys_j .. ye[j]].  Text mode (ys == nullptr):
 // consecutive phrases overlap by w bytes, ys_j = ye[j-1] - w + 1, ys_0 = 0.  Word mode (ys != nullptr): explicit
 // starts (dictionary words of several shards laid out in one buffer, see pfp_merge_shards).
-struct Spans { const uint32_t *ye; const uint32_t *ys; int w; };
-__device__ __forceinline__ void phrase_span(const Spans &sp, uint64_t j, uint32_t *ys, uint32_t *len)
+// Text positions are 64-bit (tpos_t): a 1000-haplotype collection has tens of Gbases while its dictionary and its
+// parse stay far below 2^32 entries.
+struct Spans { const tpos_t *ye; const uint32_t *ys32; const uint32_t *ye32; int w; };
+__device__ __forceinline__ void phrase_span(const Spans &sp, uint64_t j, tpos_t *ys, uint32_t *len)
 {
-    const uint32_t s = sp.ys ? sp.ys[j] : (j ? sp.ye[j - 1] - (uint32_t)sp.w + 1u : 0u);
-    *ys = s; *len = sp.ye[j] - s + 1u;
+    if (sp.ys32) { const uint32_t s = sp.ys32[j]; *ys = s; *len = sp.ye32[j] - s + 1u; return; }
+    const tpos_t s = j ? sp.ye[j - 1] - (tpos_t)sp.w + 1u : (tpos_t)0;
+    *ys = s; *len = (uint32_t)(sp.ye[j] - s + 1u);
 }
 
 constexpr uint32_t LONG_PHRASE = 2048; // phrases longer than this go to the workgroup-per-phrase kernels
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(BLOCK) void k_phrase_hash(const uint8_t *Y, Spans s
 {
     const uint64_t j = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (j >= m) return;
-    uint32_t ys, len; phrase_span(sp, j, &ys, &len);
+    tpos_t ys; uint32_t len; phrase_span(sp, j, &ys, &len);
     vals[j] = (uint32_t)j;
     if (len > LONG_PHRASE) { longlist[atomicAdd(nlong, 1u)] = (uint32_t)j; keys[j] = 0; return; }
     uint64_t h = 0;
@@ -174,23 +179,23 @@ __global__ __launch_bounds__(BLOCK) void k_phrase_hash(const uint8_t *Y, Spans s
 // ---- long phrases (e.g. a 10 Mbp run of N is ONE phrase: wang_hash(0) % 100 != 0) ----
 // A host-built chunk table spreads every long phrase over workgroups of LONG_CHUNK bytes.
 constexpr uint32_t LONG_CHUNK = 16384;
-struct LongChunk { uint32_t item; uint32_t a_off, b_off; uint32_t len; }; // item index, two Y offsets of the chunk, chunk length
+struct LongChunk { tpos_t a_off, b_off; uint32_t item; uint32_t len; }; // item index, two Y offsets of the chunk, chunk length
 
 // spans of listed phrases: out[2k] = ys, out[2k+1] = len
-__global__ __launch_bounds__(BLOCK) void k_list_spans(Spans sp, const uint32_t *list, uint32_t cnt, uint32_t *out)
+__global__ __launch_bounds__(BLOCK) void k_list_spans(Spans sp, const uint32_t *list, uint32_t cnt, tpos_t *out)
 {
     const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
     if (k >= cnt) return;
-    uint32_t ys, len; phrase_span(sp, list[k], &ys, &len);
+    tpos_t ys; uint32_t len; phrase_span(sp, list[k], &ys, &len);
     out[2 * k] = ys; out[2 * k + 1] = len;
 }
 // same for the two phrases of each listed sorted position i: (vals[i-1], vals[i]); out[3k..] = ys_a, ys_b, len
-__global__ __launch_bounds__(BLOCK) void k_pair_spans(Spans sp, const uint32_t *vals, const uint32_t *list, uint32_t cnt, uint32_t *out)
+__global__ __launch_bounds__(BLOCK) void k_pair_spans(Spans sp, const uint32_t *vals, const uint32_t *list, uint32_t cnt, tpos_t *out)
 {
     const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
     if (k >= cnt) return;
     const uint32_t i = list[k];
-    uint32_t sa_, la, sb, lb;
+    tpos_t sa_, sb; uint32_t la, lb;
     phrase_span(sp, vals[i - 1], &sa_, &la);
     phrase_span(sp, vals[i], &sb, &lb);
     out[3 * k] = sa_; out[3 * k + 1] = sb; out[3 * k + 2] = la;
@@ -219,7 +224,7 @@ __global__ __launch_bounds__(BLOCK) void k_phrase_hash_long(const uint8_t *Y, co
 }
 // one thread per long phrase folds its chunks (consecutive in the table, first chunk index in first[])
 __global__ __launch_bounds__(BLOCK) void k_phrase_hash_fold(const LongChunk *chunks, const uint32_t *first, const uint32_t *longlist, uint32_t nlong,
-                                                            const uint32_t *spans, const uint64_t *partial, uint64_t B, uint64_t Bchunk, uint64_t *keys)
+                                                            const tpos_t *spans, const uint64_t *partial, uint64_t B, uint64_t Bchunk, uint64_t *keys)
 {
     const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
     if (k >= nlong) return;
@@ -244,7 +249,7 @@ __global__ __launch_bounds__(BLOCK) void k_dedup_heads(const uint8_t *Y, Spans s
     const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= m) return;
     if (i == 0 || keys[i] != keys[i - 1]) { head[i] = 1; return; }
-    uint32_t sa_, la, sb, lb;
+    tpos_t sa_, sb; uint32_t la, lb;
     phrase_span(sp, vals[i - 1], &sa_, &la);
     phrase_span(sp, vals[i], &sb, &lb);
     if (la != lb) { head[i] = 1; atomicAdd(collide, 1u); return; }
@@ -276,7 +281,7 @@ __global__ __launch_bounds__(BLOCK) void k_word_lengths(Spans sp, const uint32_t
 {
     const uint64_t id = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (id >= dwords) return;
-    uint32_t ys, len; phrase_span(sp, rep[id], &ys, &len);
+    tpos_t ys; uint32_t len; phrase_span(sp, rep[id], &ys, &len);
     wlen1[id] = len + 1;
     occw[id] = (id + 1 < dwords ? headpos[id + 1] : (uint32_t)m) - headpos[id];
 }
@@ -290,7 +295,7 @@ __device__ __forceinline__ uint32_t upper_bound_u32(const uint32_t *a, uint32_t 
 
 // D' : words in id order, each followed by EndOfWord, then EndOfDict.  One thread = 16 output bytes.
 // srcstart[id] = Y offset of the word's first byte (or offset into another dictionary image).
-__global__ __launch_bounds__(BLOCK) void k_dict_build(const uint8_t *src, const uint32_t *srcstart, const uint32_t *ws, uint32_t dwords, uint64_t dsize,
+__global__ __launch_bounds__(BLOCK) void k_dict_build(const uint8_t *src, const tpos_t *srcstart, const uint32_t *ws, uint32_t dwords, uint64_t dsize,
                                                       uint8_t *dict, uint32_t *wordid)
 {
     const uint64_t x0 = ((uint64_t)blockIdx.x * BLOCK + threadIdx.x) * 16;
@@ -305,18 +310,18 @@ __global__ __launch_bounds__(BLOCK) void k_dict_build(const uint8_t *src, const 
         if (wordid) wordid[x] = id;
     }
 }
-__global__ __launch_bounds__(BLOCK) void k_rep_starts(Spans sp, const uint32_t *rep, uint64_t dwords, uint32_t *srcstart)
+__global__ __launch_bounds__(BLOCK) void k_rep_starts(Spans sp, const uint32_t *rep, uint64_t dwords, tpos_t *srcstart)
 {
     const uint64_t id = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (id >= dwords) return;
-    uint32_t ys, len; phrase_span(sp, rep[id], &ys, &len);
+    tpos_t ys; uint32_t len; phrase_span(sp, rep[id], &ys, &len);
     srcstart[id] = ys;
 }
 // last[j] = Y[ye[j] - w]   (pfparser.hpp:599)
-__global__ __launch_bounds__(BLOCK) void k_last_chars(const uint8_t *Y, const uint32_t *ye, uint64_t m, int w, uint8_t *last)
+__global__ __launch_bounds__(BLOCK) void k_last_chars(const uint8_t *Y, const tpos_t *ye, uint64_t m, int w, uint8_t *last)
 {
     const uint64_t j = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (j < m) last[j] = Y[ye[j] - (uint32_t)w];
+    if (j < m) last[j] = Y[ye[j] - (tpos_t)w];
 }
 __global__ __launch_bounds__(BLOCK) void k_fill_u8(uint8_t *p, uint64_t n, uint8_t v)
 {
@@ -324,6 +329,10 @@ __global__ __launch_bounds__(BLOCK) void k_fill_u8(uint8_t *p, uint64_t n, uint8
     if (i < n) p[i] = v;
 }
 __global__ __launch_bounds__(BLOCK) void k_set_u32(uint32_t *p, uint64_t idx, uint32_t v)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) p[idx] = v;
+}
+__global__ __launch_bounds__(BLOCK) void k_set_u64(uint64_t *p, uint64_t idx, uint64_t v)
 {
     if (blockIdx.x == 0 && threadIdx.x == 0) p[idx] = v;
 }

@@ -187,16 +187,16 @@ static int sort_dict_suffixes(pfp_ctx *c)
 static int hash_long_phrases(pfp_ctx *c, const uint8_t *Y, Spans sp, const uint32_t *d_longlist, uint32_t nlong, uint64_t B, uint64_t *keys)
 {
     const size_t mk = c->arena.mark_hi();
-    uint32_t *d_spans; PFP_ALLOC_HI(c, d_spans, uint32_t, 2 * (size_t)nlong);
+    tpos_t *d_spans; PFP_ALLOC_HI(c, d_spans, tpos_t, 2 * (size_t)nlong);
     PFP_LAUNCH(c, K_MISC, nlong * 16, k_list_spans, nblocks(nlong, BLOCK), sp, d_longlist, nlong, d_spans);
-    std::vector<uint32_t> spans(2 * (size_t)nlong);
-    PFP_HIP(c, hipMemcpyAsync(spans.data(), d_spans, spans.size() * 4, hipMemcpyDeviceToHost, c->stream));
+    std::vector<tpos_t> spans(2 * (size_t)nlong);
+    PFP_HIP(c, hipMemcpyAsync(spans.data(), d_spans, spans.size() * sizeof(tpos_t), hipMemcpyDeviceToHost, c->stream));
     PFP_HIP(c, hipStreamSynchronize(c->stream));
     std::vector<LongChunk> tab; std::vector<uint32_t> first(nlong + 1);
     for (uint32_t k = 0; k < nlong; ++k) {
         first[k] = (uint32_t)tab.size();
-        const uint32_t ys = spans[2 * k], len = spans[2 * k + 1];
-        for (uint32_t a = 0; a < len; a += LONG_CHUNK) tab.push_back({k, ys + a, 0u, (len - a < LONG_CHUNK) ? len - a : LONG_CHUNK});
+        const tpos_t ys = spans[2 * k]; const uint32_t len = (uint32_t)spans[2 * k + 1];
+        for (uint32_t a = 0; a < len; a += LONG_CHUNK) tab.push_back({ys + a, (tpos_t)0, k, (len - a < LONG_CHUNK) ? len - a : LONG_CHUNK});
     }
     first[nlong] = (uint32_t)tab.size();
     LongChunk *d_tab; uint32_t *d_first; uint64_t *d_part;
@@ -206,7 +206,7 @@ static int hash_long_phrases(pfp_ctx *c, const uint8_t *Y, Spans sp, const uint3
     double bytes = 0; for (auto &t : tab) bytes += t.len;
     PFP_LAUNCH(c, K_PHRASE_HASH_LONG, bytes, k_phrase_hash_long, (unsigned)tab.size(), Y, (const LongChunk *)d_tab, B, d_part);
     PFP_LAUNCH(c, K_MISC, tab.size() * 24, k_phrase_hash_fold, nblocks(nlong, BLOCK), (const LongChunk *)d_tab, (const uint32_t *)d_first, d_longlist, nlong,
-               (const uint32_t *)d_spans, (const uint64_t *)d_part, B, powmod61(B, LONG_CHUNK), keys);
+               (const tpos_t *)d_spans, (const uint64_t *)d_part, B, powmod61(B, LONG_CHUNK), keys);
     PFP_HIP(c, hipStreamSynchronize(c->stream));   // tab / first are host vectors
     c->arena.release_hi(mk);
     return PFP_OK;
@@ -214,15 +214,15 @@ static int hash_long_phrases(pfp_ctx *c, const uint8_t *Y, Spans sp, const uint3
 static int compare_long_pairs(pfp_ctx *c, const uint8_t *Y, Spans sp, const uint32_t *d_vals, const uint32_t *d_pairs, uint32_t np, uint32_t *d_collide)
 {
     const size_t mk = c->arena.mark_hi();
-    uint32_t *d_spans; PFP_ALLOC_HI(c, d_spans, uint32_t, 3 * (size_t)np);
+    tpos_t *d_spans; PFP_ALLOC_HI(c, d_spans, tpos_t, 3 * (size_t)np);
     PFP_LAUNCH(c, K_MISC, np * 24, k_pair_spans, nblocks(np, BLOCK), sp, d_vals, d_pairs, np, d_spans);
-    std::vector<uint32_t> spans(3 * (size_t)np);
-    PFP_HIP(c, hipMemcpyAsync(spans.data(), d_spans, spans.size() * 4, hipMemcpyDeviceToHost, c->stream));
+    std::vector<tpos_t> spans(3 * (size_t)np);
+    PFP_HIP(c, hipMemcpyAsync(spans.data(), d_spans, spans.size() * sizeof(tpos_t), hipMemcpyDeviceToHost, c->stream));
     PFP_HIP(c, hipStreamSynchronize(c->stream));
     std::vector<LongChunk> tab;
     for (uint32_t k = 0; k < np; ++k) {
-        const uint32_t sa_ = spans[3 * k], sb = spans[3 * k + 1], len = spans[3 * k + 2];
-        for (uint32_t a = 0; a < len; a += LONG_CHUNK) tab.push_back({k, sa_ + a, sb + a, (len - a < LONG_CHUNK) ? len - a : LONG_CHUNK});
+        const tpos_t sa_ = spans[3 * k], sb = spans[3 * k + 1]; const uint32_t len = (uint32_t)spans[3 * k + 2];
+        for (uint32_t a = 0; a < len; a += LONG_CHUNK) tab.push_back({sa_ + a, sb + a, k, (len - a < LONG_CHUNK) ? len - a : LONG_CHUNK});
     }
     LongChunk *d_tab; PFP_ALLOC_HI(c, d_tab, LongChunk, tab.size());
     PFP_HIP(c, hipMemcpyAsync(d_tab, tab.data(), tab.size() * sizeof(LongChunk), hipMemcpyHostToDevice, c->stream));
@@ -283,8 +283,8 @@ static int dedup_strings(pfp_ctx *c, const uint8_t *Y, Spans sp, uint64_t m, uin
 // word id of every offset.  occw[id] = number of input strings with that id.
 static int build_dictionary(pfp_ctx *c, const uint8_t *Y, Spans sp, const uint32_t *rep, const uint32_t *headpos, uint64_t dwords, uint64_t m, uint32_t **occw_out)
 {
-    uint32_t *wlen1, *occw, *srcstart;
-    PFP_ALLOC_HI(c, wlen1, uint32_t, dwords); PFP_ALLOC_HI(c, occw, uint32_t, dwords); PFP_ALLOC_HI(c, srcstart, uint32_t, dwords);
+    uint32_t *wlen1, *occw; tpos_t *srcstart;
+    PFP_ALLOC_HI(c, wlen1, uint32_t, dwords); PFP_ALLOC_HI(c, occw, uint32_t, dwords); PFP_ALLOC_HI(c, srcstart, tpos_t, dwords);
     const unsigned gd = nblocks(dwords, BLOCK);
     PFP_LAUNCH(c, K_MISC, dwords * 16, k_word_lengths, gd, sp, rep, headpos, dwords, m, wlen1, occw);
     PFP_ALLOC_LO(c, c->d_ws, uint32_t, dwords + 1);
@@ -296,7 +296,7 @@ static int build_dictionary(pfp_ctx *c, const uint8_t *Y, Spans sp, const uint32
     PFP_ALLOC_LO(c, c->d_dict, uint8_t, dsize + 16);
     PFP_ALLOC_LO(c, c->d_wordid, uint32_t, dsize);
     PFP_LAUNCH(c, K_MISC, dwords * 12, k_rep_starts, gd, sp, rep, dwords, srcstart);
-    PFP_LAUNCH(c, K_DICT_BUILD, dsize * 6, k_dict_build, nblocks(dsize, 16 * BLOCK), Y, (const uint32_t *)srcstart, (const uint32_t *)c->d_ws, (uint32_t)dwords, dsize, c->d_dict, c->d_wordid);
+    PFP_LAUNCH(c, K_DICT_BUILD, dsize * 6, k_dict_build, nblocks(dsize, 16 * BLOCK), Y, (const tpos_t *)srcstart, (const uint32_t *)c->d_ws, (uint32_t)dwords, dsize, c->d_dict, c->d_wordid);
     *occw_out = occw;
     return PFP_OK;
 }
@@ -309,9 +309,9 @@ static int finish_parse(pfp_ctx *c, const uint32_t *occw)
     const unsigned gm = nblocks(m, BLOCK), gd = nblocks(dwords, BLOCK);
     // suffix sort of the dictionary: gives word ranks now and the emission order later
     PFP_TRY(sort_dict_suffixes(c));
-    uint32_t *wk0, *wk1, *wv0, *wv1, *idofrank, *len1, *srcstart;
+    uint32_t *wk0, *wk1, *wv0, *wv1, *idofrank, *len1; tpos_t *srcstart;
     PFP_ALLOC_HI(c, wk0, uint32_t, dwords); PFP_ALLOC_HI(c, wk1, uint32_t, dwords); PFP_ALLOC_HI(c, wv0, uint32_t, dwords); PFP_ALLOC_HI(c, wv1, uint32_t, dwords);
-    PFP_ALLOC_HI(c, idofrank, uint32_t, dwords); PFP_ALLOC_HI(c, len1, uint32_t, dwords + 1); PFP_ALLOC_HI(c, srcstart, uint32_t, dwords);
+    PFP_ALLOC_HI(c, idofrank, uint32_t, dwords); PFP_ALLOC_HI(c, len1, uint32_t, dwords + 1); PFP_ALLOC_HI(c, srcstart, tpos_t, dwords);
     PFP_ALLOC_LO(c, c->d_wrank, uint32_t, dwords);
     PFP_ALLOC_LO(c, c->d_occ, uint32_t, dwords);
     PFP_ALLOC_LO(c, c->d_parse, uint32_t, m + 1);
@@ -326,7 +326,7 @@ static int finish_parse(pfp_ctx *c, const uint32_t *occw)
     PFP_LAUNCH(c, K_PARSE_RANKS, m * 12, k_parse_ranks, gm, (const uint32_t *)c->d_pid, (const uint32_t *)c->d_wrank, m, c->d_parse);
     PFP_LAUNCH(c, K_DICT_SORTED, dwords * 12, k_sorted_lengths, gd, (const uint32_t *)c->d_ws, (const uint32_t *)idofrank, dwords, len1, srcstart);
     PFP_TRY((device_scan<uint32_t, 0>(c, len1, len1, dwords, len1 + dwords)));
-    PFP_LAUNCH(c, K_DICT_SORTED, dsize * 2, k_dict_build, nblocks(dsize, 16 * BLOCK), (const uint8_t *)c->d_dict, (const uint32_t *)srcstart, (const uint32_t *)len1, (uint32_t)dwords, dsize,
+    PFP_LAUNCH(c, K_DICT_SORTED, dsize * 2, k_dict_build, nblocks(dsize, 16 * BLOCK), (const uint8_t *)c->d_dict, (const tpos_t *)srcstart, (const uint32_t *)len1, (uint32_t)dwords, dsize,
                c->d_sdict, (uint32_t *)nullptr);
     return PFP_OK;
 }
@@ -370,18 +370,18 @@ int pfp_parse_finalize(pfp_ctx *c, pfp_parse_sizes *out)
     }
     const uint64_t m = (uint64_t)ntrig + 1;
     c->m = m;
-    PFP_ALLOC_LO(c, c->d_ye, uint32_t, m);
+    PFP_ALLOC_LO(c, c->d_ye, tpos_t, m);
     PFP_LAUNCH(c, K_PHRASE_ENDS, n / 8 + m * 4, k_phrase_ends, gts, (const uint16_t *)mask16, (const uint32_t *)blockcnt, c->d_ye);
-    PFP_LAUNCH(c, K_MISC, 4, k_set_u32, 1, c->d_ye, m - 1, (uint32_t)(n + (uint64_t)w));
+    PFP_LAUNCH(c, K_MISC, 8, k_set_u64, 1, c->d_ye, m - 1, (uint64_t)(n + (uint64_t)w));
 
     // 2. distinct phrases, dictionary
-    Spans sp; sp.ye = c->d_ye; sp.ys = nullptr; sp.w = w;
+    Spans sp; sp.ye = c->d_ye; sp.ys32 = nullptr; sp.ye32 = nullptr; sp.w = w;
     uint64_t dwords = 0; uint32_t *rep, *headpos, *occw;
     PFP_ALLOC_LO(c, c->d_pid, uint32_t, m);
     PFP_ALLOC_LO(c, c->d_last, uint8_t, m);
     PFP_TRY(dedup_strings(c, Y, sp, m, n + (uint64_t)w + 1 + m * (uint64_t)w, c->d_pid, &dwords, &rep, &headpos));
     PFP_TRY(build_dictionary(c, Y, sp, rep, headpos, dwords, m, &occw));
-    PFP_LAUNCH(c, K_MISC, m * 6, k_last_chars, nblocks(m, BLOCK), Y, (const uint32_t *)c->d_ye, m, w, c->d_last);
+    PFP_LAUNCH(c, K_MISC, m * 6, k_last_chars, nblocks(m, BLOCK), Y, (const tpos_t *)c->d_ye, m, w, c->d_last);
     // 3. dictionary suffix sort, ranks, occ, parse, sorted .dict image
     PFP_TRY(finish_parse(c, occw));
     PFP_HIP(c, hipStreamSynchronize(c->stream));
@@ -409,9 +409,9 @@ __global__ __launch_bounds__(BLOCK) void k_merge_spans(const uint32_t *ws, uint3
     if (k == fragl) { a = fragl_ys; b = fragl_ye; }
     ys[coff + k] = a; ye[coff + k] = b;
 }
-__global__ __launch_bounds__(BLOCK) void k_merge_phrases(const uint32_t *pid, const uint32_t *ye, const uint8_t *last, uint32_t m, uint32_t j0, uint32_t goff, uint32_t coff, uint32_t shift,
-                                                         const uint32_t *cand_id, uint32_t junction_ye, uint32_t junction_last, int has_junction,
-                                                         uint32_t *gpid, uint32_t *gye, uint8_t *glast, uint32_t *occw)
+__global__ __launch_bounds__(BLOCK) void k_merge_phrases(const uint32_t *pid, const tpos_t *ye, const uint8_t *last, uint32_t m, uint32_t j0, uint32_t goff, uint32_t coff, tpos_t shift,
+                                                         const uint32_t *cand_id, tpos_t junction_ye, uint32_t junction_last, int has_junction,
+                                                         uint32_t *gpid, tpos_t *gye, uint8_t *glast, uint32_t *occw)
 {
     const uint32_t j = j0 + blockIdx.x * BLOCK + threadIdx.x;
     if (j >= m) return;
@@ -459,7 +459,7 @@ int pfp_merge_shards(pfp_ctx *c, int nshards, const pfp_shard_view *v, pfp_parse
     PFP_HIP(c, hipStreamSynchronize(c->stream));
     const size_t mk = c->arena.mark_hi();
     // ---- host: the two fragment words of every boundary -> junction words
-    struct Frag { uint32_t id0 = 0xFFFFFFFFu, idl = 0xFFFFFFFFu; uint32_t ye0 = 0, last0 = 0; std::vector<uint8_t> w0, wl; };
+    struct Frag { uint32_t id0 = 0xFFFFFFFFu, idl = 0xFFFFFFFFu; tpos_t ye0 = 0; uint32_t last0 = 0; std::vector<uint8_t> w0, wl; };
     std::vector<Frag> fr((size_t)nshards);
     auto fetch_word = [&](const pfp_shard_view &sv, uint32_t id, std::vector<uint8_t> &dst) -> int {
         uint32_t se[2];
@@ -471,7 +471,7 @@ int pfp_merge_shards(pfp_ctx *c, int nshards, const pfp_shard_view *v, pfp_parse
     for (int r = 0; r < nshards; ++r) {
         if (r > 0) {
             PFP_HIP(c, hipMemcpy(&fr[r].id0, v[r].d_pid, 4, hipMemcpyDeviceToHost));
-            PFP_HIP(c, hipMemcpy(&fr[r].ye0, v[r].d_ye, 4, hipMemcpyDeviceToHost));
+            PFP_HIP(c, hipMemcpy(&fr[r].ye0, v[r].d_ye, sizeof(tpos_t), hipMemcpyDeviceToHost));
             uint8_t l0 = 0; PFP_HIP(c, hipMemcpy(&l0, v[r].d_last, 1, hipMemcpyDeviceToHost)); fr[r].last0 = l0;
             PFP_TRY(fetch_word(v[r], fr[r].id0, fr[r].w0));
             if (fr[r].w0.size() < 1 + (size_t)w) return PFP_E_CORRUPT;
@@ -505,24 +505,24 @@ int pfp_merge_shards(pfp_ctx *c, int nshards, const pfp_shard_view *v, pfp_parse
                    fr[r].id0, f0s, f0e, fr[r].idl, fls, fle, cys, cye);
     }
     // ---- global distinct words, dictionary
-    Spans sp; sp.ye = cye; sp.ys = cys; sp.w = 0;
+    Spans sp; sp.ye = nullptr; sp.ys32 = cys; sp.ye32 = cye; sp.w = 0;
     uint64_t dwords = 0; uint32_t *rep, *headpos, *occ_cand, *occw;
     PFP_TRY(dedup_strings(c, U, sp, ctot, dtot + junc.size(), cand_id, &dwords, &rep, &headpos));
     PFP_TRY(build_dictionary(c, U, sp, rep, headpos, dwords, ctot, &occ_cand));
     // ---- global phrase sequence
     c->n = ntot; c->m = mtot;
-    PFP_ALLOC_LO(c, c->d_pid, uint32_t, mtot); PFP_ALLOC_LO(c, c->d_ye, uint32_t, mtot); PFP_ALLOC_LO(c, c->d_last, uint8_t, mtot);
+    PFP_ALLOC_LO(c, c->d_pid, uint32_t, mtot); PFP_ALLOC_LO(c, c->d_ye, tpos_t, mtot); PFP_ALLOC_LO(c, c->d_last, uint8_t, mtot);
     PFP_ALLOC_HI(c, occw, uint32_t, dwords);
     PFP_HIP(c, hipMemsetAsync(occw, 0, dwords * 4, c->stream));
     {
         uint64_t goff = 0, gtext = 0;
-        std::vector<uint32_t> shift((size_t)nshards);
-        { uint64_t g = 0; for (int r = 0; r < nshards; ++r) { shift[r] = r ? (uint32_t)(g - w) : 0u; g += v[r].n - (r ? w : 0); } }
+        std::vector<tpos_t> shift((size_t)nshards);
+        { uint64_t g = 0; for (int r = 0; r < nshards; ++r) { shift[r] = r ? (tpos_t)(g - w) : (tpos_t)0; g += v[r].n - (r ? w : 0); } }
         (void)gtext;
         for (int r = 0; r < nshards; ++r) {
             const uint32_t j0 = r ? 1u : 0u, cnt = (uint32_t)v[r].m - j0;
             const int hj = r + 1 < nshards;
-            const uint32_t jye = hj ? fr[r + 1].ye0 + shift[r + 1] : 0u, jl = hj ? fr[r + 1].last0 : 0u;
+            const tpos_t jye = hj ? fr[r + 1].ye0 + shift[r + 1] : (tpos_t)0; const uint32_t jl = hj ? fr[r + 1].last0 : 0u;
             PFP_LAUNCH(c, K_MISC, cnt * 24, k_merge_phrases, nblocks(cnt, BLOCK), v[r].d_pid, v[r].d_ye, v[r].d_last, (uint32_t)v[r].m, j0, (uint32_t)goff, coff[r], shift[r],
                        (const uint32_t *)cand_id, jye, jl, hj, c->d_pid, c->d_ye, c->d_last, occw);
             goff += cnt;
@@ -550,6 +550,17 @@ static int get_u32_as(pfp_ctx *c, const uint32_t *d, uint64_t cnt, void *dst, bo
     return PFP_OK;
 }
 
+static int get_u64_as(pfp_ctx *c, const uint64_t *d, uint64_t cnt, void *dst, bool u64)
+{
+    if (!dst || !cnt) return PFP_OK;
+    if (u64) { PFP_HIP(c, hipMemcpy(dst, d, cnt * 8, hipMemcpyDeviceToHost)); return PFP_OK; }
+    std::vector<uint64_t> tmp((size_t)cnt);
+    PFP_HIP(c, hipMemcpy(tmp.data(), d, cnt * 8, hipMemcpyDeviceToHost));
+    uint32_t *o = (uint32_t *)dst;
+    for (uint64_t i = 0; i < cnt; ++i) o[i] = (uint32_t)tmp[(size_t)i];   // uint_t = 32 bit wraps like the reference's build
+    return PFP_OK;
+}
+
 int pfp_parse_get(pfp_ctx *c, uint8_t *dict, void *occ, uint32_t *parse, uint8_t *last, void *sai)
 {
     if (!c) return PFP_E_ARG;
@@ -561,7 +572,7 @@ int pfp_parse_get(pfp_ctx *c, uint8_t *dict, void *occ, uint32_t *parse, uint8_t
     PFP_TRY(get_u32_as(c, c->d_occ, c->dwords, occ, u64));
     if (parse) PFP_HIP(c, hipMemcpy(parse, c->d_parse, c->m * 4, hipMemcpyDeviceToHost));
     if (last) PFP_HIP(c, hipMemcpy(last, c->d_last, c->m, hipMemcpyDeviceToHost));
-    PFP_TRY(get_u32_as(c, c->d_ye, c->m, sai, u64));   // sai[j] = pos_ at process_phrase = ye[j]  (pfparser.hpp:600)
+    PFP_TRY(get_u64_as(c, c->d_ye, c->m, sai, u64));   // sai[j] = pos_ at process_phrase = ye[j]  (pfparser.hpp:600)
     return PFP_OK;
 }
 
@@ -595,14 +606,14 @@ int pfp_parse_bwt(pfp_ctx *c)
     PFP_ALLOC_LO(c, c->d_bwlast, uint8_t, N);
     PFP_ALLOC_LO(c, c->d_ilist, uint32_t, N);
     const bool sai = (c->flags & PFP_FLAG_SAI) != 0;
-    if (sai) PFP_ALLOC_LO(c, c->d_bwsai, uint32_t, N); else c->d_bwsai = nullptr;
+    if (sai) PFP_ALLOC_LO(c, c->d_bwsai, tpos_t, N); else c->d_bwsai = nullptr;
     PFP_ALLOC_HI(c, SAP, uint32_t, N); PFP_ALLOC_HI(c, rk, uint2, N);
     PFP_ALLOC_HI(c, W, uint32_t, N); PFP_ALLOC_HI(c, rowid, uint32_t, N);
     PFP_ALLOC_HI(c, W2, uint32_t, N); PFP_ALLOC_HI(c, rowid2, uint32_t, N);
     int rounds = 0;
     PFP_TRY(sort_int_suffixes(c, c->d_parse, N, c->dwords, SAP, rk, &rounds));   // sacak_int, :425
     PFP_LAUNCH(c, K_PBWT_ROWS, N * 24, k_pbwt_rows, nblocks(N, BLOCK), (const uint32_t *)SAP, (const uint32_t *)c->d_parse, (const uint8_t *)c->d_last,
-               (const uint32_t *)c->d_ye, m, c->d_bwlast, c->d_bwsai, W, rowid);
+               (const tpos_t *)c->d_ye, m, c->d_bwlast, c->d_bwsai, W, rowid);
     // ilist: rows grouped by word, ascending inside a word (:452-462) = stable sort of row ids by word
     BitRange wr = {0, bits_for(c->dwords)};
     uint32_t *sw, *sr;
@@ -624,7 +635,7 @@ int pfp_parse_bwt_get(pfp_ctx *c, uint8_t *bwlast, void *ilist, void *bwsai)
     const bool u64 = (c->flags & PFP_FLAG_U64) != 0;
     if (bwlast) PFP_HIP(c, hipMemcpy(bwlast, c->d_bwlast, c->nrows, hipMemcpyDeviceToHost));
     PFP_TRY(get_u32_as(c, c->d_ilist, c->nrows, ilist, u64));
-    if (bwsai) { if (!c->d_bwsai) return PFP_E_STATE; PFP_TRY(get_u32_as(c, c->d_bwsai, c->nrows, bwsai, u64)); }
+    if (bwsai) { if (!c->d_bwsai) return PFP_E_STATE; PFP_TRY(get_u64_as(c, c->d_bwsai, c->nrows, bwsai, u64)); }
     return PFP_OK;
 }
 
@@ -661,7 +672,15 @@ int pfp_bwt_load(pfp_ctx *c, const uint8_t *dict, uint64_t dsize, const void *oc
     PFP_HIP(c, hipMemcpy(c->d_bwlast, bwlast, nrows, hipMemcpyHostToDevice));
     PFP_TRY(upload_u32_from(c, occ, dwords, u64, c->d_occ));
     PFP_TRY(upload_u32_from(c, ilist, nrows, u64, c->d_ilist));
-    if (bwsai) { PFP_ALLOC_LO(c, c->d_bwsai, uint32_t, nrows); PFP_TRY(upload_u32_from(c, bwsai, nrows, u64, c->d_bwsai)); }
+    if (bwsai) {
+        PFP_ALLOC_LO(c, c->d_bwsai, tpos_t, nrows);
+        if (u64) PFP_HIP(c, hipMemcpy(c->d_bwsai, bwsai, nrows * 8, hipMemcpyHostToDevice));
+        else {
+            std::vector<uint64_t> tmp((size_t)nrows);
+            for (uint64_t i = 0; i < nrows; ++i) tmp[(size_t)i] = ((const uint32_t *)bwsai)[i];
+            PFP_HIP(c, hipMemcpy(c->d_bwsai, tmp.data(), nrows * 8, hipMemcpyHostToDevice));
+        }
+    }
     // word index of every dictionary offset = number of EndOfWord bytes before it (dict_idx.rank, pfbwt.hpp:83-85)
     const size_t mk = c->arena.mark_hi();
     uint32_t *flag, *d_cnt;

@@ -36,7 +36,7 @@ class ShardView(C.Structure):
 
     def nbytes(self):
         """byte sizes of the five device arrays, in field order"""
-        return [self.dsize, 4 * (self.dwords + 1), 4 * self.m, 4 * self.m, self.m]
+        return [self.dsize, 4 * (self.dwords + 1), 4 * self.m, 8 * self.m, self.m]
 
 
 _libs = {}
