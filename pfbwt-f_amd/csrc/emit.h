@@ -86,7 +86,7 @@ struct EmitArgs {
     const uint2 *posinfo;
     const uint4 *winfo;     // per word id: { first byte, offset of its EndOfWord, first ilist index F[rank], occ[rank] }
     const uint8_t *bwlast;
-    const uint32_t *EB;     // exclusive scan of cnt over slots
+    const void *EB;         // exclusive scan of the per-slot row counts: uint32_t, or uint64_t when n+1 >= 2^32 (template EBT)
     const uint32_t *s_sl;   // per slot: suffix length
     const uint32_t *s_fb;   // per slot: first ilist index of the slot's word (F[rank])
     const uint8_t *s_fl;    // per slot: SF_* flags
@@ -117,10 +117,17 @@ __global__ __launch_bounds__(BLOCK) void k_pack_posinfo(const uint8_t *D, const 
 
 __device__ __forceinline__ uint32_t word_rank_of(const EmitArgs &a, uint32_t id) { return a.wrank ? a.wrank[id] : id; }
 
+template <typename T> __device__ __forceinline__ uint32_t upper_bound_t(const T *a, uint32_t n, T x)
+{   // first index with a[idx] > x
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) { uint32_t mid = lo + ((hi - lo) >> 1); if (a[mid] <= x) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
 // Per suffix-array slot (the random gathers happen here, once per slot, not once per output row):
 // cnt = rows produced (occ of the word if suff_len > w, pfbwt.hpp:114), suffix length, ilist base,
 // preceding byte, whole-word flag (pfbwt.hpp:116), multi-word-group flag (pfbwt.hpp:137).
-__global__ __launch_bounds__(BLOCK) void k_emit_slots(EmitArgs a, uint32_t *cnt, unsigned long long *hard_rows, uint32_t *s_sl, uint32_t *s_fb, uint8_t *s_fl, uint8_t *s_pc)
+template <typename EBT> __global__ __launch_bounds__(BLOCK) void k_emit_slots(EmitArgs a, EBT *cnt, unsigned long long *hard_rows, uint32_t *s_sl, uint32_t *s_fb, uint8_t *s_fl, uint8_t *s_pc)
 {
     __shared__ uint8_t hd[BLOCK + 1];
     __shared__ uint32_t red[4];   // is slot (block base + t) the head of its class of equal suffixes
@@ -147,7 +154,7 @@ __global__ __launch_bounds__(BLOCK) void k_emit_slots(EmitArgs a, uint32_t *cnt,
             else { pc = dict_byte4(P.x >> 28); if (pc == Dollar && x - 1 == wsid) pc = 0; }   // pfbwt.hpp:132 "gsa[i]-1 ? dict[..] : 0"
         }
     }
-    if (valid) { cnt[i] = c; s_sl[i] = sl; s_fb[i] = fb; s_fl[i] = fl; s_pc[i] = pc; }
+    if (valid) { cnt[i] = (EBT)c; s_sl[i] = sl; s_fb[i] = fb; s_fl[i] = fl; s_pc[i] = pc; }
     uint32_t tot;   // rows that sit in multi-word groups (the reference's "hard" bookkeeping, pfbwt.hpp:188)
     (void)block_excl_sum((fl & SF_MULTI) ? c : 0u, red, &tot);
     if (threadIdx.x == 0 && tot) atomicAdd(hard_rows, (unsigned long long)tot);
@@ -165,7 +172,7 @@ __device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t *a, uint32_t 
 // The reference's loop starts at the FIRST member: if that one is a whole word it is emitted alone
 // (:116-128) and the rest forms its own group; otherwise all members are merged by ilist position and a
 // whole-word member contributes dict[gsa-1] == EndOfWord as its BWT byte (:140).
-__device__ __forceinline__ uint64_t multi_group_pos(const EmitArgs &a, uint32_t i, uint32_t r, uint32_t q, bool self_full, bool *full_emits_eow)
+template <typename EBT> __device__ __forceinline__ uint64_t multi_group_pos(const EmitArgs &a, uint32_t i, uint32_t r, uint32_t q, bool self_full, bool *full_emits_eow)
 {
     const uint2 P = a.posinfo[a.SA[i]];
     const uint32_t g0 = P.y;
@@ -185,7 +192,7 @@ __device__ __forceinline__ uint64_t multi_group_pos(const EmitArgs &a, uint32_t 
         before += lb;
         if (rs < first_rk) { first_rk = rs; first_before = lb; first_occ = oc; first_full = (xs == Ws.x); }
     }
-    const uint64_t gb = a.EB[g0];
+    const uint64_t gb = reinterpret_cast<const EBT *>(a.EB)[g0];
     *full_emits_eow = false;
     if (first_full) return (first_rk == rk) ? gb + r : gb + first_occ + (before - first_before) + r;
     *full_emits_eow = self_full;
@@ -199,37 +206,38 @@ constexpr int EMIT_PER_THREAD = 8;
 constexpr int EMIT_TILE = BLOCK * EMIT_PER_THREAD;
 constexpr int EMIT_LDS_SLOTS = 4096;
 
-template <typename SAT> __global__ __launch_bounds__(BLOCK) void k_emit(EmitArgs a, uint8_t *bwt, SAT *sa)
+template <typename SAT, typename EBT> __global__ __launch_bounds__(BLOCK) void k_emit(EmitArgs a, uint8_t *bwt, SAT *sa)
 {
-    __shared__ uint32_t eb[EMIT_LDS_SLOTS];
+    __shared__ EBT eb[EMIT_LDS_SLOTS];
+    const EBT *EB = reinterpret_cast<const EBT *>(a.EB);
     __shared__ uint32_t range[2];
     const uint64_t o0 = a.e0 + (uint64_t)blockIdx.x * EMIT_TILE;
     const uint64_t o1 = (o0 + EMIT_TILE < a.e1) ? o0 + EMIT_TILE : a.e1;   // exclusive
     if (threadIdx.x < 2) {
         const uint64_t o = threadIdx.x == 0 ? o0 : o1 - 1;
-        range[threadIdx.x] = upper_bound_u32(a.EB, (uint32_t)a.dsize, (uint32_t)o) - 1u;   // last slot with EB <= o
+        range[threadIdx.x] = upper_bound_t<EBT>(EB, (uint32_t)a.dsize, (EBT)o) - 1u;   // last slot with EB <= o
     }
     __syncthreads();
     const uint32_t i0 = range[0], i1 = range[1];
     const uint32_t ns = i1 - i0 + 1u;
     const bool in_lds = ns <= (uint32_t)EMIT_LDS_SLOTS;
-    if (in_lds) for (uint32_t k = threadIdx.x; k < ns; k += BLOCK) eb[k] = a.EB[i0 + k];
+    if (in_lds) for (uint32_t k = threadIdx.x; k < ns; k += BLOCK) eb[k] = EB[i0 + k];
     __syncthreads();
 #pragma unroll 1
     for (int k = 0; k < EMIT_PER_THREAD; ++k) {
         const uint64_t o = o0 + (uint64_t)k * BLOCK + threadIdx.x;
         if (o >= o1) break;
         uint32_t i;
-        if (in_lds) i = i0 + upper_bound_u32(eb, ns, (uint32_t)o) - 1u;
-        else i = upper_bound_u32(a.EB, (uint32_t)a.dsize, (uint32_t)o) - 1u;
-        const uint32_t r = (uint32_t)o - (in_lds ? eb[i - i0] : a.EB[i]);
+        if (in_lds) i = i0 + upper_bound_t<EBT>(eb, ns, (EBT)o) - 1u;
+        else i = upper_bound_t<EBT>(EB, (uint32_t)a.dsize, (EBT)o) - 1u;
+        const uint32_t r = (uint32_t)(o - (uint64_t)(in_lds ? eb[i - i0] : EB[i]));
         const uint8_t fl = a.s_fl[i];
         const uint32_t sl = a.s_sl[i];                             // suff_len, pfbwt.hpp:83-85
         const uint32_t q = a.ilist[a.s_fb[i] + r];                 // parse-BWT row of this occurrence
         const bool self_full = (fl & SF_FULL) != 0;
         uint64_t pos = o;
         bool full_emits_eow = false;
-        if (fl & SF_MULTI) pos = multi_group_pos(a, i, r, q, self_full, &full_emits_eow);
+        if (fl & SF_MULTI) pos = multi_group_pos<EBT>(a, i, r, q, self_full, &full_emits_eow);
         const uint8_t c = self_full ? (full_emits_eow ? (uint8_t)EndOfWord : a.bwlast[q]) : a.s_pc[i];   // pfbwt.hpp:116-128 / :132
         if (pos < a.w0 || pos >= a.w1) continue;                    // row of a boundary group that lands in another slice
         bwt[pos - a.w0] = c;
@@ -241,26 +249,29 @@ template <typename SAT> __global__ __launch_bounds__(BLOCK) void k_emit(EmitArgs
     }
 }
 
-// run starts: bwt[o] != bwt[o-1] (pbwtc starts at 0, src/pfbwt-f.cpp:304)
-__global__ __launch_bounds__(BLOCK) void k_run_flags(const uint8_t *bwt, uint64_t nout, uint32_t *flag)
-{
-    const uint64_t o = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (o < nout) flag[o] = bwt[o] != (o ? bwt[o - 1] : (uint8_t)0) ? 1u : 0u;
-}
-// Multi-GPU slices: a slice owns output rows [w0', w1); rows of a group of equal suffixes that straddles a slice
-// boundary are enumerated by both neighbours, each keeps what lands in its window.  out[0] = first enumeration row
-// (start of the group containing row lo), out[1] = end of the group containing row hi-1.
-__global__ __launch_bounds__(BLOCK) void k_slice_bounds(EmitArgs a, uint64_t lo, uint64_t hi, unsigned long long *out)
+// Windows of output rows (multi-GPU slices, chunks of a huge text): a window owns output positions [lo, hi); rows of
+// a group of equal suffixes that straddles a window boundary are enumerated for both neighbours, each keeps what lands
+// in its window.  out[0] = first enumeration row (start of the group containing row lo), out[1] = end of the group
+// containing row hi-1.
+template <typename EBT> __global__ __launch_bounds__(BLOCK) void k_slice_bounds(EmitArgs a, uint64_t lo, uint64_t hi, unsigned long long *out)
 {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    const uint32_t il = upper_bound_u32(a.EB, (uint32_t)a.dsize, (uint32_t)lo) - 1u;
-    out[0] = a.EB[a.posinfo[a.SA[il]].y];
+    const EBT *EB = reinterpret_cast<const EBT *>(a.EB);
+    const uint32_t il = upper_bound_t<EBT>(EB, (uint32_t)a.dsize, (EBT)lo) - 1u;
+    out[0] = EB[a.posinfo[a.SA[il]].y];
     if (hi >= a.nout) { out[1] = a.nout; return; }
-    uint32_t s = upper_bound_u32(a.EB, (uint32_t)a.dsize, (uint32_t)(hi - 1)) - 1u;
+    uint32_t s = upper_bound_t<EBT>(EB, (uint32_t)a.dsize, (EBT)(hi - 1)) - 1u;
     const uint32_t g = a.posinfo[a.SA[s]].y;
     while (s < a.dsize && a.posinfo[a.SA[s]].y == g) ++s;
-    while (s < a.dsize && a.EB[s] < hi) ++s;               // slots that produce no rows keep EB unchanged
-    out[1] = s < a.dsize ? a.EB[s] : a.nout;
+    while (s < a.dsize && (uint64_t)EB[s] < hi) ++s;       // slots that produce no rows keep EB unchanged
+    out[1] = s < a.dsize ? (uint64_t)EB[s] : a.nout;
+}
+// run starts inside a window of rows: flag[j] for row (first + j); bwt points at that first row and has_prev says
+// whether bwt[-1] holds the row in front of it (pbwtc starts at 0, src/pfbwt-f.cpp:304)
+__global__ __launch_bounds__(BLOCK) void k_run_flags(const uint8_t *bwt, uint64_t rows, int has_prev, uint32_t *flag)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (j < rows) flag[j] = bwt[j] != ((j || has_prev) ? *(bwt + j - 1) : (uint8_t)0) ? 1u : 0u;
 }
 // run count only (no samples wanted): workgroup reduction + one atomic per workgroup.  `bwt` points at the first
 // row to count; has_prev says whether bwt[-1] holds the row in front of it (slices > 0).
@@ -277,18 +288,20 @@ __global__ __launch_bounds__(BLOCK) void k_run_count(const uint8_t *bwt, uint64_
     (void)block_excl_sum(cntr, red, &tot);
     if (threadIdx.x == 0 && tot) atomicAdd(runs, (unsigned long long)tot);
 }
-// .ssa / .esa pairs, src/pfbwt-f.cpp:306-315 and :325-328
-template <typename SAT> __global__ __launch_bounds__(BLOCK) void k_samples(const uint32_t *flag, const uint32_t *runidx, const SAT *sa, uint64_t nout, uint64_t runs,
-                                                                           SAT *ssa, SAT *esa)
+// .ssa / .esa pairs, src/pfbwt-f.cpp:306-315 and :325-328, for a window of rows: row index = row_base + j, sa[j]
+// (sa[-1] valid when has_prev), run index = run_base + runidx[j]; total_rows / total_runs describe the whole output.
+template <typename SAT> __global__ __launch_bounds__(BLOCK) void k_samples(const uint32_t *flag, const uint32_t *runidx, const SAT *sa, uint64_t rows, uint64_t row_base, uint64_t run_base,
+                                                                           uint64_t total_rows, uint64_t total_runs, SAT *ssa, SAT *esa)
 {
-    const uint64_t o = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (o >= nout) return;
-    if (flag[o]) {
-        const uint64_t k = runidx[o];
-        ssa[2 * k] = (SAT)o; ssa[2 * k + 1] = sa[o];
-        if (o) { esa[2 * (k - 1)] = (SAT)(o - 1); esa[2 * (k - 1) + 1] = sa[o - 1]; }
+    const uint64_t j = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (j >= rows) return;
+    const uint64_t o = row_base + j;
+    if (flag[j]) {
+        const uint64_t k = run_base + runidx[j];
+        ssa[2 * k] = (SAT)o; ssa[2 * k + 1] = sa[j];
+        if (o) { esa[2 * (k - 1)] = (SAT)(o - 1); esa[2 * (k - 1) + 1] = *(sa + j - 1); }
     }
-    if (o + 1 == nout && runs) { esa[2 * (runs - 1)] = (SAT)o; esa[2 * (runs - 1) + 1] = sa[o]; }
+    if (o + 1 == total_rows && total_runs) { esa[2 * (total_runs - 1)] = (SAT)o; esa[2 * (total_runs - 1) + 1] = sa[j]; }
 }
 
 } // namespace pfp

@@ -65,7 +65,7 @@ __device__ __forceinline__ uint32_t pack16(const uint4 &q, bool ntoa, uint32_t *
 // 16-bit trigger mask per thread and the trigger count of the workgroup.
 // X must be 16-byte aligned with capacity rounded up to the grid; positions >= n are ignored.
 __global__ __launch_bounds__(BLOCK) void k_trigger_scan(uint8_t *X, uint64_t n, int w, uint64_t p, uint64_t kmask, int ntoa,
-                                                        uint16_t *mask16, uint32_t *blockcnt, unsigned long long *err_pos)
+                                                        uint16_t *mask16, uint64_t *blockcnt, unsigned long long *err_pos)
 {
     __shared__ uint32_t pk[BLOCK + 2];
     __shared__ uint32_t red[4];
@@ -111,16 +111,16 @@ __global__ __launch_bounds__(BLOCK) void k_trigger_scan(uint8_t *X, uint64_t n, 
     mask16[t] = (uint16_t)trig;
     uint32_t tot;
     (void)block_excl_sum((uint32_t)__popc(trig), red, &tot);
-    if (threadIdx.x == 0) blockcnt[blockIdx.x] = tot;
+    if (threadIdx.x == 0) blockcnt[blockIdx.x] = tot;   // 64-bit: the scan over workgroups yields phrase indices
 }
 
 // ye[j] = (trigger position e_j) + 1 for every trigger, in text order
-__global__ __launch_bounds__(BLOCK) void k_phrase_ends(const uint16_t *mask16, const uint32_t *blockoff, tpos_t *ye)
+__global__ __launch_bounds__(BLOCK) void k_phrase_ends(const uint16_t *mask16, const uint64_t *blockoff, tpos_t *ye)
 {
     __shared__ uint32_t red[4];
     const uint64_t t = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     uint32_t m = mask16[t], tot;
-    uint32_t o = blockoff[blockIdx.x] + block_excl_sum((uint32_t)__popc(m), red, &tot);
+    uint64_t o = blockoff[blockIdx.x] + block_excl_sum((uint32_t)__popc(m), red, &tot);
     while (m) { int b = __ffs((int)m) - 1; m &= m - 1; ye[o++] = (tpos_t)(t * 16 + b + 1); }
 }
 

@@ -150,7 +150,8 @@ static int feed_common(pfp_ctx *c, const void *src, uint64_t len, int end_of_seq
     PFP_HIP(c, hipSetDevice(c->device));
     if (c->stage != 0) reset_results(c);
     const uint64_t add = len + (end_of_seq ? (uint64_t)c->w : 0);
-    if (c->n + add + (uint64_t)c->w + 64 >= 0xFFFFFFFFULL) return PFP_E_TOO_LARGE;   // pfparser.hpp:326-331
+    // pfparser.hpp:326-331: the 32-bit build stops at 2^32 bases; the 64-bit build here at 2^40 (device positions are 64-bit)
+    if (c->n + add + (uint64_t)c->w + 64 >= ((c->flags & PFP_FLAG_U64) ? (1ULL << 40) : 0xFFFFFFFFULL)) return PFP_E_TOO_LARGE;
     PFP_TRY(ensure_text(c, c->n + add + (uint64_t)c->w));
     if (len) PFP_HIP(c, hipMemcpyAsync(c->tb + 16 + c->n, src, (size_t)len, kind, c->stream));
     c->n += len;
@@ -349,29 +350,31 @@ int pfp_parse_finalize(pfp_ctx *c, pfp_parse_sizes *out)
 
     // 1. trigger scan
     const unsigned gts = nblocks(n, 16 * BLOCK);
-    uint16_t *mask16; uint32_t *blockcnt, *d_u32; unsigned long long *d_err;
+    uint16_t *mask16; uint64_t *blockcnt; uint32_t *d_u32; unsigned long long *d_err;
     PFP_ALLOC_HI(c, mask16, uint16_t, (size_t)gts * BLOCK);
-    PFP_ALLOC_HI(c, blockcnt, uint32_t, gts);
+    PFP_ALLOC_HI(c, blockcnt, uint64_t, (size_t)gts + 1);
     PFP_ALLOC_HI(c, d_u32, uint32_t, 8);
     PFP_ALLOC_HI(c, d_err, unsigned long long, 1);
     PFP_HIP(c, hipMemsetAsync(d_err, 0xff, 8, c->stream));
     PFP_HIP(c, hipMemsetAsync(d_u32, 0, 32, c->stream));
     const uint64_t kmask = (w == 32) ? 0ULL : ((1ULL << (2 * w)) - 1ULL);   // hash.hpp:26 (w == 32: observed x86 value)
     PFP_LAUNCH(c, K_TRIGGER_SCAN, n * 2 + n / 8, k_trigger_scan, gts, X, n, w, c->p, kmask, (int)((c->flags & PFP_FLAG_NON_ACGT_TO_A) != 0), mask16, blockcnt, d_err);
-    PFP_TRY((device_scan<uint32_t, 0>(c, blockcnt, blockcnt, gts, d_u32)));
-    uint32_t ntrig = 0; unsigned long long herr = 0;
+    PFP_TRY((device_scan<uint64_t, 0>(c, blockcnt, blockcnt, gts, blockcnt + gts)));
+    uint64_t ntrig = 0; unsigned long long herr = 0;
     PFP_HIP(c, hipMemcpyAsync(&herr, d_err, 8, hipMemcpyDeviceToHost, c->stream));
-    PFP_TRY(d2h_u32(c, d_u32, &ntrig));
+    PFP_HIP(c, hipMemcpyAsync(&ntrig, blockcnt + gts, 8, hipMemcpyDeviceToHost, c->stream));
+    PFP_HIP(c, hipStreamSynchronize(c->stream));
     if (herr != ~0ULL) {   // hash.hpp:31
         uint8_t ch = 0;
         PFP_HIP(c, hipMemcpy(&ch, X + herr, 1, hipMemcpyDeviceToHost));
         c->err_pos = herr; c->err_ch = ch;
         return PFP_E_INVALID_CHAR;
     }
-    const uint64_t m = (uint64_t)ntrig + 1;
+    const uint64_t m = ntrig + 1;
+    if (m > 0xFFFFFFFEULL - 64) return PFP_E_TOO_LARGE;       // pfparser.hpp:399-404: more than 2^32-2 phrases is a hard limit of the reference too
     c->m = m;
     PFP_ALLOC_LO(c, c->d_ye, tpos_t, m);
-    PFP_LAUNCH(c, K_PHRASE_ENDS, n / 8 + m * 4, k_phrase_ends, gts, (const uint16_t *)mask16, (const uint32_t *)blockcnt, c->d_ye);
+    PFP_LAUNCH(c, K_PHRASE_ENDS, n / 8 + m * 4, k_phrase_ends, gts, (const uint16_t *)mask16, (const uint64_t *)blockcnt, c->d_ye);
     PFP_LAUNCH(c, K_MISC, 8, k_set_u64, 1, c->d_ye, m - 1, (uint64_t)(n + (uint64_t)w));
 
     // 2. distinct phrases, dictionary
@@ -452,7 +455,7 @@ int pfp_merge_shards(pfp_ctx *c, int nshards, const pfp_shard_view *v, pfp_parse
         if (v[r].m < 2 || v[r].n < (r ? w + 1 : 1) || !v[r].d_dict || !v[r].d_ws || !v[r].d_pid || !v[r].d_ye || !v[r].d_last) return PFP_E_ARG;
         ntot += v[r].n - (r ? w : 0); mtot += v[r].m - (r ? 1 : 0); dtot += v[r].dsize; ctot += v[r].dwords;
     }
-    if (ntot + w + 64 >= 0xFFFFFFFFULL || dtot + ntot / 8 + 64 >= 0xFFFFFFFFULL) return PFP_E_TOO_LARGE;
+    if (ntot + w + 64 >= ((c->flags & PFP_FLAG_U64) ? (1ULL << 40) : 0xFFFFFFFFULL) || dtot + 64 >= 0xFFFFFFFFULL || mtot > 0xFFFFFFFEULL - 64) return PFP_E_TOO_LARGE;
     reset_results(c);
     PFP_TRY(ensure_arena(c, ntot + dtot));
     c->arena.reset();
@@ -698,53 +701,114 @@ int pfp_bwt_load(pfp_ctx *c, const uint8_t *dict, uint64_t dsize, const void *oc
 }
 
 extern "C++" {
-template <typename SAT> static int emit_and_sample(pfp_ctx *c, EmitArgs ea, bool want_sa, bool want_rssa, int slice, int nslices)
+// Emission of the rows [s0, s1) of this slice (all rows when nslices == 1), in windows of at most `chunk_rows` rows so
+// that the per-window scratch (run flags, SA values needed only at run boundaries) stays bounded for texts of tens of
+// Gbases.  Rows of a group of equal suffixes that straddles a window boundary are enumerated for both windows.
+template <typename SAT, typename EBT> static int emit_and_sample(pfp_ctx *c, EmitArgs ea, bool want_sa, bool want_rssa, int slice, int nslices)
 {
     const uint64_t total = ea.nout;
-    const bool any_sa = want_sa || want_rssa;
-    // output rows of this slice, plus the row in front of it (run detection needs its BWT byte)
-    const uint64_t s0 = total * (uint64_t)slice / (uint64_t)nslices, s1 = total * (uint64_t)(slice + 1) / (uint64_t)nslices;
-    const uint64_t lead = s0 ? 1 : 0;
-    const uint64_t nout = s1 - s0;
-    c->slice_begin = s0; c->slice_rows = nout;
-    uint8_t *bwtbuf; PFP_ALLOC_LO(c, bwtbuf, uint8_t, nout + lead + 16);
+    const uint64_t s0 = total / (uint64_t)nslices * (uint64_t)slice + (total % (uint64_t)nslices) * (uint64_t)slice / (uint64_t)nslices;
+    const uint64_t s1 = slice + 1 == nslices ? total : total / (uint64_t)nslices * (uint64_t)(slice + 1) + (total % (uint64_t)nslices) * (uint64_t)(slice + 1) / (uint64_t)nslices;
+    const uint64_t lead = s0 ? 1 : 0;                     // the row in front of the slice (run detection needs its BWT byte)
+    const uint64_t nrows = s1 - s0;
+    c->slice_begin = s0; c->slice_rows = nrows;
+    static uint64_t chunk_rows = 0;
+    if (!chunk_rows) { const char *e = getenv("PFP_EMIT_CHUNK_ROWS"); chunk_rows = (e && atoll(e) > 0) ? (uint64_t)atoll(e) : (1ULL << 30); }
+    const uint64_t nchunks = (nrows + chunk_rows - 1) / chunk_rows;
+    const bool windowed = nslices > 1 || nchunks > 1;
+    uint8_t *bwtbuf; PFP_ALLOC_LO(c, bwtbuf, uint8_t, nrows + lead + 16);
     c->d_bwt = bwtbuf + lead;
-    SAT *sabuf = nullptr, *sa = nullptr;
-    if (any_sa) { PFP_ALLOC_LO(c, sabuf, SAT, nout + lead); sa = sabuf + lead; }
-    c->d_sa = sa;
-    ea.w0 = s0 - lead; ea.w1 = s1; ea.e0 = 0; ea.e1 = total;
-    if (nslices > 1) {
-        unsigned long long *d_b; PFP_ALLOC_HI(c, d_b, unsigned long long, 2);
-        PFP_LAUNCH(c, K_MISC, 64, k_slice_bounds, 1, ea, ea.w0, ea.w1, d_b);
-        unsigned long long hb[2];
-        PFP_HIP(c, hipMemcpyAsync(hb, d_b, 16, hipMemcpyDeviceToHost, c->stream));
-        PFP_HIP(c, hipStreamSynchronize(c->stream));
-        ea.e0 = hb[0]; ea.e1 = hb[1];
-    }
-    PFP_LAUNCH(c, K_EMIT, nout * (1 + (any_sa ? sizeof(SAT) : 0)) + c->nrows * 9 + c->dsize * 9, (k_emit<SAT>), nblocks(ea.e1 - ea.e0, EMIT_TILE), ea, bwtbuf, sabuf);
-    // runs (src/pfbwt-f.cpp:304-305); the samples need the index of every run start, the count alone does not
+    const bool keep_sa = want_sa || (want_rssa && nchunks == 1);   // a full SA array for this slice lives in the arena
+    SAT *sabuf = nullptr;
+    if (keep_sa) PFP_ALLOC_LO(c, sabuf, SAT, nrows + lead);
+    c->d_sa = sabuf ? sabuf + lead : nullptr;
     c->d_ssa = c->d_esa = nullptr;
-    if (!want_rssa) {
-        unsigned long long *d_runs; PFP_ALLOC_HI(c, d_runs, unsigned long long, 1);
+    unsigned long long *d_b; PFP_ALLOC_HI(c, d_b, unsigned long long, 4);
+    // emits the rows whose output position lies in [w0, w1); bwt_at / sa_at point at position w0
+    auto emit_window = [&](uint64_t w0, uint64_t w1, uint8_t *bwt_at, SAT *sa_at) -> int {
+        ea.w0 = w0; ea.w1 = w1; ea.e0 = 0; ea.e1 = total;
+        if (windowed) {
+            PFP_LAUNCH(c, K_MISC, 64, (k_slice_bounds<EBT>), 1, ea, w0, w1, d_b);
+            unsigned long long hb[2];
+            PFP_HIP(c, hipMemcpyAsync(hb, d_b, 16, hipMemcpyDeviceToHost, c->stream));
+            PFP_HIP(c, hipStreamSynchronize(c->stream));
+            ea.e0 = hb[0]; ea.e1 = hb[1];
+        }
+        const uint64_t rows = w1 - w0;
+        PFP_LAUNCH(c, K_EMIT, rows * (1 + (sa_at ? sizeof(SAT) : 0)) + rows * 18, (k_emit<SAT, EBT>), nblocks(ea.e1 - ea.e0, EMIT_TILE), ea, bwt_at, sa_at);
+        return PFP_OK;
+    };
+    // pass 1: BWT bytes (and SA values if a full SA is kept)
+    for (uint64_t ch = 0; ch < nchunks; ++ch) {
+        const uint64_t cs = s0 + ch * chunk_rows, ce = (cs + chunk_rows < s1) ? cs + chunk_rows : s1;
+        const uint64_t cl = cs ? 1 : 0;
+        PFP_TRY(emit_window(cs - cl, ce, bwtbuf + (cs - cl - (s0 - lead)), sabuf ? sabuf + (cs - cl - (s0 - lead)) : (SAT *)nullptr));
+    }
+    // runs (src/pfbwt-f.cpp:304-305): runs that start in this slice
+    {
+        unsigned long long *d_runs = d_b + 2;
         PFP_HIP(c, hipMemsetAsync(d_runs, 0, 8, c->stream));
-        PFP_LAUNCH(c, K_RUNS, nout, k_run_count, nblocks(nout, 16 * BLOCK), (const uint8_t *)c->d_bwt, nout, (int)lead, d_runs);
+        PFP_LAUNCH(c, K_RUNS, nrows, k_run_count, nblocks(nrows, 16 * BLOCK), (const uint8_t *)c->d_bwt, nrows, (int)lead, d_runs);
         unsigned long long r = 0;
         PFP_HIP(c, hipMemcpyAsync(&r, d_runs, 8, hipMemcpyDeviceToHost, c->stream));
         PFP_HIP(c, hipStreamSynchronize(c->stream));
         c->runs = r;
-    } else {
-        uint32_t *flag, *ridx, *d_cnt;
-        PFP_ALLOC_HI(c, flag, uint32_t, nout); PFP_ALLOC_HI(c, ridx, uint32_t, nout); PFP_ALLOC_HI(c, d_cnt, uint32_t, 1);
-        PFP_LAUNCH(c, K_RUNS, nout * 5, k_run_flags, nblocks(nout, BLOCK), (const uint8_t *)c->d_bwt, nout, flag);
-        PFP_TRY((device_scan<uint32_t, 0>(c, flag, ridx, nout, d_cnt)));
-        uint32_t r = 0; PFP_TRY(d2h_u32(c, d_cnt, &r));
-        c->runs = r;
+    }
+    if (want_rssa) {   // .ssa / .esa samples (pfbwt-f.cpp:306-315, 325-328); only with nslices == 1
+        const uint64_t r = c->runs;
         SAT *ssa, *esa;
-        PFP_ALLOC_LO(c, ssa, SAT, 2 * (uint64_t)r); PFP_ALLOC_LO(c, esa, SAT, 2 * (uint64_t)r);
-        PFP_LAUNCH(c, K_SAMPLES, nout * 8 + (uint64_t)r * 4 * sizeof(SAT), (k_samples<SAT>), nblocks(nout, BLOCK), (const uint32_t *)flag, (const uint32_t *)ridx, (const SAT *)sa, nout, (uint64_t)r, ssa, esa);
+        PFP_ALLOC_LO(c, ssa, SAT, 2 * r); PFP_ALLOC_LO(c, esa, SAT, 2 * r);
         c->d_ssa = ssa; c->d_esa = esa;
+        const uint64_t maxrows = nchunks == 1 ? nrows : chunk_rows;
+        uint32_t *flag, *ridx, *d_cnt; SAT *satmp = nullptr;
+        PFP_ALLOC_HI(c, flag, uint32_t, maxrows); PFP_ALLOC_HI(c, ridx, uint32_t, maxrows); PFP_ALLOC_HI(c, d_cnt, uint32_t, 1);
+        if (!sabuf) PFP_ALLOC_HI(c, satmp, SAT, maxrows + 1);
+        uint64_t run_base = 0;
+        for (uint64_t ch = 0; ch < nchunks; ++ch) {
+            const uint64_t cs = s0 + ch * chunk_rows, ce = (cs + chunk_rows < s1) ? cs + chunk_rows : s1, rows = ce - cs;
+            const uint64_t cl = cs ? 1 : 0;
+            uint8_t *bw = bwtbuf + (cs - (s0 - lead));                       // first row of the chunk
+            const SAT *sa_first;
+            if (sabuf) sa_first = sabuf + (cs - (s0 - lead));
+            else {   // pass 2 of this window: the same rows again, now with their SA values
+                PFP_TRY(emit_window(cs - cl, ce, bw - cl, satmp));
+                sa_first = satmp + cl;
+            }
+            PFP_LAUNCH(c, K_RUNS, rows * 5, k_run_flags, nblocks(rows, BLOCK), (const uint8_t *)bw, rows, (int)cl, flag);
+            PFP_TRY((device_scan<uint32_t, 0>(c, flag, ridx, rows, d_cnt)));
+            uint32_t rc = 0; PFP_TRY(d2h_u32(c, d_cnt, &rc));
+            PFP_LAUNCH(c, K_SAMPLES, rows * 8 + (uint64_t)rc * 4 * sizeof(SAT), (k_samples<SAT>), nblocks(rows, BLOCK), (const uint32_t *)flag, (const uint32_t *)ridx, sa_first, rows, cs, run_base,
+                       total, r, ssa, esa);
+            run_base += rc;
+        }
+        if (run_base != r) return PFP_E_CORRUPT;
     }
     return PFP_OK;
+}
+
+// everything of stage 2 that depends on the width of the row counter (EBT = uint32_t while n + 1 < 2^32)
+template <typename EBT> static int emit_stage(pfp_ctx *c, EmitArgs ea, int want_sa, int want_rssa, int slice, int nslices)
+{
+    const uint64_t dsize = c->dsize;
+    EBT *cnt, *EB, *d_tot; unsigned long long *d_hard;
+    PFP_ALLOC_HI(c, cnt, EBT, dsize); PFP_ALLOC_HI(c, EB, EBT, dsize); PFP_ALLOC_HI(c, d_hard, unsigned long long, 2); PFP_ALLOC_HI(c, d_tot, EBT, 2);
+    PFP_HIP(c, hipMemsetAsync(d_hard, 0, 16, c->stream));
+    ea.EB = EB;
+    PFP_LAUNCH(c, K_EMIT_COUNT, dsize * (30 + sizeof(EBT)), (k_emit_slots<EBT>), nblocks(dsize, BLOCK), ea, cnt, d_hard, (uint32_t *)ea.s_sl, (uint32_t *)ea.s_fb, (uint8_t *)ea.s_fl, (uint8_t *)ea.s_pc);
+    PFP_TRY((device_scan<EBT, 0>(c, cnt, EB, dsize, d_tot)));
+    EBT tot = 0; unsigned long long hardrows = 0;
+    PFP_HIP(c, hipMemcpyAsync(&hardrows, d_hard, 8, hipMemcpyDeviceToHost, c->stream));
+    PFP_HIP(c, hipMemcpyAsync(&tot, d_tot, sizeof(EBT), hipMemcpyDeviceToHost, c->stream));
+    PFP_HIP(c, hipStreamSynchronize(c->stream));
+    const uint64_t nout = tot;
+    if (nout < 2) return PFP_E_CORRUPT;
+    if (c->n && nout != c->n + 1) return PFP_E_CORRUPT;         // emission must produce exactly n+1 rows
+    if (!c->n) c->n = nout - 1;
+    ea.nout = nout; ea.n = c->n;
+    c->nout = nout; c->hard = hardrows; c->easy = nout - hardrows;
+    if (c->flags & PFP_FLAG_U64) return emit_and_sample<uint64_t, EBT>(c, ea, want_sa != 0, want_rssa != 0, slice, nslices);
+    if (nout > 0xFFFFFFFFULL) return PFP_E_TOO_LARGE;           // 32-bit uint_t cannot hold the SA values (pfparser.hpp:326-331)
+    return emit_and_sample<uint32_t, EBT>(c, ea, want_sa != 0, want_rssa != 0, slice, nslices);
 }
 } // extern "C++"
 
@@ -759,16 +823,13 @@ static int bwt_build_impl(pfp_ctx *c, int want_sa, int want_rssa, int slice, int
     const size_t mk = c->arena.mark_hi();
     if (!c->gsa_valid) { PFP_TRY(sort_dict_suffixes(c)); c->lo_after_pbwt = c->arena.mark_lo(); }   // gsacak, pfbwt.hpp:211
     const uint64_t dsize = c->dsize, dwords = c->dwords;
-    uint32_t *F, *cnt, *EB, *d_tot, *s_sl, *s_fb; uint8_t *s_fl, *s_pc; uint2 *posinfo; uint4 *winfo; unsigned long long *d_hard;
+    uint32_t *F, *s_sl, *s_fb; uint8_t *s_fl, *s_pc; uint2 *posinfo; uint4 *winfo;
     if (dwords > WID_MASK) return PFP_E_TOO_LARGE;
     PFP_ALLOC_HI(c, posinfo, uint2, dsize);
     PFP_LAUNCH(c, K_EMIT_COUNT, dsize * 17, k_pack_posinfo, nblocks(dsize, BLOCK), (const uint8_t *)c->d_dict, (const uint32_t *)c->d_wordid, (const uint2 *)c->d_grank, dsize, posinfo);
     PFP_ALLOC_HI(c, F, uint32_t, dwords + 1);
-    PFP_ALLOC_HI(c, cnt, uint32_t, dsize); PFP_ALLOC_HI(c, EB, uint32_t, dsize); PFP_ALLOC_HI(c, d_hard, unsigned long long, 2);
-    PFP_HIP(c, hipMemsetAsync(d_hard, 0, 16, c->stream));
     PFP_ALLOC_HI(c, s_sl, uint32_t, dsize); PFP_ALLOC_HI(c, s_fb, uint32_t, dsize);
     PFP_ALLOC_HI(c, s_fl, uint8_t, dsize); PFP_ALLOC_HI(c, s_pc, uint8_t, dsize);
-    PFP_ALLOC_HI(c, d_tot, uint32_t, 4);
     // F[r] = 1 + sum_{r' < r} occ[r']  (ilist[0] is the EOS row; pfbwt.hpp:259-268)
     PFP_TRY((device_scan<uint32_t, 0>(c, c->d_occ, F, dwords, nullptr)));
     PFP_LAUNCH(c, K_MISC, dwords * 8, k_u32_add_store, nblocks(dwords, BLOCK), (const uint32_t *)F, dwords, 1u, F);
@@ -779,28 +840,18 @@ static int bwt_build_impl(pfp_ctx *c, int want_sa, int want_rssa, int slice, int
     PFP_ALLOC_HI(c, winfo, uint4, dwords);
     PFP_LAUNCH(c, K_MISC, dwords * 32, k_pack_winfo, nblocks(dwords, BLOCK), (const uint32_t *)c->d_ws, (const uint32_t *)c->d_wrank, (const uint32_t *)c->d_occ, (const uint32_t *)F, dwords, winfo);
     ea.winfo = winfo;
-    ea.EB = EB; ea.s_sl = s_sl; ea.s_fb = s_fb; ea.s_fl = s_fl; ea.s_pc = s_pc; ea.nout = 0; ea.n = 0;
-    PFP_LAUNCH(c, K_EMIT_COUNT, dsize * 34, k_emit_slots, nblocks(dsize, BLOCK), ea, cnt, d_hard, s_sl, s_fb, s_fl, s_pc);
-    PFP_TRY((device_scan<uint32_t, 0>(c, cnt, EB, dsize, d_tot)));
-    uint32_t tot = 0; unsigned long long hardrows = 0;
-    PFP_HIP(c, hipMemcpyAsync(&hardrows, d_hard, 8, hipMemcpyDeviceToHost, c->stream));
-    PFP_TRY(d2h_u32(c, d_tot, &tot));
-    const uint64_t nout = tot;
-    if (nout < 2) return PFP_E_CORRUPT;
-    if (c->n && nout != c->n + 1) return PFP_E_CORRUPT;         // emission must produce exactly n+1 rows
-    if (!c->n) c->n = nout - 1;
-    ea.nout = nout; ea.n = c->n;
-    c->nout = nout; c->hard = hardrows; c->easy = nout - hardrows;
+    ea.EB = nullptr; ea.s_sl = s_sl; ea.s_fb = s_fb; ea.s_fl = s_fl; ea.s_pc = s_pc; ea.nout = 0; ea.n = 0; ea.e0 = ea.e1 = ea.w0 = ea.w1 = 0;
     c->have_sa = want_sa != 0; c->have_rssa = want_rssa != 0;
-    int rc;
-    if (c->flags & PFP_FLAG_U64) rc = emit_and_sample<uint64_t>(c, ea, want_sa != 0, want_rssa != 0, slice, nslices);
-    else rc = emit_and_sample<uint32_t>(c, ea, want_sa != 0, want_rssa != 0, slice, nslices);
+    // 64-bit row counters when the text may have 2^32 - 1 positions or more (n unknown after pfp_bwt_load without a hint)
+    static const bool force_wide = getenv("PFP_FORCE_WIDE_ROWS") != nullptr;
+    const bool wide = force_wide || c->n == 0 || c->n + 2 >= 0xFFFFFFFFULL;
+    int rc = wide ? emit_stage<uint64_t>(c, ea, want_sa, want_rssa, slice, nslices) : emit_stage<uint32_t>(c, ea, want_sa, want_rssa, slice, nslices);
     if (rc != PFP_OK) return rc;
     PFP_HIP(c, hipStreamSynchronize(c->stream));
     c->arena.release_hi(mk);
     c->stage = 3;
     c->stage_ms[2] = timer.ms();
-    if (out) { out->nout = nout; out->r = c->runs; out->easy_cases = c->easy; out->hard_cases = c->hard; }
+    if (out) { out->nout = c->nout; out->r = c->runs; out->easy_cases = c->easy; out->hard_cases = c->hard; }
     return PFP_OK;
 }
 

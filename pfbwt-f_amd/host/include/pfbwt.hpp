@@ -67,23 +67,25 @@ template <template <typename, typename...> class ReadConType, template <typename
     PrefixFreeBWT &operator=(const PrefixFreeBWT &) = delete;
     ~PrefixFreeBWT() { if (ctx_ && owns_) pfp_destroy(ctx_); }
 
-    // runs the build; afterwards bwt()/sa()/ssa()/esa() hold the whole output
-    void build()
+    // runs the build; afterwards bwt()/ssa()/esa() hold the whole output and sa() the full SA if it was asked for
+    // (-s, or rows_need_sa: generate_bwt_lcp hands every row's SA value to out_fn even when only -r is set)
+    void build(bool rows_need_sa = false)
     {
-        if (built_) return;
+        const bool full_sa = build_sa || (rows_need_sa && any_sa);
+        if (built_ && (!full_sa || !sa_.empty())) return;
         pfp_bwt_sizes bs;
-        engine_check(ctx_, pfp_bwt_build(ctx_, any_sa ? 1 : 0, build_rssa ? 1 : 0, &bs), "pfp_bwt_build");
+        engine_check(ctx_, pfp_bwt_build(ctx_, full_sa ? 1 : 0, build_rssa ? 1 : 0, &bs), "pfp_bwt_build");
         nout_ = bs.nout; r_ = bs.r; easy_ = bs.easy_cases; hard_ = bs.hard_cases;
-        bwt_.resize(nout_); if (any_sa) sa_.resize(nout_);
+        bwt_.resize(nout_); if (full_sa) sa_.resize(nout_);
         if (build_rssa) { ssa_.resize(2 * r_); esa_.resize(2 * r_); }
-        engine_check(ctx_, pfp_bwt_get(ctx_, bwt_.data(), any_sa ? sa_.data() : nullptr, build_rssa ? ssa_.data() : nullptr, build_rssa ? esa_.data() : nullptr), "pfp_bwt_get");
+        engine_check(ctx_, pfp_bwt_get(ctx_, bwt_.data(), full_sa ? sa_.data() : nullptr, build_rssa ? ssa_.data() : nullptr, build_rssa ? esa_.data() : nullptr), "pfp_bwt_get");
         built_ = true;
     }
 
     template <typename Fn> void generate_bwt_lcp(Fn out_fn)
     {
         if (verbose) fprintf(stderr, "generating dict suffixes\n");
-        build();
+        build(true);
         if (verbose) fprintf(stderr, "processing words to build BWT\n");
         uint8_t pbwtc = 0;
         for (size_t i = 0; i < nout_; ++i) {

@@ -195,7 +195,7 @@ class PfpContext:
     def bwt_get(self):
         b = self.bsizes
         sa, rssa = self._want
-        out = {"bwt": np.empty(self._rows, np.uint8), "sa": np.empty(self._rows, self.udt) if (sa or rssa) else None,
+        out = {"bwt": np.empty(self._rows, np.uint8), "sa": np.empty(self._rows, self.udt) if sa else None,
                "ssa": np.empty(2 * b.r, self.udt) if rssa else None, "esa": np.empty(2 * b.r, self.udt) if rssa else None}
         self._check(self.L.pfp_bwt_get(self.h, _ptr(out["bwt"]), _ptr(out["sa"]), _ptr(out["ssa"]), _ptr(out["esa"])))
         return out

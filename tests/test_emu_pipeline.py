@@ -64,3 +64,32 @@ def test_emu_error_paths(emu_factory):
 def test_emu_ragged_inputs(emu_factory):
     from pfp_testlib import check_ragged
     check_ragged(emu_factory)
+
+
+VARIANT_CODE = r'''
+import sys
+sys.path.insert(0, sys.argv[1] + "/tests")
+from pfp_testlib import *
+import pfbwt_hip
+F = lambda **kw: pfbwt_hip.PfpContext(lib=EMU_SO, **kw)
+man, recs = golden_case("w4p7"); seqs = [s for _, s in recs]
+for U in (4, 8):
+    ref = oracle_run(seqs, w=man["w"], p=man["p"], U=U)
+    for sa, rssa in ((True, True), (False, True), (True, False), (False, False)):
+        res = engine_run(F, seqs, man["w"], man["p"], U, sa=sa, rssa=rssa)
+        names = ["bwt"] + (["sa"] if sa else []) + (["ssa", "esa"] if rssa else [])
+        bad = compare(res, ref, U, names=tuple(names))
+        assert bad == [] and res["r"] == ref["r"], (U, sa, rssa, bad)
+print("variant ok")
+'''
+
+
+@pytest.mark.parametrize("env", [{"PFP_FORCE_WIDE_ROWS": "1"}, {"PFP_EMIT_CHUNK_ROWS": "777"}, {"PFP_FORCE_WIDE_ROWS": "1", "PFP_EMIT_CHUNK_ROWS": "1000"}])
+def test_emu_wide_rows_and_chunked_emission(emu_factory, env):
+    """The code paths taken by texts of 2^32 bases and more (64-bit row counters, emission in windows of rows, run
+    samples in two passes) forced on a small input: every output combination must still equal the oracle."""
+    import sys
+    from pfp_testlib import ROOT
+    e = dict(os.environ); e.update(env)
+    pr = subprocess.run([sys.executable, "-c", VARIANT_CODE, ROOT], env=e, capture_output=True, text=True, timeout=900)
+    assert pr.returncode == 0 and "variant ok" in pr.stdout, pr.stdout[-1500:] + pr.stderr[-3000:]
