@@ -39,13 +39,17 @@ for r in rows[:14]: print("  %-20s %6d launches %10.2f ms %5.1f%%" % (r["kernel"
 out = ctx.bwt_get(); ctx.close()
 n = sz.n; assert n == T.size
 bwt = out["bwt"]; ssa = out["ssa"].reshape(-1, 2); esa = out["esa"].reshape(-1, 2)
-hb = np.bincount(bwt, minlength=256); ht = np.bincount(T, minlength=256); ht[0] += 1
+CH = 1 << 28
+hb = np.zeros(256, np.int64); ht = np.zeros(256, np.int64); starts = []
+for s in range(0, n + 1, CH):                      # chunked: numpy promotes uint8 -> int64 inside bincount
+    e = min(n + 1, s + CH); seg = bwt[s:e]
+    hb += np.bincount(seg, minlength=256)
+    if s < n: ht += np.bincount(T[s:min(n, e)], minlength=256)
+    prev = bwt[s - 1] if s else 0
+    d = np.flatnonzero(np.concatenate(([seg[0] != prev], seg[1:] != seg[:-1]))) + s; starts.append(d)
+ht[0] += 1
 assert np.array_equal(hb, ht), "BWT is not a permutation of the text"
 print("histogram ok", flush=True)
-CH = 1 << 30; starts = []
-for s in range(0, n + 1, CH):
-    e = min(n + 1, s + CH); seg = bwt[s:e]; prev = bwt[s - 1] if s else 0
-    d = np.flatnonzero(np.concatenate(([seg[0] != prev], seg[1:] != seg[:-1]))) + s; starts.append(d)
 starts = np.concatenate(starts)
 assert starts.size == b.r == ssa.shape[0] == esa.shape[0], (starts.size, b.r)
 assert np.array_equal(ssa[:, 0].astype(np.int64), starts) and np.array_equal(esa[:, 0].astype(np.int64), np.concatenate((starts[1:] - 1, [n])))
