@@ -159,6 +159,9 @@ __device__ __forceinline__ void phrase_span(const Spans &sp, uint64_t j, tpos_t 
     *ys = s; *len = (uint32_t)(sp.ye[j] - s + 1u);
 }
 
+// unaligned 8-byte read (gfx950 global loads need no alignment; callers keep 7 readable bytes behind every string)
+__device__ __forceinline__ uint64_t ld8(const uint8_t *p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+
 constexpr uint32_t LONG_PHRASE = 2048; // phrases longer than this go to the workgroup-per-phrase kernels
 
 // one thread per phrase
@@ -172,7 +175,16 @@ __global__ __launch_bounds__(BLOCK) void k_phrase_hash(const uint8_t *Y, Spans s
     if (len > LONG_PHRASE) { longlist[atomicAdd(nlong, 1u)] = (uint32_t)j; keys[j] = 0; return; }
     uint64_t h = 0;
     const uint8_t *s = Y + ys;
-    for (uint32_t i = 0; i < len; ++i) h = addmod61(mulmod61(h, B), s[i]);
+    uint32_t i = 0;
+    for (; i + 8 <= len; i += 8) {
+        uint64_t v = ld8(s + i);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) { h = addmod61(mulmod61(h, B), v & 0xff); v >>= 8; }
+    }
+    if (i < len) {
+        uint64_t v = ld8(s + i);
+        for (; i < len; ++i) { h = addmod61(mulmod61(h, B), v & 0xff); v >>= 8; }
+    }
     keys[j] = addmod61(mulmod61(h, B), len % P61);
 }
 
@@ -255,8 +267,10 @@ __global__ __launch_bounds__(BLOCK) void k_dedup_heads(const uint8_t *Y, Spans s
     if (la != lb) { head[i] = 1; atomicAdd(collide, 1u); return; }
     if (la > LONG_PHRASE) { head[i] = 0; longpairs[atomicAdd(nlongpairs, 1u)] = (uint32_t)i; return; }
     const uint8_t *a = Y + sa_, *b = Y + sb;
-    uint32_t diff = 0;
-    for (uint32_t k = 0; k < la; ++k) diff |= (uint32_t)(a[k] ^ b[k]);
+    uint64_t diff = 0;
+    uint32_t k = 0;
+    for (; k + 8 <= la; k += 8) diff |= ld8(a + k) ^ ld8(b + k);
+    if (k < la) diff |= (ld8(a + k) ^ ld8(b + k)) & ((1ULL << (8 * (la - k))) - 1ULL);
     head[i] = 0;
     if (diff) { head[i] = 1; atomicAdd(collide, 1u); }
 }

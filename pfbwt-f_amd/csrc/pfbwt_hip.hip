@@ -738,6 +738,41 @@ template <typename SAT, typename EBT> static int emit_and_sample(pfp_ctx *c, Emi
         PFP_LAUNCH(c, K_EMIT, rows * (1 + (sa_at ? sizeof(SAT) : 0)) + rows * 18, (k_emit<SAT, EBT>), nblocks(ea.e1 - ea.e0, EMIT_TILE), ea, bwt_at, sa_at);
         return PFP_OK;
     };
+    if (want_rssa && !keep_sa) {
+        // Huge text, samples only: ONE pass per window -- emit BWT bytes + SA values of the window into scratch, find the
+        // run starts, write the (row, sa) samples, forget the SA values.  r is not known in advance, so the sample
+        // arrays get a capacity from the free workspace; if r exceeds it the exact two-pass route below is taken.
+        const size_t lo_mark = c->arena.mark_lo(), hi_mark = c->arena.mark_hi();
+        uint32_t *flag, *ridx, *d_cnt; SAT *satmp;
+        PFP_ALLOC_HI(c, flag, uint32_t, chunk_rows); PFP_ALLOC_HI(c, ridx, uint32_t, chunk_rows); PFP_ALLOC_HI(c, d_cnt, uint32_t, 1);
+        PFP_ALLOC_HI(c, satmp, SAT, chunk_rows + 1);
+        const size_t freeb = c->arena.hi > c->arena.lo + ((size_t)256 << 20) ? c->arena.hi - c->arena.lo - ((size_t)256 << 20) : 0;
+        uint64_t cap = freeb / (4 * sizeof(SAT));
+        if (cap > nrows) cap = nrows;
+        if (const char *e = getenv("PFP_SAMPLE_CAP")) { const uint64_t lim = (uint64_t)atoll(e); if (lim < cap) cap = lim; }   // tests: force the fallback
+        SAT *samp = nullptr;
+        if (cap) PFP_ALLOC_LO(c, samp, SAT, 4 * cap);
+        SAT *ssa = samp, *esa = samp ? samp + 2 * cap : nullptr;
+        uint64_t run_base = 0; bool overflow = cap == 0;
+        for (uint64_t ch = 0; ch < nchunks; ++ch) {
+            const uint64_t cs = s0 + ch * chunk_rows, ce = (cs + chunk_rows < s1) ? cs + chunk_rows : s1, rows = ce - cs;
+            const uint64_t cl = cs ? 1 : 0;
+            uint8_t *bw = bwtbuf + (cs - (s0 - lead));                       // first row of the window
+            PFP_TRY(emit_window(cs - cl, ce, bw - cl, satmp));
+            PFP_LAUNCH(c, K_RUNS, rows * 5, k_run_flags, nblocks(rows, BLOCK), (const uint8_t *)bw, rows, (int)cl, flag);
+            PFP_TRY((device_scan<uint32_t, 0>(c, flag, ridx, rows, d_cnt)));
+            uint32_t rc = 0; PFP_TRY(d2h_u32(c, d_cnt, &rc));
+            if (!overflow && run_base + rc > cap) overflow = true;
+            if (!overflow)
+                PFP_LAUNCH(c, K_SAMPLES, rows * 8 + (uint64_t)rc * 4 * sizeof(SAT), (k_samples<SAT>), nblocks(rows, BLOCK), (const uint32_t *)flag, (const uint32_t *)ridx, (const SAT *)(satmp + cl), rows, cs,
+                           run_base, total, ce == total ? run_base + rc : (uint64_t)0, ssa, esa);
+            run_base += rc;
+        }
+        c->runs = run_base;
+        c->arena.release_hi(hi_mark);
+        if (!overflow) { c->d_ssa = ssa; c->d_esa = esa; return PFP_OK; }
+        c->arena.release_lo(lo_mark);      // fall through: BWT bytes are complete, samples are redone with exact sizes
+    } else {
     // pass 1: BWT bytes (and SA values if a full SA is kept)
     for (uint64_t ch = 0; ch < nchunks; ++ch) {
         const uint64_t cs = s0 + ch * chunk_rows, ce = (cs + chunk_rows < s1) ? cs + chunk_rows : s1;
@@ -753,6 +788,7 @@ template <typename SAT, typename EBT> static int emit_and_sample(pfp_ctx *c, Emi
         PFP_HIP(c, hipMemcpyAsync(&r, d_runs, 8, hipMemcpyDeviceToHost, c->stream));
         PFP_HIP(c, hipStreamSynchronize(c->stream));
         c->runs = r;
+    }
     }
     if (want_rssa) {   // .ssa / .esa samples (pfbwt-f.cpp:306-315, 325-328); only with nslices == 1
         const uint64_t r = c->runs;
