@@ -167,26 +167,41 @@ __device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t *a, uint32_t 
     return lo;
 }
 
-// first index in a[lo, n) whose entry is >= x: exponential steps from lo, then bisection (O(log distance))
-__device__ __forceinline__ uint32_t gallop_lower_bound(const uint32_t *a, uint32_t lo, uint32_t n, uint32_t x)
+// position of a row inside a multi-word group (pfbwt.hpp:137-181) and whether a whole-word member
+// emits EndOfWord.  gsacak puts byte-identical suffixes in dictionary-position order, i.e. by word rank.
+// The reference's loop starts at the FIRST member: if that one is a whole word it is emitted alone
+// (:116-128) and the rest forms its own group; otherwise all members are merged by ilist position and a
+// whole-word member contributes dict[gsa-1] == EndOfWord as its BWT byte (:140).
+template <typename EBT> __device__ __forceinline__ uint64_t multi_group_pos(const EmitArgs &a, uint32_t i, uint32_t r, uint32_t q, bool self_full, bool *full_emits_eow)
 {
-    if (lo >= n || a[lo] >= x) return lo;
-    uint32_t step = 1, prev = lo, cur = lo + 1;
-    while (cur < n && a[cur] < x) { prev = cur; step <<= 1; cur = (n - cur > step) ? cur + step : n; }
-    uint32_t l = prev + 1, h = cur < n ? cur : n;          // a[prev] < x, and (cur == n or a[cur] >= x)
-    while (l < h) { const uint32_t mid = l + ((h - l) >> 1); if (a[mid] < x) l = mid + 1; else h = mid; }
-    return l;
+    const uint2 P = a.posinfo[a.SA[i]];
+    const uint32_t g0 = P.y;
+    const uint32_t rk = word_rank_of(a, P.x & WID_MASK);
+    uint64_t before = 0;
+    uint32_t first_rk = rk, first_before = 0, first_occ = a.winfo[P.x & WID_MASK].w; bool first_full = self_full;
+    for (uint32_t s = g0; s < a.dsize; ++s) {
+        const uint32_t xs = a.SA[s];
+        const uint2 Ps = a.posinfo[xs];
+        if (Ps.y != g0) break;
+        if (s == i) continue;
+        const uint32_t ids = Ps.x & WID_MASK;
+        const uint32_t rs = word_rank_of(a, ids);
+        const uint4 Ws = a.winfo[ids];
+        const uint32_t oc = Ws.w;
+        const uint32_t lb = lower_bound_u32(a.ilist + Ws.z, oc, q);
+        before += lb;
+        if (rs < first_rk) { first_rk = rs; first_before = lb; first_occ = oc; first_full = (xs == Ws.x); }
+    }
+    const uint64_t gb = reinterpret_cast<const EBT *>(a.EB)[g0];
+    *full_emits_eow = false;
+    if (first_full) return (first_rk == rk) ? gb + r : gb + first_occ + (before - first_before) + r;
+    *full_emits_eow = self_full;
+    return gb + before + r;
 }
 
-// Output-stationary emission.  A workgroup owns EMIT_TILE consecutive rows; the slots they come from are a contiguous
-// range found by two binary searches per workgroup; that slice of EB goes to LDS.  Every thread owns EMIT_PER_THREAD
-// CONSECUTIVE rows: it locates its first slot by bisection and walks on from there; consecutive rows of one slot are
-// consecutive entries of one word's ilist, so for multi-word groups (pfbwt.hpp:137-181) the ranks of a thread's rows
-// in another member's ilist are found by galloping forward instead of one full bisection per row and member.
-// gsacak puts byte-identical suffixes in dictionary-position order, i.e. by word rank.  The reference's loop starts at
-// the FIRST member: if that one is a whole word it is emitted alone (:116-128) and the rest forms its own group;
-// otherwise all members are merged by ilist position and a whole-word member contributes dict[gsa-1] == EndOfWord as
-// its BWT byte (:140).
+// Output-stationary emission.  A workgroup owns EMIT_TILE consecutive rows; the slots they come from
+// are a contiguous range found by two binary searches per workgroup; that slice of EB goes to LDS and
+// every row finds its slot there.
 constexpr int EMIT_PER_THREAD = 8;
 constexpr int EMIT_TILE = BLOCK * EMIT_PER_THREAD;
 constexpr int EMIT_LDS_SLOTS = 4096;
@@ -208,74 +223,29 @@ template <typename SAT, typename EBT> __global__ __launch_bounds__(BLOCK) void k
     const bool in_lds = ns <= (uint32_t)EMIT_LDS_SLOTS;
     if (in_lds) for (uint32_t k = threadIdx.x; k < ns; k += BLOCK) eb[k] = EB[i0 + k];
     __syncthreads();
-    const uint64_t ob = o0 + (uint64_t)threadIdx.x * EMIT_PER_THREAD;
-    if (ob >= o1) return;
-    const int nk = (o1 - ob) < (uint64_t)EMIT_PER_THREAD ? (int)(o1 - ob) : EMIT_PER_THREAD;
-    uint32_t i = in_lds ? i0 + upper_bound_t<EBT>(eb, ns, (EBT)ob) - 1u : upper_bound_t<EBT>(EB, (uint32_t)a.dsize, (EBT)ob) - 1u;
-    int k = 0;
 #pragma unroll 1
-    while (k < nk) {
-        const uint64_t o = ob + (uint64_t)k;
-        while (i < i1 && (uint64_t)(in_lds ? eb[i + 1 - i0] : EB[i + 1]) <= o) ++i;      // slots without rows keep EB unchanged
-        const uint64_t sbeg = in_lds ? eb[i - i0] : EB[i];
-        const uint64_t send = i < i1 ? (uint64_t)(in_lds ? eb[i + 1 - i0] : EB[i + 1]) : o1;
-        const int ke = (send - ob) < (uint64_t)nk ? (int)(send - ob) : nk;                  // rows k .. ke-1 come from slot i
+    for (int k = 0; k < EMIT_PER_THREAD; ++k) {
+        const uint64_t o = o0 + (uint64_t)k * BLOCK + threadIdx.x;
+        if (o >= o1) break;
+        uint32_t i;
+        if (in_lds) i = i0 + upper_bound_t<EBT>(eb, ns, (EBT)o) - 1u;
+        else i = upper_bound_t<EBT>(EB, (uint32_t)a.dsize, (EBT)o) - 1u;
+        const uint32_t r = (uint32_t)(o - (uint64_t)(in_lds ? eb[i - i0] : EB[i]));
         const uint8_t fl = a.s_fl[i];
         const uint32_t sl = a.s_sl[i];                             // suff_len, pfbwt.hpp:83-85
-        const uint32_t fb = a.s_fb[i] + (uint32_t)(o - sbeg);      // ilist index of row k
+        const uint32_t q = a.ilist[a.s_fb[i] + r];                 // parse-BWT row of this occurrence
         const bool self_full = (fl & SF_FULL) != 0;
-        uint32_t q[EMIT_PER_THREAD];
-        uint64_t pos[EMIT_PER_THREAD];
-#pragma unroll
-        for (int j = 0; j < EMIT_PER_THREAD; ++j) if (j >= k && j < ke) { q[j] = a.ilist[fb + (uint32_t)(j - k)]; pos[j] = ob + (uint64_t)j; }
+        uint64_t pos = o;
         bool full_emits_eow = false;
-        if (fl & SF_MULTI) {
-            const uint2 P = a.posinfo[a.SA[i]];
-            const uint32_t g0 = P.y, rk = word_rank_of(a, P.x & WID_MASK);
-            uint32_t before[EMIT_PER_THREAD], fbefore[EMIT_PER_THREAD];
-#pragma unroll
-            for (int j = 0; j < EMIT_PER_THREAD; ++j) { before[j] = 0; fbefore[j] = 0; }
-            uint32_t first_rk = rk, first_occ = a.winfo[P.x & WID_MASK].w; bool first_full = self_full;
-            for (uint32_t s = g0; s < a.dsize; ++s) {
-                const uint2 Ps = a.posinfo[a.SA[s]];
-                if (Ps.y != g0) break;
-                if (s == i) continue;
-                const uint32_t ids = Ps.x & WID_MASK, rs = word_rank_of(a, ids);
-                const uint4 Ws = a.winfo[ids];
-                const uint32_t *il = a.ilist + Ws.z;
-                const bool newfirst = rs < first_rk;
-                if (newfirst) { first_rk = rs; first_occ = Ws.w; first_full = (a.SA[s] == Ws.x); }
-                uint32_t p = 0;
-#pragma unroll
-                for (int j = 0; j < EMIT_PER_THREAD; ++j) if (j >= k && j < ke) {
-                    p = (j == k) ? lower_bound_u32(il, Ws.w, q[j]) : gallop_lower_bound(il, p, Ws.w, q[j]);
-                    before[j] += p;
-                    if (newfirst) fbefore[j] = p;
-                }
-            }
-            const uint64_t gb = EB[g0];
-            const uint32_t r0 = (uint32_t)(o - sbeg);
-#pragma unroll
-            for (int j = 0; j < EMIT_PER_THREAD; ++j) if (j >= k && j < ke) {
-                const uint32_t r = r0 + (uint32_t)(j - k);
-                if (first_full) pos[j] = (first_rk == rk) ? gb + r : gb + first_occ + (before[j] - fbefore[j]) + r;
-                else pos[j] = gb + before[j] + r;
-            }
-            full_emits_eow = !first_full && self_full;
+        if (fl & SF_MULTI) pos = multi_group_pos<EBT>(a, i, r, q, self_full, &full_emits_eow);
+        const uint8_t c = self_full ? (full_emits_eow ? (uint8_t)EndOfWord : a.bwlast[q]) : a.s_pc[i];   // pfbwt.hpp:116-128 / :132
+        if (pos < a.w0 || pos >= a.w1) continue;                    // row of a boundary group that lands in another slice
+        bwt[pos - a.w0] = c;
+        if (sa) {
+            SAT v = (SAT)((SAT)(a.bwsai[q]) - (SAT)sl);             // UPDATE_SA, pfbwt.hpp:87-89
+            if (pos == 0) v = (SAT)a.n;                             // src/pfbwt-f.cpp:301
+            sa[pos - a.w0] = v;
         }
-        const uint8_t pcv = a.s_pc[i];
-#pragma unroll
-        for (int j = 0; j < EMIT_PER_THREAD; ++j) if (j >= k && j < ke) {
-            const uint64_t ps = pos[j];
-            if (ps < a.w0 || ps >= a.w1) continue;                  // row of a boundary group that lands in another window
-            bwt[ps - a.w0] = self_full ? (full_emits_eow ? (uint8_t)EndOfWord : a.bwlast[q[j]]) : pcv;   // pfbwt.hpp:116-128 / :132
-            if (sa) {
-                SAT v = (SAT)((SAT)(a.bwsai[q[j]]) - (SAT)sl);      // UPDATE_SA, pfbwt.hpp:87-89
-                if (ps == 0) v = (SAT)a.n;                          // src/pfbwt-f.cpp:301
-                sa[ps - a.w0] = v;
-            }
-        }
-        k = ke;
     }
 }
 
