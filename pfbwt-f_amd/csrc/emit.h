@@ -91,11 +91,16 @@ struct EmitArgs {
     const uint32_t *s_fb;   // per slot: first ilist index of the slot's word (F[rank])
     const uint8_t *s_fl;    // per slot: SF_* flags
     const uint8_t *s_pc;    // per slot: BWT byte of a proper-suffix slot (preceding dictionary byte, 0 after the first Dollar)
+    const uint32_t *s_g0;   // per slot: first slot of its group of equal suffixes
+    // rows of groups with many members are not ranked one by one: they are collected here and sorted by (group, q)
+    uint64_t *big_keys; uint32_t *big_vals; unsigned long long *big_count;  // big_count[1] != 0: list overflow
+    uint64_t big_cap, big_total;
     uint64_t nout, n;
     uint64_t e0, e1;        // rows (in enumeration order) this launch walks
     uint64_t w0, w1;        // output positions this launch may write: [w0, w1) -> buffer index pos - w0 (multi-GPU slices)
 };
-constexpr uint8_t SF_MULTI = 1, SF_FULL = 2;
+constexpr uint8_t SF_MULTI = 1, SF_FULL = 2, SF_BIG = 4;
+constexpr uint32_t BIG_GROUP_MEMBERS = 8;   // groups with more members than this take the sort route
 // posinfo[x] = { word id of dictionary offset x | 4-bit code of D[x-1] << 28 , class-head slot of x }: one 8-byte
 // gather per slot instead of three separate random reads (wordid, grank, D[x-1])
 constexpr uint32_t WID_MASK = 0x0FFFFFFFu;
@@ -127,7 +132,8 @@ template <typename T> __device__ __forceinline__ uint32_t upper_bound_t(const T 
 // Per suffix-array slot (the random gathers happen here, once per slot, not once per output row):
 // cnt = rows produced (occ of the word if suff_len > w, pfbwt.hpp:114), suffix length, ilist base,
 // preceding byte, whole-word flag (pfbwt.hpp:116), multi-word-group flag (pfbwt.hpp:137).
-template <typename EBT> __global__ __launch_bounds__(BLOCK) void k_emit_slots(EmitArgs a, EBT *cnt, unsigned long long *hard_rows, uint32_t *s_sl, uint32_t *s_fb, uint8_t *s_fl, uint8_t *s_pc)
+template <typename EBT> __global__ __launch_bounds__(BLOCK) void k_emit_slots(EmitArgs a, EBT *cnt, unsigned long long *hard_rows, uint32_t *s_sl, uint32_t *s_fb, uint8_t *s_fl, uint8_t *s_pc,
+                                                                             uint32_t *s_g0, uint32_t *gk /*per head slot: members*/, uint8_t *gfl /*per head slot: has a whole-word member*/)
 {
     __shared__ uint8_t hd[BLOCK + 1];
     __shared__ uint32_t red[4];   // is slot (block base + t) the head of its class of equal suffixes
@@ -154,7 +160,13 @@ template <typename EBT> __global__ __launch_bounds__(BLOCK) void k_emit_slots(Em
             else { pc = dict_byte4(P.x >> 28); if (pc == Dollar && x - 1 == wsid) pc = 0; }   // pfbwt.hpp:132 "gsa[i]-1 ? dict[..] : 0"
         }
     }
-    if (valid) { cnt[i] = (EBT)c; s_sl[i] = sl; s_fb[i] = fb; s_fl[i] = fl; s_pc[i] = pc; }
+    if (valid) {
+        cnt[i] = (EBT)c; s_sl[i] = sl; s_fb[i] = fb; s_fl[i] = fl; s_pc[i] = pc; s_g0[i] = P.y;
+        if (fl & SF_MULTI) {
+            if (i + 1 >= a.dsize || hd[threadIdx.x + 1]) gk[P.y] = (uint32_t)i - P.y + 1u;     // last member: group size
+            if (fl & SF_FULL) gfl[P.y] = 1;
+        }
+    }
     uint32_t tot;   // rows that sit in multi-word groups (the reference's "hard" bookkeeping, pfbwt.hpp:188)
     (void)block_excl_sum((fl & SF_MULTI) ? c : 0u, red, &tot);
     if (threadIdx.x == 0 && tot) atomicAdd(hard_rows, (unsigned long long)tot);
@@ -165,6 +177,44 @@ __device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t *a, uint32_t 
     uint32_t lo = 0, hi = n;
     while (lo < hi) { uint32_t mid = lo + ((hi - lo) >> 1); if (a[mid] < x) lo = mid + 1; else hi = mid; }
     return lo;
+}
+
+// Groups with more than BIG_GROUP_MEMBERS members (on a 1000-haplotype panel the suffixes of length w+1, w+2 have
+// tens of members and thousands of rows): ranking every row in every other member's ilist costs O(members) bisections
+// per row.  Their rows are instead collected as (group head slot, q) keys, sorted, and placed by their index inside
+// the group.  Groups with a whole-word member keep the ranking route (reference quirk handling lives there).
+template <typename EBT> __global__ __launch_bounds__(BLOCK) void k_big_mark(const EBT *cnt, const uint32_t *s_g0, const uint32_t *gk, const uint8_t *gfl, uint64_t dsize, uint32_t min_members, uint8_t *s_fl, unsigned long long *big_rows)
+{
+    __shared__ unsigned long long red[4];
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    unsigned long long mine = 0;
+    if (i < dsize && (s_fl[i] & SF_MULTI)) {
+        const uint32_t g0 = s_g0[i];
+        if (gk[g0] > min_members && !gfl[g0]) { s_fl[i] |= SF_BIG; mine = (unsigned long long)cnt[i]; }
+    }
+    unsigned long long tot;
+    (void)block_excl_sum(mine, red, &tot);
+    if (threadIdx.x == 0 && tot) atomicAdd(big_rows, tot);
+}
+__global__ __launch_bounds__(BLOCK) void k_big_heads(const uint64_t *keys, uint64_t nb, uint32_t *headidx)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t < nb) headidx[t] = (t == 0 || (keys[t] >> 32) != (keys[t - 1] >> 32)) ? (uint32_t)t : 0u;
+}
+template <typename SAT, typename EBT> __global__ __launch_bounds__(BLOCK) void k_big_place(EmitArgs a, const uint64_t *keys, const uint32_t *vals, const uint32_t *tg, uint64_t nb, uint8_t *bwt, SAT *sa, uint32_t *qrow)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= nb) return;
+    const uint32_t g0 = (uint32_t)(keys[t] >> 32), q = (uint32_t)keys[t], i = vals[t];
+    const uint64_t pos = (uint64_t)reinterpret_cast<const EBT *>(a.EB)[g0] + (t - tg[t]);
+    if (pos < a.w0 || pos >= a.w1) return;
+    bwt[pos - a.w0] = a.s_pc[i];                                // no whole-word member in these groups
+    if (sa) {
+        SAT v = (SAT)((SAT)(a.bwsai[q]) - (SAT)a.s_sl[i]);
+        if (pos == 0) v = (SAT)a.n;
+        sa[pos - a.w0] = v;
+    }
+    if (qrow) qrow[pos - a.w0] = q;
 }
 
 // position of a row inside a multi-word group (pfbwt.hpp:137-181) and whether a whole-word member
@@ -206,7 +256,7 @@ constexpr int EMIT_PER_THREAD = 8;
 constexpr int EMIT_TILE = BLOCK * EMIT_PER_THREAD;
 constexpr int EMIT_LDS_SLOTS = 4096;
 
-template <typename SAT, typename EBT> __global__ __launch_bounds__(BLOCK) void k_emit(EmitArgs a, uint8_t *bwt, SAT *sa)
+template <typename SAT, typename EBT> __global__ __launch_bounds__(BLOCK) void k_emit(EmitArgs a, uint8_t *bwt, SAT *sa, uint32_t *qrow /*or: parse-BWT row of every output row (samples-only mode)*/)
 {
     __shared__ EBT eb[EMIT_LDS_SLOTS];
     const EBT *EB = reinterpret_cast<const EBT *>(a.EB);
@@ -237,6 +287,22 @@ template <typename SAT, typename EBT> __global__ __launch_bounds__(BLOCK) void k
         const bool self_full = (fl & SF_FULL) != 0;
         uint64_t pos = o;
         bool full_emits_eow = false;
+        const bool big = (fl & SF_BIG) != 0;
+        {   // rows of many-member groups go to the sort list: one atomic per wave, lanes take consecutive entries
+            const unsigned long long bm = __ballot(big);
+            if (bm) {
+                const int lane = threadIdx.x & 63, leader = __ffsll((long long)bm) - 1;
+                unsigned long long basei = 0;
+                if (lane == leader) basei = atomicAdd(a.big_count, (unsigned long long)__popcll(bm));
+                basei = __shfl(basei, leader);
+                if (big) {
+                    const unsigned long long idx = basei + (unsigned long long)__popcll(bm & (lane ? (~0ULL >> (64 - lane)) : 0ULL));
+                    if (idx < a.big_cap) { a.big_keys[idx] = ((uint64_t)a.s_g0[i] << 32) | q; a.big_vals[idx] = i; }
+                    else a.big_count[1] = 1;
+                }
+            }
+        }
+        if (big) continue;
         if (fl & SF_MULTI) pos = multi_group_pos<EBT>(a, i, r, q, self_full, &full_emits_eow);
         const uint8_t c = self_full ? (full_emits_eow ? (uint8_t)EndOfWord : a.bwlast[q]) : a.s_pc[i];   // pfbwt.hpp:116-128 / :132
         if (pos < a.w0 || pos >= a.w1) continue;                    // row of a boundary group that lands in another slice
@@ -246,6 +312,7 @@ template <typename SAT, typename EBT> __global__ __launch_bounds__(BLOCK) void k
             if (pos == 0) v = (SAT)a.n;                             // src/pfbwt-f.cpp:301
             sa[pos - a.w0] = v;
         }
+        if (qrow) qrow[pos - a.w0] = q;
     }
 }
 
@@ -302,6 +369,28 @@ template <typename SAT> __global__ __launch_bounds__(BLOCK) void k_samples(const
         if (o) { esa[2 * (k - 1)] = (SAT)(o - 1); esa[2 * (k - 1) + 1] = *(sa + j - 1); }
     }
     if (o + 1 == total_rows && total_runs) { esa[2 * (total_runs - 1)] = (SAT)o; esa[2 * (total_runs - 1) + 1] = sa[j]; }
+}
+// The same from the parse-BWT rows of the window instead of SA values (samples-only mode: the bwsai gather and the
+// subtraction of the suffix length, pfbwt.hpp:87-89, are done for the 2r sampled rows only).  All members of a group of
+// equal suffixes have the same suffix length, so any slot whose row range covers the output row gives it.
+template <typename SAT, typename EBT> __device__ __forceinline__ SAT sa_of_row(const EmitArgs &a, uint32_t q, uint64_t o)
+{
+    if (o == 0) return (SAT)a.n;                                     // src/pfbwt-f.cpp:301
+    const uint32_t slot = upper_bound_t<EBT>(reinterpret_cast<const EBT *>(a.EB), (uint32_t)a.dsize, (EBT)o) - 1u;
+    return (SAT)((SAT)a.bwsai[q] - (SAT)a.s_sl[slot]);
+}
+template <typename SAT, typename EBT> __global__ __launch_bounds__(BLOCK) void k_samples_q(EmitArgs a, const uint32_t *flag, const uint32_t *runidx, const uint32_t *qrow, uint64_t rows, uint64_t row_base,
+                                                                                           uint64_t run_base, uint64_t total_rows, uint64_t total_runs, SAT *ssa, SAT *esa)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (j >= rows) return;
+    const uint64_t o = row_base + j;
+    if (flag[j]) {
+        const uint64_t k = run_base + runidx[j];
+        ssa[2 * k] = (SAT)o; ssa[2 * k + 1] = sa_of_row<SAT, EBT>(a, qrow[j], o);
+        if (o) { esa[2 * (k - 1)] = (SAT)(o - 1); esa[2 * (k - 1) + 1] = sa_of_row<SAT, EBT>(a, *(qrow + j - 1), o - 1); }
+    }
+    if (o + 1 == total_rows && total_runs) { esa[2 * (total_runs - 1)] = (SAT)o; esa[2 * (total_runs - 1) + 1] = sa_of_row<SAT, EBT>(a, qrow[j], o); }
 }
 
 } // namespace pfp

@@ -718,14 +718,23 @@ template <typename SAT, typename EBT> static int emit_and_sample(pfp_ctx *c, Emi
     const bool windowed = nslices > 1 || nchunks > 1;
     uint8_t *bwtbuf; PFP_ALLOC_LO(c, bwtbuf, uint8_t, nrows + lead + 16);
     c->d_bwt = bwtbuf + lead;
-    const bool keep_sa = want_sa || (want_rssa && nchunks == 1);   // a full SA array for this slice lives in the arena
+    const bool keep_sa = want_sa;                          // a full SA array for this slice lives in the arena
     SAT *sabuf = nullptr;
     if (keep_sa) PFP_ALLOC_LO(c, sabuf, SAT, nrows + lead);
     c->d_sa = sabuf ? sabuf + lead : nullptr;
     c->d_ssa = c->d_esa = nullptr;
-    unsigned long long *d_b; PFP_ALLOC_HI(c, d_b, unsigned long long, 4);
+    unsigned long long *d_b; PFP_ALLOC_HI(c, d_b, unsigned long long, 6);
+    // list of the rows of many-member groups (sorted per window instead of ranked row by row)
+    uint64_t *bk0 = nullptr, *bk1 = nullptr; uint32_t *bv0 = nullptr, *bv1 = nullptr, *btg = nullptr;
+    if (ea.big_total) {
+        if (ea.big_total >= 0xFFFFFFF0ULL) return PFP_E_TOO_LARGE;
+        PFP_ALLOC_HI(c, bk0, uint64_t, ea.big_total); PFP_ALLOC_HI(c, bk1, uint64_t, ea.big_total);
+        PFP_ALLOC_HI(c, bv0, uint32_t, ea.big_total); PFP_ALLOC_HI(c, bv1, uint32_t, ea.big_total); PFP_ALLOC_HI(c, btg, uint32_t, ea.big_total);
+    }
+    ea.big_keys = bk0; ea.big_vals = bv0; ea.big_count = d_b + 4; ea.big_cap = ea.big_total;
+    const BitRange big_ranges[2] = {{0, bits_for(c->nrows)}, {32, 32 + bits_for(ea.dsize)}};
     // emits the rows whose output position lies in [w0, w1); bwt_at / sa_at point at position w0
-    auto emit_window = [&](uint64_t w0, uint64_t w1, uint8_t *bwt_at, SAT *sa_at) -> int {
+    auto emit_window = [&](uint64_t w0, uint64_t w1, uint8_t *bwt_at, SAT *sa_at, uint32_t *q_at) -> int {
         ea.w0 = w0; ea.w1 = w1; ea.e0 = 0; ea.e1 = total;
         if (windowed) {
             PFP_LAUNCH(c, K_MISC, 64, (k_slice_bounds<EBT>), 1, ea, w0, w1, d_b);
@@ -735,17 +744,34 @@ template <typename SAT, typename EBT> static int emit_and_sample(pfp_ctx *c, Emi
             ea.e0 = hb[0]; ea.e1 = hb[1];
         }
         const uint64_t rows = w1 - w0;
-        PFP_LAUNCH(c, K_EMIT, rows * (1 + (sa_at ? sizeof(SAT) : 0)) + rows * 18, (k_emit<SAT, EBT>), nblocks(ea.e1 - ea.e0, EMIT_TILE), ea, bwt_at, sa_at);
+        if (ea.big_total) PFP_HIP(c, hipMemsetAsync(ea.big_count, 0, 16, c->stream));
+        PFP_LAUNCH(c, K_EMIT, rows * (1 + (sa_at ? 8 + sizeof(SAT) : 0) + (q_at ? 4 : 0)) + rows * 10, (k_emit<SAT, EBT>), nblocks(ea.e1 - ea.e0, EMIT_TILE), ea, bwt_at, sa_at, q_at);
+        if (ea.big_total) {
+            unsigned long long hb[2];
+            PFP_HIP(c, hipMemcpyAsync(hb, ea.big_count, 16, hipMemcpyDeviceToHost, c->stream));
+            PFP_HIP(c, hipStreamSynchronize(c->stream));
+            if (hb[1] || hb[0] > ea.big_total) return PFP_E_CORRUPT;
+            const uint64_t nb = hb[0];
+            if (nb) {
+                uint64_t *sk; uint32_t *sv;
+                PFP_TRY(radix_sort_pairs<uint64_t>(c, bk0, bv0, bk1, bv1, nb, big_ranges, 2, &sk, &sv));
+                PFP_LAUNCH(c, K_EMIT_BIG, nb * 12, k_big_heads, nblocks(nb, BLOCK), (const uint64_t *)sk, nb, btg);
+                PFP_TRY((device_scan<uint32_t, 1>(c, btg, btg, nb, nullptr)));
+                PFP_LAUNCH(c, K_EMIT_BIG, nb * (30 + sizeof(SAT)), (k_big_place<SAT, EBT>), nblocks(nb, BLOCK), ea, (const uint64_t *)sk, (const uint32_t *)sv, (const uint32_t *)btg, nb, bwt_at, sa_at, q_at);
+            }
+        }
         return PFP_OK;
     };
     if (want_rssa && !keep_sa) {
-        // Huge text, samples only: ONE pass per window -- emit BWT bytes + SA values of the window into scratch, find the
-        // run starts, write the (row, sa) samples, forget the SA values.  r is not known in advance, so the sample
-        // arrays get a capacity from the free workspace; if r exceeds it the exact two-pass route below is taken.
+        // Samples only: ONE pass per window -- emit the BWT bytes and, per row, its parse-BWT row q into scratch, find the
+        // run starts, compute SA values for the 2r sampled rows only (k_samples_q), forget the q's.  r is not known in
+        // advance, so the sample arrays get a capacity from the free workspace; if r exceeds it the exact two-pass
+        // route below is taken.
         const size_t lo_mark = c->arena.mark_lo(), hi_mark = c->arena.mark_hi();
-        uint32_t *flag, *ridx, *d_cnt; SAT *satmp;
-        PFP_ALLOC_HI(c, flag, uint32_t, chunk_rows); PFP_ALLOC_HI(c, ridx, uint32_t, chunk_rows); PFP_ALLOC_HI(c, d_cnt, uint32_t, 1);
-        PFP_ALLOC_HI(c, satmp, SAT, chunk_rows + 1);
+        const uint64_t maxrows = nchunks == 1 ? nrows : chunk_rows;
+        uint32_t *flag, *ridx, *d_cnt, *qtmp;
+        PFP_ALLOC_HI(c, flag, uint32_t, maxrows); PFP_ALLOC_HI(c, ridx, uint32_t, maxrows); PFP_ALLOC_HI(c, d_cnt, uint32_t, 1);
+        PFP_ALLOC_HI(c, qtmp, uint32_t, maxrows + 1);
         const size_t freeb = c->arena.hi > c->arena.lo + ((size_t)256 << 20) ? c->arena.hi - c->arena.lo - ((size_t)256 << 20) : 0;
         uint64_t cap = freeb / (4 * sizeof(SAT));
         if (cap > nrows) cap = nrows;
@@ -758,14 +784,14 @@ template <typename SAT, typename EBT> static int emit_and_sample(pfp_ctx *c, Emi
             const uint64_t cs = s0 + ch * chunk_rows, ce = (cs + chunk_rows < s1) ? cs + chunk_rows : s1, rows = ce - cs;
             const uint64_t cl = cs ? 1 : 0;
             uint8_t *bw = bwtbuf + (cs - (s0 - lead));                       // first row of the window
-            PFP_TRY(emit_window(cs - cl, ce, bw - cl, satmp));
+            PFP_TRY(emit_window(cs - cl, ce, bw - cl, (SAT *)nullptr, qtmp));
             PFP_LAUNCH(c, K_RUNS, rows * 5, k_run_flags, nblocks(rows, BLOCK), (const uint8_t *)bw, rows, (int)cl, flag);
             PFP_TRY((device_scan<uint32_t, 0>(c, flag, ridx, rows, d_cnt)));
             uint32_t rc = 0; PFP_TRY(d2h_u32(c, d_cnt, &rc));
             if (!overflow && run_base + rc > cap) overflow = true;
             if (!overflow)
-                PFP_LAUNCH(c, K_SAMPLES, rows * 8 + (uint64_t)rc * 4 * sizeof(SAT), (k_samples<SAT>), nblocks(rows, BLOCK), (const uint32_t *)flag, (const uint32_t *)ridx, (const SAT *)(satmp + cl), rows, cs,
-                           run_base, total, ce == total ? run_base + rc : (uint64_t)0, ssa, esa);
+                PFP_LAUNCH(c, K_SAMPLES, rows * 8 + (uint64_t)rc * (32 + 4 * sizeof(SAT)), (k_samples_q<SAT, EBT>), nblocks(rows, BLOCK), ea, (const uint32_t *)flag, (const uint32_t *)ridx, (const uint32_t *)(qtmp + cl),
+                           rows, cs, run_base, total, ce == total ? run_base + rc : (uint64_t)0, ssa, esa);
             run_base += rc;
         }
         c->runs = run_base;
@@ -777,7 +803,7 @@ template <typename SAT, typename EBT> static int emit_and_sample(pfp_ctx *c, Emi
     for (uint64_t ch = 0; ch < nchunks; ++ch) {
         const uint64_t cs = s0 + ch * chunk_rows, ce = (cs + chunk_rows < s1) ? cs + chunk_rows : s1;
         const uint64_t cl = cs ? 1 : 0;
-        PFP_TRY(emit_window(cs - cl, ce, bwtbuf + (cs - cl - (s0 - lead)), sabuf ? sabuf + (cs - cl - (s0 - lead)) : (SAT *)nullptr));
+        PFP_TRY(emit_window(cs - cl, ce, bwtbuf + (cs - cl - (s0 - lead)), sabuf ? sabuf + (cs - cl - (s0 - lead)) : (SAT *)nullptr, (uint32_t *)nullptr));
     }
     // runs (src/pfbwt-f.cpp:304-305): runs that start in this slice
     {
@@ -796,25 +822,24 @@ template <typename SAT, typename EBT> static int emit_and_sample(pfp_ctx *c, Emi
         PFP_ALLOC_LO(c, ssa, SAT, 2 * r); PFP_ALLOC_LO(c, esa, SAT, 2 * r);
         c->d_ssa = ssa; c->d_esa = esa;
         const uint64_t maxrows = nchunks == 1 ? nrows : chunk_rows;
-        uint32_t *flag, *ridx, *d_cnt; SAT *satmp = nullptr;
+        uint32_t *flag, *ridx, *d_cnt, *qtmp = nullptr;
         PFP_ALLOC_HI(c, flag, uint32_t, maxrows); PFP_ALLOC_HI(c, ridx, uint32_t, maxrows); PFP_ALLOC_HI(c, d_cnt, uint32_t, 1);
-        if (!sabuf) PFP_ALLOC_HI(c, satmp, SAT, maxrows + 1);
+        if (!sabuf) PFP_ALLOC_HI(c, qtmp, uint32_t, maxrows + 1);
         uint64_t run_base = 0;
         for (uint64_t ch = 0; ch < nchunks; ++ch) {
             const uint64_t cs = s0 + ch * chunk_rows, ce = (cs + chunk_rows < s1) ? cs + chunk_rows : s1, rows = ce - cs;
             const uint64_t cl = cs ? 1 : 0;
             uint8_t *bw = bwtbuf + (cs - (s0 - lead));                       // first row of the chunk
-            const SAT *sa_first;
-            if (sabuf) sa_first = sabuf + (cs - (s0 - lead));
-            else {   // pass 2 of this window: the same rows again, now with their SA values
-                PFP_TRY(emit_window(cs - cl, ce, bw - cl, satmp));
-                sa_first = satmp + cl;
-            }
+            if (!sabuf) PFP_TRY(emit_window(cs - cl, ce, bw - cl, (SAT *)nullptr, qtmp));   // pass 2 of this window: the same rows again, now with their q
             PFP_LAUNCH(c, K_RUNS, rows * 5, k_run_flags, nblocks(rows, BLOCK), (const uint8_t *)bw, rows, (int)cl, flag);
             PFP_TRY((device_scan<uint32_t, 0>(c, flag, ridx, rows, d_cnt)));
             uint32_t rc = 0; PFP_TRY(d2h_u32(c, d_cnt, &rc));
-            PFP_LAUNCH(c, K_SAMPLES, rows * 8 + (uint64_t)rc * 4 * sizeof(SAT), (k_samples<SAT>), nblocks(rows, BLOCK), (const uint32_t *)flag, (const uint32_t *)ridx, sa_first, rows, cs, run_base,
-                       total, r, ssa, esa);
+            if (sabuf)
+                PFP_LAUNCH(c, K_SAMPLES, rows * 8 + (uint64_t)rc * 4 * sizeof(SAT), (k_samples<SAT>), nblocks(rows, BLOCK), (const uint32_t *)flag, (const uint32_t *)ridx, (const SAT *)(sabuf + (cs - (s0 - lead))), rows, cs,
+                           run_base, total, r, ssa, esa);
+            else
+                PFP_LAUNCH(c, K_SAMPLES, rows * 8 + (uint64_t)rc * (32 + 4 * sizeof(SAT)), (k_samples_q<SAT, EBT>), nblocks(rows, BLOCK), ea, (const uint32_t *)flag, (const uint32_t *)ridx, (const uint32_t *)(qtmp + cl), rows, cs,
+                           run_base, total, r, ssa, esa);
             run_base += rc;
         }
         if (run_base != r) return PFP_E_CORRUPT;
@@ -830,12 +855,19 @@ template <typename EBT> static int emit_stage(pfp_ctx *c, EmitArgs ea, int want_
     PFP_ALLOC_HI(c, cnt, EBT, dsize); PFP_ALLOC_HI(c, EB, EBT, dsize); PFP_ALLOC_HI(c, d_hard, unsigned long long, 2); PFP_ALLOC_HI(c, d_tot, EBT, 2);
     PFP_HIP(c, hipMemsetAsync(d_hard, 0, 16, c->stream));
     ea.EB = EB;
-    PFP_LAUNCH(c, K_EMIT_COUNT, dsize * (30 + sizeof(EBT)), (k_emit_slots<EBT>), nblocks(dsize, BLOCK), ea, cnt, d_hard, (uint32_t *)ea.s_sl, (uint32_t *)ea.s_fb, (uint8_t *)ea.s_fl, (uint8_t *)ea.s_pc);
+    uint32_t *s_g0, *gk; uint8_t *gfl;
+    PFP_ALLOC_HI(c, s_g0, uint32_t, dsize); PFP_ALLOC_HI(c, gk, uint32_t, dsize); PFP_ALLOC_HI(c, gfl, uint8_t, dsize);
+    PFP_HIP(c, hipMemsetAsync(gfl, 0, dsize, c->stream));
+    ea.s_g0 = s_g0;
+    PFP_LAUNCH(c, K_EMIT_COUNT, dsize * (30 + sizeof(EBT)), (k_emit_slots<EBT>), nblocks(dsize, BLOCK), ea, cnt, d_hard, (uint32_t *)ea.s_sl, (uint32_t *)ea.s_fb, (uint8_t *)ea.s_fl, (uint8_t *)ea.s_pc, s_g0, gk, gfl);
+    static const long big_members = getenv("PFP_BIG_GROUP_MEMBERS") ? atol(getenv("PFP_BIG_GROUP_MEMBERS")) : (long)BIG_GROUP_MEMBERS;   // < 0: never
+    if (big_members >= 0) PFP_LAUNCH(c, K_EMIT_COUNT, dsize * 14, (k_big_mark<EBT>), nblocks(dsize, BLOCK), (const EBT *)cnt, (const uint32_t *)s_g0, (const uint32_t *)gk, (const uint8_t *)gfl, dsize, (uint32_t)big_members, (uint8_t *)ea.s_fl, d_hard + 1);
     PFP_TRY((device_scan<EBT, 0>(c, cnt, EB, dsize, d_tot)));
-    EBT tot = 0; unsigned long long hardrows = 0;
-    PFP_HIP(c, hipMemcpyAsync(&hardrows, d_hard, 8, hipMemcpyDeviceToHost, c->stream));
+    EBT tot = 0; unsigned long long hardrows = 0, hh[2] = {0, 0};
+    PFP_HIP(c, hipMemcpyAsync(hh, d_hard, 16, hipMemcpyDeviceToHost, c->stream));
     PFP_HIP(c, hipMemcpyAsync(&tot, d_tot, sizeof(EBT), hipMemcpyDeviceToHost, c->stream));
     PFP_HIP(c, hipStreamSynchronize(c->stream));
+    hardrows = hh[0]; ea.big_total = hh[1];
     const uint64_t nout = tot;
     if (nout < 2) return PFP_E_CORRUPT;
     if (c->n && nout != c->n + 1) return PFP_E_CORRUPT;         // emission must produce exactly n+1 rows

@@ -72,23 +72,35 @@ sys.path.insert(0, sys.argv[1] + "/tests")
 from pfp_testlib import *
 import pfbwt_hip
 F = lambda **kw: pfbwt_hip.PfpContext(lib=EMU_SO, **kw)
-man, recs = golden_case("w4p7"); seqs = [s for _, s in recs]
-for U in (4, 8):
-    ref = oracle_run(seqs, w=man["w"], p=man["p"], U=U)
-    for sa, rssa in ((True, True), (False, True), (True, False), (False, False)):
-        res = engine_run(F, seqs, man["w"], man["p"], U, sa=sa, rssa=rssa)
-        names = ["bwt"] + (["sa"] if sa else []) + (["ssa", "esa"] if rssa else [])
-        bad = compare(res, ref, U, names=tuple(names))
-        assert bad == [] and res["r"] == ref["r"], (U, sa, rssa, bad)
+import os, random
+man, recs = golden_case("w4p7")
+cases = [([s for _, s in recs], man["w"], man["p"])]
+if "PFP_BIG_GROUP_MEMBERS" in os.environ:       # a small "panel": many words share long suffixes -> groups with many members
+    rng = random.Random(5); base = [rng.choice("ACGT") for _ in range(1500)]; haps = []
+    for h in range(7):
+        b = list(base)
+        for _ in range(40): b[rng.randrange(len(b))] = rng.choice("ACGT")
+        haps.append("".join(b).encode())
+    cases.append((haps, 4, 11))
+for seqs, w, p in cases:
+    for U in (4, 8):
+        ref = oracle_run(seqs, w=w, p=p, U=U)
+        for sa, rssa in ((True, True), (False, True), (True, False), (False, False)):
+            res = engine_run(F, seqs, w, p, U, sa=sa, rssa=rssa)
+            names = ["bwt"] + (["sa"] if sa else []) + (["ssa", "esa"] if rssa else [])
+            bad = compare(res, ref, U, names=tuple(names))
+            assert bad == [] and res["r"] == ref["r"], (U, sa, rssa, bad)
 print("variant ok")
 '''
 
 
 @pytest.mark.parametrize("env", [{"PFP_FORCE_WIDE_ROWS": "1"}, {"PFP_EMIT_CHUNK_ROWS": "777"}, {"PFP_FORCE_WIDE_ROWS": "1", "PFP_EMIT_CHUNK_ROWS": "1000"},
-                                 {"PFP_EMIT_CHUNK_ROWS": "777", "PFP_SAMPLE_CAP": "40"}])
+                                 {"PFP_EMIT_CHUNK_ROWS": "777", "PFP_SAMPLE_CAP": "40"},
+                                 {"PFP_BIG_GROUP_MEMBERS": "1"}, {"PFP_BIG_GROUP_MEMBERS": "2", "PFP_EMIT_CHUNK_ROWS": "777"},
+                                 {"PFP_BIG_GROUP_MEMBERS": "-1"}])
 def test_emu_wide_rows_and_chunked_emission(emu_factory, env):
     """The code paths taken by texts of 2^32 bases and more (64-bit row counters, emission in windows of rows, run
-    samples in two passes) forced on a small input: every output combination must still equal the oracle."""
+    samples in two passes) and the sort route for groups of equal suffixes with many members, forced on small inputs: every output combination must still equal the oracle."""
     import sys
     from pfp_testlib import ROOT
     e = dict(os.environ); e.update(env)
