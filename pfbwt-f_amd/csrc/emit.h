@@ -92,6 +92,8 @@ struct EmitArgs {
     const uint8_t *s_fl;    // per slot: SF_* flags
     const uint8_t *s_pc;    // per slot: BWT byte of a proper-suffix slot (preceding dictionary byte, 0 after the first Dollar)
     const uint32_t *s_g0;   // per slot: first slot of its group of equal suffixes
+    const uint32_t *gk;     // per group head slot: number of members
+    const void *cnt;        // per slot: rows it produces (EBT)
     // rows of groups with many members are not ranked one by one: they are collected here and sorted by (group, q)
     uint64_t *big_keys; uint32_t *big_vals; unsigned long long *big_count;  // big_count[1] != 0: list overflow
     uint64_t big_cap, big_total;
@@ -99,7 +101,7 @@ struct EmitArgs {
     uint64_t e0, e1;        // rows (in enumeration order) this launch walks
     uint64_t w0, w1;        // output positions this launch may write: [w0, w1) -> buffer index pos - w0 (multi-GPU slices)
 };
-constexpr uint8_t SF_MULTI = 1, SF_FULL = 2, SF_BIG = 4;
+constexpr uint8_t SF_MULTI = 1, SF_FULL = 2, SF_BIG = 4, SF_GFULL = 8;   // GFULL: some member of the group is a whole word
 constexpr uint32_t BIG_GROUP_MEMBERS = 8;   // groups with more members than this take the sort route
 // posinfo[x] = { word id of dictionary offset x | 4-bit code of D[x-1] << 28 , class-head slot of x }: one 8-byte
 // gather per slot instead of three separate random reads (wordid, grank, D[x-1])
@@ -190,7 +192,8 @@ template <typename EBT> __global__ __launch_bounds__(BLOCK) void k_big_mark(cons
     unsigned long long mine = 0;
     if (i < dsize && (s_fl[i] & SF_MULTI)) {
         const uint32_t g0 = s_g0[i];
-        if (gk[g0] > min_members && !gfl[g0]) { s_fl[i] |= SF_BIG; mine = (unsigned long long)cnt[i]; }
+        if (gfl[g0]) s_fl[i] |= SF_GFULL;
+        else if (gk[g0] > min_members) { s_fl[i] |= SF_BIG; mine = (unsigned long long)cnt[i]; }
     }
     unsigned long long tot;
     (void)block_excl_sum(mine, red, &tot);
@@ -215,6 +218,35 @@ template <typename SAT, typename EBT> __global__ __launch_bounds__(BLOCK) void k
         sa[pos - a.w0] = v;
     }
     if (qrow) qrow[pos - a.w0] = q;
+}
+
+// Position of a row inside a group without whole-word members: gb + r + the number of occurrences of the OTHER members
+// that precede parse row q (pfbwt.hpp:137-181: the members' ilists are merged by value).  Everything comes from the
+// per-slot arrays (no SA / posinfo / winfo gathers); the bisections of up to four members run interleaved so that their
+// loads are in flight together.
+template <typename EBT> __device__ __forceinline__ uint64_t plain_group_pos(const EmitArgs &a, uint32_t i, uint32_t r, uint32_t q)
+{
+    const EBT *EB = reinterpret_cast<const EBT *>(a.EB), *CN = reinterpret_cast<const EBT *>(a.cnt);
+    const uint32_t g0 = a.s_g0[i], k = a.gk[g0];
+    uint64_t before = 0;
+    for (uint32_t s0 = 0; s0 < k; s0 += 4) {
+        const uint32_t *base[4]; uint32_t lo[4], hi[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t s = g0 + s0 + j;
+            const bool on = s0 + j < k && s != i;
+            base[j] = a.ilist + (on ? a.s_fb[s] : 0u); lo[j] = 0; hi[j] = on ? (uint32_t)CN[s] : 0u;
+        }
+        while ((lo[0] < hi[0]) | (lo[1] < hi[1]) | (lo[2] < hi[2]) | (lo[3] < hi[3])) {
+            uint32_t v[4], mid[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { mid[j] = lo[j] + ((hi[j] - lo[j]) >> 1); v[j] = lo[j] < hi[j] ? base[j][mid[j]] : 0u; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (lo[j] < hi[j]) { if (v[j] < q) lo[j] = mid[j] + 1; else hi[j] = mid[j]; }
+        }
+        before += (uint64_t)lo[0] + lo[1] + lo[2] + lo[3];
+    }
+    return (uint64_t)EB[g0] + before + r;
 }
 
 // position of a row inside a multi-word group (pfbwt.hpp:137-181) and whether a whole-word member
@@ -255,10 +287,15 @@ template <typename EBT> __device__ __forceinline__ uint64_t multi_group_pos(cons
 constexpr int EMIT_PER_THREAD = 8;
 constexpr int EMIT_TILE = BLOCK * EMIT_PER_THREAD;
 constexpr int EMIT_LDS_SLOTS = 4096;
+#ifndef PFP_EMIT_ROWS_IN_FLIGHT
+#define PFP_EMIT_ROWS_IN_FLIGHT 2
+#endif
+constexpr int EMIT_ROWS_IN_FLIGHT = PFP_EMIT_ROWS_IN_FLIGHT;
+static_assert(EMIT_PER_THREAD % EMIT_ROWS_IN_FLIGHT == 0, "rows per thread");
 
 template <typename SAT, typename EBT> __global__ __launch_bounds__(BLOCK) void k_emit(EmitArgs a, uint8_t *bwt, SAT *sa, uint32_t *qrow /*or: parse-BWT row of every output row (samples-only mode)*/)
 {
-    __shared__ EBT eb[EMIT_LDS_SLOTS];
+    __shared__ uint32_t eb[EMIT_LDS_SLOTS];                  // EB[i0 + k] - EB[i0]
     const EBT *EB = reinterpret_cast<const EBT *>(a.EB);
     __shared__ uint32_t range[2];
     const uint64_t o0 = a.e0 + (uint64_t)blockIdx.x * EMIT_TILE;
@@ -270,49 +307,63 @@ template <typename SAT, typename EBT> __global__ __launch_bounds__(BLOCK) void k
     __syncthreads();
     const uint32_t i0 = range[0], i1 = range[1];
     const uint32_t ns = i1 - i0 + 1u;
-    const bool in_lds = ns <= (uint32_t)EMIT_LDS_SLOTS;
-    if (in_lds) for (uint32_t k = threadIdx.x; k < ns; k += BLOCK) eb[k] = EB[i0 + k];
+    const uint64_t ebase = (uint64_t)EB[i0];
+    const bool in_lds = ns <= (uint32_t)EMIT_LDS_SLOTS && o1 - ebase < 0xFFFFFFFFULL;
+    if (in_lds) for (uint32_t k = threadIdx.x; k < ns; k += BLOCK) eb[k] = (uint32_t)((uint64_t)EB[i0 + k] - ebase);
     __syncthreads();
+    // EMIT_ROWS_IN_FLIGHT rows per thread are taken through the load stages together (slot search, per-slot fields,
+    // ilist, bwsai): the kernel is bound by the latency of these dependent loads, not by bandwidth.
 #pragma unroll 1
-    for (int k = 0; k < EMIT_PER_THREAD; ++k) {
-        const uint64_t o = o0 + (uint64_t)k * BLOCK + threadIdx.x;
-        if (o >= o1) break;
-        uint32_t i;
-        if (in_lds) i = i0 + upper_bound_t<EBT>(eb, ns, (EBT)o) - 1u;
-        else i = upper_bound_t<EBT>(EB, (uint32_t)a.dsize, (EBT)o) - 1u;
-        const uint32_t r = (uint32_t)(o - (uint64_t)(in_lds ? eb[i - i0] : EB[i]));
-        const uint8_t fl = a.s_fl[i];
-        const uint32_t sl = a.s_sl[i];                             // suff_len, pfbwt.hpp:83-85
-        const uint32_t q = a.ilist[a.s_fb[i] + r];                 // parse-BWT row of this occurrence
-        const bool self_full = (fl & SF_FULL) != 0;
-        uint64_t pos = o;
-        bool full_emits_eow = false;
-        const bool big = (fl & SF_BIG) != 0;
-        {   // rows of many-member groups go to the sort list: one atomic per wave, lanes take consecutive entries
-            const unsigned long long bm = __ballot(big);
-            if (bm) {
-                const int lane = threadIdx.x & 63, leader = __ffsll((long long)bm) - 1;
-                unsigned long long basei = 0;
-                if (lane == leader) basei = atomicAdd(a.big_count, (unsigned long long)__popcll(bm));
-                basei = __shfl(basei, leader);
-                if (big) {
-                    const unsigned long long idx = basei + (unsigned long long)__popcll(bm & (lane ? (~0ULL >> (64 - lane)) : 0ULL));
-                    if (idx < a.big_cap) { a.big_keys[idx] = ((uint64_t)a.s_g0[i] << 32) | q; a.big_vals[idx] = i; }
-                    else a.big_count[1] = 1;
+    for (int k = 0; k < EMIT_PER_THREAD; k += EMIT_ROWS_IN_FLIGHT) {
+        uint64_t o[EMIT_ROWS_IN_FLIGHT]; uint32_t i[EMIT_ROWS_IN_FLIGHT], r[EMIT_ROWS_IN_FLIGHT], sl[EMIT_ROWS_IN_FLIGHT], fb[EMIT_ROWS_IN_FLIGHT], q[EMIT_ROWS_IN_FLIGHT];
+        uint8_t fl[EMIT_ROWS_IN_FLIGHT], pc[EMIT_ROWS_IN_FLIGHT]; bool on[EMIT_ROWS_IN_FLIGHT]; uint64_t sv[EMIT_ROWS_IN_FLIGHT];
+#pragma unroll
+        for (int u = 0; u < EMIT_ROWS_IN_FLIGHT; ++u) {
+            o[u] = o0 + (uint64_t)(k + u) * BLOCK + threadIdx.x;
+            on[u] = o[u] < o1;
+            const uint64_t oo = on[u] ? o[u] : o0;
+            if (in_lds) { const uint32_t j = upper_bound_t<uint32_t>(eb, ns, (uint32_t)(oo - ebase)) - 1u; i[u] = i0 + j; r[u] = (uint32_t)(oo - ebase) - eb[j]; }
+            else { i[u] = upper_bound_t<EBT>(EB, (uint32_t)a.dsize, (EBT)oo) - 1u; r[u] = (uint32_t)(oo - (uint64_t)EB[i[u]]); }
+        }
+#pragma unroll
+        for (int u = 0; u < EMIT_ROWS_IN_FLIGHT; ++u) { fl[u] = a.s_fl[i[u]]; sl[u] = a.s_sl[i[u]]; fb[u] = a.s_fb[i[u]]; pc[u] = a.s_pc[i[u]]; }   // suff_len, pfbwt.hpp:83-85
+#pragma unroll
+        for (int u = 0; u < EMIT_ROWS_IN_FLIGHT; ++u) q[u] = a.ilist[fb[u] + r[u]];                    // parse-BWT row of this occurrence
+#pragma unroll
+        for (int u = 0; u < EMIT_ROWS_IN_FLIGHT; ++u) sv[u] = (sa && on[u] && !(fl[u] & SF_BIG)) ? a.bwsai[q[u]] : 0ULL;
+#pragma unroll
+        for (int u = 0; u < EMIT_ROWS_IN_FLIGHT; ++u) {
+            const bool self_full = (fl[u] & SF_FULL) != 0;
+            uint64_t pos = o[u];
+            bool full_emits_eow = false;
+            const bool big = on[u] && (fl[u] & SF_BIG) != 0;
+            {   // rows of many-member groups go to the sort list: one atomic per wave, lanes take consecutive entries
+                const unsigned long long bm = __ballot(big);
+                if (bm) {
+                    const int lane = threadIdx.x & 63, leader = __ffsll((long long)bm) - 1;
+                    unsigned long long basei = 0;
+                    if (lane == leader) basei = atomicAdd(a.big_count, (unsigned long long)__popcll(bm));
+                    basei = __shfl(basei, leader);
+                    if (big) {
+                        const unsigned long long idx = basei + (unsigned long long)__popcll(bm & (lane ? (~0ULL >> (64 - lane)) : 0ULL));
+                        if (idx < a.big_cap) { a.big_keys[idx] = ((uint64_t)a.s_g0[i[u]] << 32) | q[u]; a.big_vals[idx] = i[u]; }
+                        else a.big_count[1] = 1;
+                    }
                 }
             }
+            if (!on[u] || big) continue;
+            if (fl[u] & SF_GFULL) pos = multi_group_pos<EBT>(a, i[u], r[u], q[u], self_full, &full_emits_eow);
+            else if (fl[u] & SF_MULTI) pos = plain_group_pos<EBT>(a, i[u], r[u], q[u]);
+            const uint8_t c = self_full ? (full_emits_eow ? (uint8_t)EndOfWord : a.bwlast[q[u]]) : pc[u];   // pfbwt.hpp:116-128 / :132
+            if (pos < a.w0 || pos >= a.w1) continue;                    // row of a boundary group that lands in another slice
+            bwt[pos - a.w0] = c;
+            if (sa) {
+                SAT v = (SAT)((SAT)sv[u] - (SAT)sl[u]);                 // UPDATE_SA, pfbwt.hpp:87-89
+                if (pos == 0) v = (SAT)a.n;                             // src/pfbwt-f.cpp:301
+                sa[pos - a.w0] = v;
+            }
+            if (qrow) qrow[pos - a.w0] = q[u];
         }
-        if (big) continue;
-        if (fl & SF_MULTI) pos = multi_group_pos<EBT>(a, i, r, q, self_full, &full_emits_eow);
-        const uint8_t c = self_full ? (full_emits_eow ? (uint8_t)EndOfWord : a.bwlast[q]) : a.s_pc[i];   // pfbwt.hpp:116-128 / :132
-        if (pos < a.w0 || pos >= a.w1) continue;                    // row of a boundary group that lands in another slice
-        bwt[pos - a.w0] = c;
-        if (sa) {
-            SAT v = (SAT)((SAT)(a.bwsai[q]) - (SAT)sl);             // UPDATE_SA, pfbwt.hpp:87-89
-            if (pos == 0) v = (SAT)a.n;                             // src/pfbwt-f.cpp:301
-            sa[pos - a.w0] = v;
-        }
-        if (qrow) qrow[pos - a.w0] = q;
     }
 }
 
@@ -333,13 +384,6 @@ template <typename EBT> __global__ __launch_bounds__(BLOCK) void k_slice_bounds(
     while (s < a.dsize && (uint64_t)EB[s] < hi) ++s;       // slots that produce no rows keep EB unchanged
     out[1] = s < a.dsize ? (uint64_t)EB[s] : a.nout;
 }
-// run starts inside a window of rows: flag[j] for row (first + j); bwt points at that first row and has_prev says
-// whether bwt[-1] holds the row in front of it (pbwtc starts at 0, src/pfbwt-f.cpp:304)
-__global__ __launch_bounds__(BLOCK) void k_run_flags(const uint8_t *bwt, uint64_t rows, int has_prev, uint32_t *flag)
-{
-    const uint64_t j = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (j < rows) flag[j] = bwt[j] != ((j || has_prev) ? *(bwt + j - 1) : (uint8_t)0) ? 1u : 0u;
-}
 // run count only (no samples wanted): workgroup reduction + one atomic per workgroup.  `bwt` points at the first
 // row to count; has_prev says whether bwt[-1] holds the row in front of it (slices > 0).
 __global__ __launch_bounds__(BLOCK) void k_run_count(const uint8_t *bwt, uint64_t nout, int has_prev, unsigned long long *runs)
@@ -355,22 +399,7 @@ __global__ __launch_bounds__(BLOCK) void k_run_count(const uint8_t *bwt, uint64_
     (void)block_excl_sum(cntr, red, &tot);
     if (threadIdx.x == 0 && tot) atomicAdd(runs, (unsigned long long)tot);
 }
-// .ssa / .esa pairs, src/pfbwt-f.cpp:306-315 and :325-328, for a window of rows: row index = row_base + j, sa[j]
-// (sa[-1] valid when has_prev), run index = run_base + runidx[j]; total_rows / total_runs describe the whole output.
-template <typename SAT> __global__ __launch_bounds__(BLOCK) void k_samples(const uint32_t *flag, const uint32_t *runidx, const SAT *sa, uint64_t rows, uint64_t row_base, uint64_t run_base,
-                                                                           uint64_t total_rows, uint64_t total_runs, SAT *ssa, SAT *esa)
-{
-    const uint64_t j = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (j >= rows) return;
-    const uint64_t o = row_base + j;
-    if (flag[j]) {
-        const uint64_t k = run_base + runidx[j];
-        ssa[2 * k] = (SAT)o; ssa[2 * k + 1] = sa[j];
-        if (o) { esa[2 * (k - 1)] = (SAT)(o - 1); esa[2 * (k - 1) + 1] = *(sa + j - 1); }
-    }
-    if (o + 1 == total_rows && total_runs) { esa[2 * (total_runs - 1)] = (SAT)o; esa[2 * (total_runs - 1) + 1] = sa[j]; }
-}
-// The same from the parse-BWT rows of the window instead of SA values (samples-only mode: the bwsai gather and the
+// SA value of an output row from its parse-BWT row (samples-only mode: the bwsai gather and the
 // subtraction of the suffix length, pfbwt.hpp:87-89, are done for the 2r sampled rows only).  All members of a group of
 // equal suffixes have the same suffix length, so any slot whose row range covers the output row gives it.
 template <typename SAT, typename EBT> __device__ __forceinline__ SAT sa_of_row(const EmitArgs &a, uint32_t q, uint64_t o)
@@ -379,18 +408,52 @@ template <typename SAT, typename EBT> __device__ __forceinline__ SAT sa_of_row(c
     const uint32_t slot = upper_bound_t<EBT>(reinterpret_cast<const EBT *>(a.EB), (uint32_t)a.dsize, (EBT)o) - 1u;
     return (SAT)((SAT)a.bwsai[q] - (SAT)a.s_sl[slot]);
 }
-template <typename SAT, typename EBT> __global__ __launch_bounds__(BLOCK) void k_samples_q(EmitArgs a, const uint32_t *flag, const uint32_t *runidx, const uint32_t *qrow, uint64_t rows, uint64_t row_base,
-                                                                                           uint64_t run_base, uint64_t total_rows, uint64_t total_runs, SAT *ssa, SAT *esa)
+// Run starts of a window, 16 rows per thread: bit k of the result <=> row j0 + k (< rows) differs from the row in front
+// of it (pbwtc starts at 0, src/pfbwt-f.cpp:304).  Reads up to 15 bytes past the window (the BWT buffer is padded).
+constexpr int RUN_PER_THREAD = 16, RUN_TILE = BLOCK * RUN_PER_THREAD;
+__device__ __forceinline__ uint32_t run_mask16(const uint8_t *bwt, uint64_t j0, uint64_t rows, int has_prev)
 {
-    const uint64_t j = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (j >= rows) return;
-    const uint64_t o = row_base + j;
-    if (flag[j]) {
-        const uint64_t k = run_base + runidx[j];
-        ssa[2 * k] = (SAT)o; ssa[2 * k + 1] = sa_of_row<SAT, EBT>(a, qrow[j], o);
-        if (o) { esa[2 * (k - 1)] = (SAT)(o - 1); esa[2 * (k - 1) + 1] = sa_of_row<SAT, EBT>(a, *(qrow + j - 1), o - 1); }
+    if (j0 >= rows) return 0;
+    const uint64_t lo = ld8(bwt + j0), hi = ld8(bwt + j0 + 8);
+    const uint64_t prev = (j0 || has_prev) ? (uint64_t)*(bwt + j0 - 1) : 0ULL;
+    const uint64_t xl = lo ^ ((lo << 8) | prev), xh = hi ^ ((hi << 8) | (lo >> 56));
+    uint32_t m = 0;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) { m |= ((xl >> (8 * b)) & 0xff) ? (1u << b) : 0u; m |= ((xh >> (8 * b)) & 0xff) ? (1u << (8 + b)) : 0u; }
+    const uint64_t left = rows - j0;
+    return left >= 16 ? m : (m & ((1u << left) - 1u));
+}
+__global__ __launch_bounds__(BLOCK) void k_run_tile_count(const uint8_t *bwt, uint64_t rows, int has_prev, uint32_t *tilecnt)
+{
+    __shared__ uint32_t red[4];
+    const uint64_t j0 = ((uint64_t)blockIdx.x * BLOCK + threadIdx.x) * RUN_PER_THREAD;
+    uint32_t tot;
+    (void)block_excl_sum((uint32_t)__popc(run_mask16(bwt, j0, rows, has_prev)), red, &tot);
+    if (threadIdx.x == 0) tilecnt[blockIdx.x] = tot;
+}
+// .ssa / .esa pairs, src/pfbwt-f.cpp:306-315 and :325-328, for a window of rows: row index = row_base + j, run index =
+// run_base + tilebase[tile] + rank inside the tile; total_rows / total_runs describe the whole output.  The SA value of
+// row j is sa[j] (sa[-1] valid when has_prev) or, in samples-only mode (sa == nullptr), computed from qrow[j].
+template <typename SAT, typename EBT> __global__ __launch_bounds__(BLOCK) void k_samples_tile(EmitArgs a, const uint8_t *bwt, uint64_t rows, int has_prev, const uint32_t *tilebase, const SAT *sa, const uint32_t *qrow,
+                                                                                              uint64_t row_base, uint64_t run_base, uint64_t total_rows, uint64_t total_runs, SAT *ssa, SAT *esa)
+{
+    __shared__ uint32_t red[4];
+    const uint64_t j0 = ((uint64_t)blockIdx.x * BLOCK + threadIdx.x) * RUN_PER_THREAD;
+    uint32_t m = run_mask16(bwt, j0, rows, has_prev), tot;
+    const uint32_t ex = block_excl_sum((uint32_t)__popc(m), red, &tot);
+    uint64_t k = run_base + tilebase[blockIdx.x] + ex;
+    auto value = [&](uint64_t j) -> SAT { return sa ? *(sa + j) : sa_of_row<SAT, EBT>(a, *(qrow + j), row_base + j); };   // j may be -1 (as uint64) for the row in front
+    while (m) {
+        const int b = __ffs((int)m) - 1; m &= m - 1;
+        const uint64_t j = j0 + b, o = row_base + j;
+        ssa[2 * k] = (SAT)o; ssa[2 * k + 1] = value(j);
+        if (o) { esa[2 * (k - 1)] = (SAT)(o - 1); esa[2 * (k - 1) + 1] = value(j - 1); }
+        ++k;
     }
-    if (o + 1 == total_rows && total_runs) { esa[2 * (total_runs - 1)] = (SAT)o; esa[2 * (total_runs - 1) + 1] = sa_of_row<SAT, EBT>(a, qrow[j], o); }
+    if (total_runs && j0 < rows && row_base + rows == total_rows && total_rows - 1 - row_base - j0 < RUN_PER_THREAD) {   // the last row of the output ends the last run
+        const uint64_t j = rows - 1;
+        esa[2 * (total_runs - 1)] = (SAT)(row_base + j); esa[2 * (total_runs - 1) + 1] = value(j);
+    }
 }
 
 } // namespace pfp

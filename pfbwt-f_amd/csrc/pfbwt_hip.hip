@@ -769,8 +769,9 @@ template <typename SAT, typename EBT> static int emit_and_sample(pfp_ctx *c, Emi
         // route below is taken.
         const size_t lo_mark = c->arena.mark_lo(), hi_mark = c->arena.mark_hi();
         const uint64_t maxrows = nchunks == 1 ? nrows : chunk_rows;
-        uint32_t *flag, *ridx, *d_cnt, *qtmp;
-        PFP_ALLOC_HI(c, flag, uint32_t, maxrows); PFP_ALLOC_HI(c, ridx, uint32_t, maxrows); PFP_ALLOC_HI(c, d_cnt, uint32_t, 1);
+        const uint64_t maxtiles = nblocks(maxrows, RUN_TILE);
+        uint32_t *tilecnt, *tilebase, *d_cnt, *qtmp;
+        PFP_ALLOC_HI(c, tilecnt, uint32_t, maxtiles); PFP_ALLOC_HI(c, tilebase, uint32_t, maxtiles); PFP_ALLOC_HI(c, d_cnt, uint32_t, 1);
         PFP_ALLOC_HI(c, qtmp, uint32_t, maxrows + 1);
         const size_t freeb = c->arena.hi > c->arena.lo + ((size_t)256 << 20) ? c->arena.hi - c->arena.lo - ((size_t)256 << 20) : 0;
         uint64_t cap = freeb / (4 * sizeof(SAT));
@@ -785,13 +786,14 @@ template <typename SAT, typename EBT> static int emit_and_sample(pfp_ctx *c, Emi
             const uint64_t cl = cs ? 1 : 0;
             uint8_t *bw = bwtbuf + (cs - (s0 - lead));                       // first row of the window
             PFP_TRY(emit_window(cs - cl, ce, bw - cl, (SAT *)nullptr, qtmp));
-            PFP_LAUNCH(c, K_RUNS, rows * 5, k_run_flags, nblocks(rows, BLOCK), (const uint8_t *)bw, rows, (int)cl, flag);
-            PFP_TRY((device_scan<uint32_t, 0>(c, flag, ridx, rows, d_cnt)));
+            const uint64_t ntiles = nblocks(rows, RUN_TILE);
+            PFP_LAUNCH(c, K_RUNS, rows, k_run_tile_count, ntiles, (const uint8_t *)bw, rows, (int)cl, tilecnt);
+            PFP_TRY((device_scan<uint32_t, 0>(c, tilecnt, tilebase, ntiles, d_cnt)));
             uint32_t rc = 0; PFP_TRY(d2h_u32(c, d_cnt, &rc));
             if (!overflow && run_base + rc > cap) overflow = true;
             if (!overflow)
-                PFP_LAUNCH(c, K_SAMPLES, rows * 8 + (uint64_t)rc * (32 + 4 * sizeof(SAT)), (k_samples_q<SAT, EBT>), nblocks(rows, BLOCK), ea, (const uint32_t *)flag, (const uint32_t *)ridx, (const uint32_t *)(qtmp + cl),
-                           rows, cs, run_base, total, ce == total ? run_base + rc : (uint64_t)0, ssa, esa);
+                PFP_LAUNCH(c, K_SAMPLES, rows + (uint64_t)rc * (32 + 4 * sizeof(SAT)), (k_samples_tile<SAT, EBT>), ntiles, ea, (const uint8_t *)bw, rows, (int)cl, (const uint32_t *)tilebase, (const SAT *)nullptr,
+                           (const uint32_t *)(qtmp + cl), cs, run_base, total, ce == total ? run_base + rc : (uint64_t)0, ssa, esa);
             run_base += rc;
         }
         c->runs = run_base;
@@ -822,8 +824,9 @@ template <typename SAT, typename EBT> static int emit_and_sample(pfp_ctx *c, Emi
         PFP_ALLOC_LO(c, ssa, SAT, 2 * r); PFP_ALLOC_LO(c, esa, SAT, 2 * r);
         c->d_ssa = ssa; c->d_esa = esa;
         const uint64_t maxrows = nchunks == 1 ? nrows : chunk_rows;
-        uint32_t *flag, *ridx, *d_cnt, *qtmp = nullptr;
-        PFP_ALLOC_HI(c, flag, uint32_t, maxrows); PFP_ALLOC_HI(c, ridx, uint32_t, maxrows); PFP_ALLOC_HI(c, d_cnt, uint32_t, 1);
+        const uint64_t maxtiles = nblocks(maxrows, RUN_TILE);
+        uint32_t *tilecnt, *tilebase, *d_cnt, *qtmp = nullptr;
+        PFP_ALLOC_HI(c, tilecnt, uint32_t, maxtiles); PFP_ALLOC_HI(c, tilebase, uint32_t, maxtiles); PFP_ALLOC_HI(c, d_cnt, uint32_t, 1);
         if (!sabuf) PFP_ALLOC_HI(c, qtmp, uint32_t, maxrows + 1);
         uint64_t run_base = 0;
         for (uint64_t ch = 0; ch < nchunks; ++ch) {
@@ -831,15 +834,12 @@ template <typename SAT, typename EBT> static int emit_and_sample(pfp_ctx *c, Emi
             const uint64_t cl = cs ? 1 : 0;
             uint8_t *bw = bwtbuf + (cs - (s0 - lead));                       // first row of the chunk
             if (!sabuf) PFP_TRY(emit_window(cs - cl, ce, bw - cl, (SAT *)nullptr, qtmp));   // pass 2 of this window: the same rows again, now with their q
-            PFP_LAUNCH(c, K_RUNS, rows * 5, k_run_flags, nblocks(rows, BLOCK), (const uint8_t *)bw, rows, (int)cl, flag);
-            PFP_TRY((device_scan<uint32_t, 0>(c, flag, ridx, rows, d_cnt)));
+            const uint64_t ntiles = nblocks(rows, RUN_TILE);
+            PFP_LAUNCH(c, K_RUNS, rows, k_run_tile_count, ntiles, (const uint8_t *)bw, rows, (int)cl, tilecnt);
+            PFP_TRY((device_scan<uint32_t, 0>(c, tilecnt, tilebase, ntiles, d_cnt)));
             uint32_t rc = 0; PFP_TRY(d2h_u32(c, d_cnt, &rc));
-            if (sabuf)
-                PFP_LAUNCH(c, K_SAMPLES, rows * 8 + (uint64_t)rc * 4 * sizeof(SAT), (k_samples<SAT>), nblocks(rows, BLOCK), (const uint32_t *)flag, (const uint32_t *)ridx, (const SAT *)(sabuf + (cs - (s0 - lead))), rows, cs,
-                           run_base, total, r, ssa, esa);
-            else
-                PFP_LAUNCH(c, K_SAMPLES, rows * 8 + (uint64_t)rc * (32 + 4 * sizeof(SAT)), (k_samples_q<SAT, EBT>), nblocks(rows, BLOCK), ea, (const uint32_t *)flag, (const uint32_t *)ridx, (const uint32_t *)(qtmp + cl), rows, cs,
-                           run_base, total, r, ssa, esa);
+            PFP_LAUNCH(c, K_SAMPLES, rows + (uint64_t)rc * (32 + 4 * sizeof(SAT)), (k_samples_tile<SAT, EBT>), ntiles, ea, (const uint8_t *)bw, rows, (int)cl, (const uint32_t *)tilebase,
+                       sabuf ? (const SAT *)(sabuf + (cs - (s0 - lead))) : (const SAT *)nullptr, (const uint32_t *)(sabuf ? nullptr : qtmp + cl), cs, run_base, total, r, ssa, esa);
             run_base += rc;
         }
         if (run_base != r) return PFP_E_CORRUPT;
@@ -858,10 +858,10 @@ template <typename EBT> static int emit_stage(pfp_ctx *c, EmitArgs ea, int want_
     uint32_t *s_g0, *gk; uint8_t *gfl;
     PFP_ALLOC_HI(c, s_g0, uint32_t, dsize); PFP_ALLOC_HI(c, gk, uint32_t, dsize); PFP_ALLOC_HI(c, gfl, uint8_t, dsize);
     PFP_HIP(c, hipMemsetAsync(gfl, 0, dsize, c->stream));
-    ea.s_g0 = s_g0;
+    ea.s_g0 = s_g0; ea.gk = gk; ea.cnt = cnt;
     PFP_LAUNCH(c, K_EMIT_COUNT, dsize * (30 + sizeof(EBT)), (k_emit_slots<EBT>), nblocks(dsize, BLOCK), ea, cnt, d_hard, (uint32_t *)ea.s_sl, (uint32_t *)ea.s_fb, (uint8_t *)ea.s_fl, (uint8_t *)ea.s_pc, s_g0, gk, gfl);
     static const long big_members = getenv("PFP_BIG_GROUP_MEMBERS") ? atol(getenv("PFP_BIG_GROUP_MEMBERS")) : (long)BIG_GROUP_MEMBERS;   // < 0: never
-    if (big_members >= 0) PFP_LAUNCH(c, K_EMIT_COUNT, dsize * 14, (k_big_mark<EBT>), nblocks(dsize, BLOCK), (const EBT *)cnt, (const uint32_t *)s_g0, (const uint32_t *)gk, (const uint8_t *)gfl, dsize, (uint32_t)big_members, (uint8_t *)ea.s_fl, d_hard + 1);
+    PFP_LAUNCH(c, K_EMIT_COUNT, dsize * 14, (k_big_mark<EBT>), nblocks(dsize, BLOCK), (const EBT *)cnt, (const uint32_t *)s_g0, (const uint32_t *)gk, (const uint8_t *)gfl, dsize, big_members >= 0 ? (uint32_t)big_members : 0xFFFFFFFFu, (uint8_t *)ea.s_fl, d_hard + 1);
     PFP_TRY((device_scan<EBT, 0>(c, cnt, EB, dsize, d_tot)));
     EBT tot = 0; unsigned long long hardrows = 0, hh[2] = {0, 0};
     PFP_HIP(c, hipMemcpyAsync(hh, d_hard, 16, hipMemcpyDeviceToHost, c->stream));

@@ -43,7 +43,7 @@ _libs = {}
 
 
 def load_library(path=None):
-    path = os.path.abspath(path or DEFAULT_LIB)
+    path = os.path.abspath(path or os.environ.get("PFBWT_HIP_LIB") or DEFAULT_LIB)   # PFBWT_HIP_LIB: another build of the same library
     if path in _libs:
         return _libs[path]
     if not os.path.exists(path):
