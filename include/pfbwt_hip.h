@@ -116,9 +116,14 @@ int pfp_bwt_load(pfp_ctx *ctx, const uint8_t *dict, uint64_t dsize, const void *
 int pfp_bwt_build(pfp_ctx *ctx, int want_sa, int want_rssa, pfp_bwt_sizes *out);
 /* Multi-GPU emission: every rank holds the same parse state (after pfp_merge_shards + pfp_parse_bwt) and emits
  * only output rows [nout*slice/nslices, nout*(slice+1)/nslices).  out->r counts the runs that START in the slice
- * (the sum over slices is r); pfp_bwt_get / pfp_bwt_device_ptrs then refer to the slice (slice_rows entries). */
-int pfp_bwt_build_slice(pfp_ctx *ctx, int want_sa, int slice, int nslices, pfp_bwt_sizes *out, uint64_t *slice_begin, uint64_t *slice_rows);
-/* copy results to host (NULL skips): bwt nout bytes; sa nout U-wide; ssa/esa 2*r U-wide each */
+ * (the sum over slices is r); pfp_bwt_get / pfp_bwt_device_ptrs then refer to the slice (slice_rows entries).
+ * want_rssa: the slice's part of the run samples (src/pfbwt-f.cpp:306-315, 325-328) -- out->r (row, sa) pairs for the
+ * run starts in the slice and *esa_pairs pairs for the run ends they imply (the row in front of every run start, which
+ * for the first start of a slice > 0 lies in the previous slice, plus the last row of the output in the last slice).
+ * Concatenated over the slices in order they are the reference's .ssa / .esa files; no rank needs another rank's data. */
+int pfp_bwt_build_slice(pfp_ctx *ctx, int want_sa, int want_rssa, int slice, int nslices, pfp_bwt_sizes *out,
+                        uint64_t *slice_begin, uint64_t *slice_rows, uint64_t *esa_pairs);
+/* copy results to host (NULL skips): bwt nout bytes; sa nout U-wide; ssa 2*r, esa 2*r (slices: 2*esa_pairs) U-wide */
 int pfp_bwt_get(pfp_ctx *ctx, uint8_t *bwt, void *sa, void *ssa, void *esa);
 /* device pointers of the same results (valid until the next pfp_* call that rebuilds them) */
 int pfp_bwt_device_ptrs(pfp_ctx *ctx, const void **d_bwt, const void **d_sa, const void **d_ssa, const void **d_esa);

@@ -91,7 +91,7 @@ struct pfp_ctx {
     uint64_t nrows = 0;
     uint8_t *d_bwlast = nullptr; uint32_t *d_ilist = nullptr; uint64_t *d_bwsai = nullptr;
     // --- BWT results
-    uint64_t nout = 0, runs = 0, easy = 0, hard = 0, slice_begin = 0, slice_rows = 0;
+    uint64_t nout = 0, runs = 0, esa_pairs = 0, easy = 0, hard = 0, slice_begin = 0, slice_rows = 0;
     uint8_t *d_bwt = nullptr; void *d_sa = nullptr; void *d_ssa = nullptr; void *d_esa = nullptr;
     bool have_sa = false, have_rssa = false;
     size_t lo_after_parse = 0, lo_after_pbwt = 0;

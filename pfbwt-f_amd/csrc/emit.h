@@ -102,7 +102,7 @@ struct EmitArgs {
     uint64_t w0, w1;        // output positions this launch may write: [w0, w1) -> buffer index pos - w0 (multi-GPU slices)
 };
 constexpr uint8_t SF_MULTI = 1, SF_FULL = 2, SF_BIG = 4, SF_GFULL = 8;   // GFULL: some member of the group is a whole word
-constexpr uint32_t BIG_GROUP_MEMBERS = 8;   // groups with more members than this take the sort route
+constexpr uint32_t BIG_GROUP_MEMBERS = 64;  // groups with more members than this take the sort route (measured: below ~64 ranking is faster)
 // posinfo[x] = { word id of dictionary offset x | 4-bit code of D[x-1] << 28 , class-head slot of x }: one 8-byte
 // gather per slot instead of three separate random reads (wordid, grank, D[x-1])
 constexpr uint32_t WID_MASK = 0x0FFFFFFFu;

@@ -64,7 +64,25 @@ __device__ __forceinline__ uint32_t pack16(const uint4 &q, bool ntoa, uint32_t *
 // One thread = 16 consecutive bases (one 16-byte load).  Writes the normalised bytes back, one
 // 16-bit trigger mask per thread and the trigger count of the workgroup.
 // X must be 16-byte aligned with capacity rounded up to the grid; positions >= n are ignored.
-__global__ __launch_bounds__(BLOCK) void k_trigger_scan(uint8_t *X, uint64_t n, int w, uint64_t p, uint64_t kmask, int ntoa,
+// The trigger test h % p == 0 (pfparser.hpp:347) is done without a division: with p = 2^k * d (d odd) and
+// dinv = d^-1 mod 2^64, h is a multiple of p exactly when rotr64(h * dinv, k) <= (2^64 - 1) / p.
+struct DivTest { uint64_t dinv, limit; int k; };
+inline DivTest make_divtest(uint64_t p)
+{
+    DivTest t; t.k = 0;
+    uint64_t d = p;
+    while (!(d & 1)) { d >>= 1; ++t.k; }
+    uint64_t x = d;                                    // Newton: 3 correct bits -> 6 -> 12 -> 24 -> 48 -> 96
+    for (int i = 0; i < 5; ++i) x *= 2 - d * x;
+    t.dinv = x; t.limit = ~0ULL / p;
+    return t;
+}
+__device__ __forceinline__ bool divisible(uint64_t h, const DivTest &t)
+{
+    const uint64_t v = h * t.dinv;
+    return (t.k ? ((v >> t.k) | (v << (64 - t.k))) : v) <= t.limit;
+}
+__global__ __launch_bounds__(BLOCK) void k_trigger_scan(uint8_t *X, uint64_t n, int w, DivTest p, uint64_t kmask, int ntoa,
                                                         uint16_t *mask16, uint64_t *blockcnt, unsigned long long *err_pos)
 {
     __shared__ uint32_t pk[BLOCK + 2];
@@ -106,7 +124,7 @@ __global__ __launch_bounds__(BLOCK) void k_trigger_scan(uint8_t *X, uint64_t n, 
         const uint64_t pos = base + b;
         const uint64_t h = wang_hash(kmer & kmask);
         // pfparser.hpp:347: pos_ > w  <=>  pos >= w (pos_ = pos + 1 at the test)
-        if (pos < n && pos >= (uint64_t)w && (h % p) == 0) trig |= 1u << b;
+        if (pos < n && pos >= (uint64_t)w && divisible(h, p)) trig |= 1u << b;
     }
     mask16[t] = (uint16_t)trig;
     uint32_t tot;

@@ -55,7 +55,7 @@ static int ensure_text(pfp_ctx *c, uint64_t need_n)
 
 static void reset_results(pfp_ctx *c)
 {
-    c->stage = 0; c->n = 0; c->m = c->dwords = c->dsize = 0; c->nrows = 0; c->nout = c->runs = 0;
+    c->stage = 0; c->n = 0; c->m = c->dwords = c->dsize = 0; c->nrows = 0; c->nout = c->runs = c->esa_pairs = 0;
     c->gsa_valid = false; c->d_wrank = nullptr; c->d_bwt = nullptr; c->d_sa = c->d_ssa = c->d_esa = nullptr;
     c->d_bwlast = nullptr; c->d_ilist = nullptr; c->d_bwsai = nullptr;
     c->arena.reset();
@@ -358,7 +358,7 @@ int pfp_parse_finalize(pfp_ctx *c, pfp_parse_sizes *out)
     PFP_HIP(c, hipMemsetAsync(d_err, 0xff, 8, c->stream));
     PFP_HIP(c, hipMemsetAsync(d_u32, 0, 32, c->stream));
     const uint64_t kmask = (w == 32) ? 0ULL : ((1ULL << (2 * w)) - 1ULL);   // hash.hpp:26 (w == 32: observed x86 value)
-    PFP_LAUNCH(c, K_TRIGGER_SCAN, n * 2 + n / 8, k_trigger_scan, gts, X, n, w, c->p, kmask, (int)((c->flags & PFP_FLAG_NON_ACGT_TO_A) != 0), mask16, blockcnt, d_err);
+    PFP_LAUNCH(c, K_TRIGGER_SCAN, n * 2 + n / 8, k_trigger_scan, gts, X, n, w, make_divtest(c->p), kmask, (int)((c->flags & PFP_FLAG_NON_ACGT_TO_A) != 0), mask16, blockcnt, d_err);
     PFP_TRY((device_scan<uint64_t, 0>(c, blockcnt, blockcnt, gts, blockcnt + gts)));
     uint64_t ntrig = 0; unsigned long long herr = 0;
     PFP_HIP(c, hipMemcpyAsync(&herr, d_err, 8, hipMemcpyDeviceToHost, c->stream));
@@ -778,8 +778,9 @@ template <typename SAT, typename EBT> static int emit_and_sample(pfp_ctx *c, Emi
         if (cap > nrows) cap = nrows;
         if (const char *e = getenv("PFP_SAMPLE_CAP")) { const uint64_t lim = (uint64_t)atoll(e); if (lim < cap) cap = lim; }   // tests: force the fallback
         SAT *samp = nullptr;
-        if (cap) PFP_ALLOC_LO(c, samp, SAT, 4 * cap);
+        if (cap) PFP_ALLOC_LO(c, samp, SAT, 4 * cap + 4);
         SAT *ssa = samp, *esa = samp ? samp + 2 * cap : nullptr;
+        SAT *esa_w = esa ? esa + 2 * lead : nullptr;      // slices > 0: the first run start of the slice closes a run of the previous slice
         uint64_t run_base = 0; bool overflow = cap == 0;
         for (uint64_t ch = 0; ch < nchunks; ++ch) {
             const uint64_t cs = s0 + ch * chunk_rows, ce = (cs + chunk_rows < s1) ? cs + chunk_rows : s1, rows = ce - cs;
@@ -793,10 +794,10 @@ template <typename SAT, typename EBT> static int emit_and_sample(pfp_ctx *c, Emi
             if (!overflow && run_base + rc > cap) overflow = true;
             if (!overflow)
                 PFP_LAUNCH(c, K_SAMPLES, rows + (uint64_t)rc * (32 + 4 * sizeof(SAT)), (k_samples_tile<SAT, EBT>), ntiles, ea, (const uint8_t *)bw, rows, (int)cl, (const uint32_t *)tilebase, (const SAT *)nullptr,
-                           (const uint32_t *)(qtmp + cl), cs, run_base, total, ce == total ? run_base + rc : (uint64_t)0, ssa, esa);
+                           (const uint32_t *)(qtmp + cl), cs, run_base, total, ce == total ? run_base + rc : (uint64_t)0, ssa, esa_w);
             run_base += rc;
         }
-        c->runs = run_base;
+        c->runs = run_base; c->esa_pairs = run_base - (s0 == 0 ? 1 : 0) + (s1 == total ? 1 : 0);
         c->arena.release_hi(hi_mark);
         if (!overflow) { c->d_ssa = ssa; c->d_esa = esa; return PFP_OK; }
         c->arena.release_lo(lo_mark);      // fall through: BWT bytes are complete, samples are redone with exact sizes
@@ -815,14 +816,15 @@ template <typename SAT, typename EBT> static int emit_and_sample(pfp_ctx *c, Emi
         unsigned long long r = 0;
         PFP_HIP(c, hipMemcpyAsync(&r, d_runs, 8, hipMemcpyDeviceToHost, c->stream));
         PFP_HIP(c, hipStreamSynchronize(c->stream));
-        c->runs = r;
+        c->runs = r; c->esa_pairs = r - (s0 == 0 ? 1 : 0) + (s1 == total ? 1 : 0);
     }
     }
-    if (want_rssa) {   // .ssa / .esa samples (pfbwt-f.cpp:306-315, 325-328); only with nslices == 1
+    if (want_rssa) {   // .ssa / .esa samples (pfbwt-f.cpp:306-315, 325-328) of the runs that start in this slice
         const uint64_t r = c->runs;
         SAT *ssa, *esa;
-        PFP_ALLOC_LO(c, ssa, SAT, 2 * r); PFP_ALLOC_LO(c, esa, SAT, 2 * r);
+        PFP_ALLOC_LO(c, ssa, SAT, 2 * r + 2); PFP_ALLOC_LO(c, esa, SAT, 2 * r + 4);
         c->d_ssa = ssa; c->d_esa = esa;
+        SAT *esa_w = esa + 2 * lead;
         const uint64_t maxrows = nchunks == 1 ? nrows : chunk_rows;
         const uint64_t maxtiles = nblocks(maxrows, RUN_TILE);
         uint32_t *tilecnt, *tilebase, *d_cnt, *qtmp = nullptr;
@@ -839,7 +841,7 @@ template <typename SAT, typename EBT> static int emit_and_sample(pfp_ctx *c, Emi
             PFP_TRY((device_scan<uint32_t, 0>(c, tilecnt, tilebase, ntiles, d_cnt)));
             uint32_t rc = 0; PFP_TRY(d2h_u32(c, d_cnt, &rc));
             PFP_LAUNCH(c, K_SAMPLES, rows + (uint64_t)rc * (32 + 4 * sizeof(SAT)), (k_samples_tile<SAT, EBT>), ntiles, ea, (const uint8_t *)bw, rows, (int)cl, (const uint32_t *)tilebase,
-                       sabuf ? (const SAT *)(sabuf + (cs - (s0 - lead))) : (const SAT *)nullptr, (const uint32_t *)(sabuf ? nullptr : qtmp + cl), cs, run_base, total, r, ssa, esa);
+                       sabuf ? (const SAT *)(sabuf + (cs - (s0 - lead))) : (const SAT *)nullptr, (const uint32_t *)(sabuf ? nullptr : qtmp + cl), cs, run_base, total, ce == total ? r : (uint64_t)0, ssa, esa_w);
             run_base += rc;
         }
         if (run_base != r) return PFP_E_CORRUPT;
@@ -882,7 +884,7 @@ template <typename EBT> static int emit_stage(pfp_ctx *c, EmitArgs ea, int want_
 
 static int bwt_build_impl(pfp_ctx *c, int want_sa, int want_rssa, int slice, int nslices, pfp_bwt_sizes *out)
 {
-    if (!c || nslices < 1 || slice < 0 || slice >= nslices || (want_rssa && nslices > 1)) return PFP_E_ARG;
+    if (!c || nslices < 1 || slice < 0 || slice >= nslices) return PFP_E_ARG;
     if (c->stage < 2) return PFP_E_STATE;
     if ((want_sa || want_rssa) && !c->d_bwsai) return PFP_E_STATE;
     PFP_HIP(c, hipSetDevice(c->device));
@@ -924,12 +926,13 @@ static int bwt_build_impl(pfp_ctx *c, int want_sa, int want_rssa, int slice, int
 }
 
 int pfp_bwt_build(pfp_ctx *c, int want_sa, int want_rssa, pfp_bwt_sizes *out) { return bwt_build_impl(c, want_sa, want_rssa, 0, 1, out); }
-int pfp_bwt_build_slice(pfp_ctx *c, int want_sa, int slice, int nslices, pfp_bwt_sizes *out, uint64_t *slice_begin, uint64_t *slice_rows)
+int pfp_bwt_build_slice(pfp_ctx *c, int want_sa, int want_rssa, int slice, int nslices, pfp_bwt_sizes *out, uint64_t *slice_begin, uint64_t *slice_rows, uint64_t *esa_pairs)
 {
-    int rc = bwt_build_impl(c, want_sa, 0, slice, nslices, out);
+    int rc = bwt_build_impl(c, want_sa, want_rssa, slice, nslices, out);
     if (rc != PFP_OK) return rc;
     if (slice_begin) *slice_begin = c->slice_begin;
     if (slice_rows) *slice_rows = c->slice_rows;
+    if (esa_pairs) *esa_pairs = c->esa_pairs;
     return PFP_OK;
 }
 
@@ -942,7 +945,7 @@ int pfp_bwt_get(pfp_ctx *c, uint8_t *bwt, void *sa, void *ssa, void *esa)
     if (bwt) PFP_HIP(c, hipMemcpy(bwt, c->d_bwt, c->slice_rows, hipMemcpyDeviceToHost));
     if (sa) { if (!c->d_sa) return PFP_E_STATE; PFP_HIP(c, hipMemcpy(sa, c->d_sa, c->slice_rows * U, hipMemcpyDeviceToHost)); }
     if (ssa) { if (!c->d_ssa) return PFP_E_STATE; PFP_HIP(c, hipMemcpy(ssa, c->d_ssa, c->runs * 2 * U, hipMemcpyDeviceToHost)); }
-    if (esa) { if (!c->d_esa) return PFP_E_STATE; PFP_HIP(c, hipMemcpy(esa, c->d_esa, c->runs * 2 * U, hipMemcpyDeviceToHost)); }
+    if (esa) { if (!c->d_esa) return PFP_E_STATE; PFP_HIP(c, hipMemcpy(esa, c->d_esa, c->esa_pairs * 2 * U, hipMemcpyDeviceToHost)); }
     return PFP_OK;
 }
 

@@ -50,7 +50,7 @@ def allgather_shards(ctx, device, group=None):
     return views, recv
 
 
-def sharded_build(ctx, feed_local, w, device, sa=True, group=None):
+def sharded_build(ctx, feed_local, w, device, sa=True, rssa=False, group=None):
     """SPMD build over the ranks of `group`.
     1. every rank parses its own run of whole sequences (rank r > 0 with the w 'A's of the previous shard as context);
     2. ONE all-gather moves every rank's dictionary + parse to every rank;
@@ -67,5 +67,5 @@ def sharded_build(ctx, feed_local, w, device, sa=True, group=None):
     sz = ctx.merge_shards(views)     # the local parse is consumed through its copy in `keep`
     del keep, views
     ctx.parse_bwt()
-    b, begin, rows = ctx.bwt_build_slice(rank, world, sa=sa)
+    b, begin, rows = ctx.bwt_build_slice(rank, world, sa=sa, rssa=rssa)
     return sz, b, begin, rows

@@ -68,7 +68,7 @@ def load_library(path=None):
     L.pfp_parse_bwt_get.argtypes = [vp, vp, vp, vp]
     L.pfp_bwt_load.argtypes = [vp, vp, u64, vp, u64, vp, vp, vp, u64, u64]
     L.pfp_bwt_build.argtypes = [vp, i32, i32, C.POINTER(BwtSizes)]
-    L.pfp_bwt_build_slice.argtypes = [vp, i32, i32, i32, C.POINTER(BwtSizes), C.POINTER(u64), C.POINTER(u64)]
+    L.pfp_bwt_build_slice.argtypes = [vp, i32, i32, i32, i32, C.POINTER(BwtSizes), C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
     L.pfp_bwt_get.argtypes = [vp, vp, vp, vp, vp]
     L.pfp_bwt_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.pfp_shard_view_get.argtypes = [vp, C.POINTER(ShardView)]
@@ -182,21 +182,22 @@ class PfpContext:
     def bwt_build(self, sa=True, rssa=False):
         b = BwtSizes()
         self._check(self.L.pfp_bwt_build(self.h, 1 if sa else 0, 1 if rssa else 0, C.byref(b)))
-        self.bsizes, self._want, self._rows = b, (bool(sa), bool(rssa)), b.nout
+        self.bsizes, self._want, self._rows, self.esa_pairs = b, (bool(sa), bool(rssa)), b.nout, b.r
         return b
 
-    def bwt_build_slice(self, slice_index, nslices, sa=True):
-        """multi-GPU emission: this context emits only its slice of the output rows; returns (sizes, begin, rows)"""
-        b = BwtSizes(); beg, rows = C.c_uint64(0), C.c_uint64(0)
-        self._check(self.L.pfp_bwt_build_slice(self.h, 1 if sa else 0, int(slice_index), int(nslices), C.byref(b), C.byref(beg), C.byref(rows)))
-        self.bsizes, self._want, self._rows = b, (bool(sa), False), rows.value
+    def bwt_build_slice(self, slice_index, nslices, sa=True, rssa=False):
+        """multi-GPU emission: this context emits only its slice of the output rows; returns (sizes, begin, rows).
+        rssa: also the slice's part of the run samples (b.r ssa pairs, self.esa_pairs esa pairs; see include/pfbwt_hip.h)"""
+        b = BwtSizes(); beg, rows, ep = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        self._check(self.L.pfp_bwt_build_slice(self.h, 1 if sa else 0, 1 if rssa else 0, int(slice_index), int(nslices), C.byref(b), C.byref(beg), C.byref(rows), C.byref(ep)))
+        self.bsizes, self._want, self._rows, self.esa_pairs = b, (bool(sa), bool(rssa)), rows.value, ep.value
         return b, beg.value, rows.value
 
     def bwt_get(self):
         b = self.bsizes
         sa, rssa = self._want
         out = {"bwt": np.empty(self._rows, np.uint8), "sa": np.empty(self._rows, self.udt) if sa else None,
-               "ssa": np.empty(2 * b.r, self.udt) if rssa else None, "esa": np.empty(2 * b.r, self.udt) if rssa else None}
+               "ssa": np.empty(2 * b.r, self.udt) if rssa else None, "esa": np.empty(2 * getattr(self, "esa_pairs", b.r), self.udt) if rssa else None}
         self._check(self.L.pfp_bwt_get(self.h, _ptr(out["bwt"]), _ptr(out["sa"]), _ptr(out["ssa"]), _ptr(out["esa"])))
         return out
 

@@ -108,12 +108,34 @@ def sliced_emission(factory, seqs, w, p, U, nslices):
     return np.concatenate(bwt), np.concatenate(sa), r
 
 
+def sliced_samples(factory, seqs, w, p, U, nslices, ref, sa):
+    """-r over slices: every slice's ssa / esa pairs, concatenated in slice order, are the reference's .ssa / .esa"""
+    parts = {"bwt": [], "ssa": [], "esa": []}
+    r = 0
+    for sl in range(nslices):
+        c = factory(w=w, p=p, u64=(U == 8), sai=True)
+        for s in seqs:
+            c.feed(s, True)
+        c.finalize(); c.parse_bwt()
+        b, beg, rows = c.bwt_build_slice(sl, nslices, sa=sa, rssa=True)
+        o = c.bwt_get(); c.close()
+        assert len(o["ssa"]) == 2 * b.r
+        for k in parts:
+            parts[k].append(o[k])
+        r += b.r
+    res = {k: np.concatenate(v) for k, v in parts.items()}
+    res["r"] = r
+    assert compare(res, ref, U, names=("bwt", "ssa", "esa")) == [], (nslices, sa)
+
+
 def test_sliced_emission_emu(emu_factory):
     seqs = synth(5, 4000, 3)
     ref = oracle_run(seqs, w=4, p=7, U=4)       # many multi-word groups straddle the slice boundaries
     for ns in (2, 5):
         bwt, sa, r = sliced_emission(emu_factory, seqs, 4, 7, 4, ns)
         assert np.array_equal(bwt, ref["bwt"]) and np.array_equal(sa.astype(np.uint64), ref["sa"] & np.uint64(0xFFFFFFFF)) and r == ref["r"]
+    sliced_samples(emu_factory, seqs, 4, 7, 4, 3, ref, sa=False)
+    sliced_samples(emu_factory, seqs, 4, 7, 4, 2, ref, sa=True)
 
 
 @pytest.mark.gpu
@@ -125,6 +147,8 @@ def test_sliced_emission_gpu(gpu_ctx_factory):
             bwt, sa, r = sliced_emission(gpu_ctx_factory, seqs, w, p, U, ns)
             want = ref["sa"] & np.uint64(0xFFFFFFFF) if U == 4 else ref["sa"]
             assert np.array_equal(bwt, ref["bwt"]) and np.array_equal(sa.astype(np.uint64), want) and r == ref["r"]
+        for ns, sa in ((2, False), (7, False), (3, True)):
+            sliced_samples(gpu_ctx_factory, seqs, w, p, U, ns, ref, sa)
 
 
 @pytest.mark.gpu
