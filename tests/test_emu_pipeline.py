@@ -83,9 +83,9 @@ if "PFP_BIG_GROUP_MEMBERS" in os.environ:       # a small "panel": many words sh
         haps.append("".join(b).encode())
     cases.append((haps, 4, 11))
 for seqs, w, p in cases:
-    for U in (4, 8):
+    for U in (8, 4):
         ref = oracle_run(seqs, w=w, p=p, U=U)
-        for sa, rssa in ((True, True), (False, True), (True, False), (False, False)):
+        for sa, rssa in (((True, True), (False, True), (True, False), (False, False)) if U == 8 else ((True, True), (False, True))):
             res = engine_run(F, seqs, w, p, U, sa=sa, rssa=rssa)
             names = ["bwt"] + (["sa"] if sa else []) + (["ssa", "esa"] if rssa else [])
             bad = compare(res, ref, U, names=tuple(names))
@@ -96,7 +96,7 @@ print("variant ok")
 
 @pytest.mark.parametrize("env", [{"PFP_FORCE_WIDE_ROWS": "1"}, {"PFP_EMIT_CHUNK_ROWS": "777"}, {"PFP_FORCE_WIDE_ROWS": "1", "PFP_EMIT_CHUNK_ROWS": "1000"},
                                  {"PFP_EMIT_CHUNK_ROWS": "777", "PFP_SAMPLE_CAP": "40"},
-                                 {"PFP_BIG_GROUP_MEMBERS": "1"}, {"PFP_BIG_GROUP_MEMBERS": "2", "PFP_EMIT_CHUNK_ROWS": "777"},
+                                 {"PFP_BIG_GROUP_MEMBERS": "1"}, {"PFP_BIG_GROUP_MEMBERS": "2", "PFP_EMIT_CHUNK_ROWS": "5000"},
                                  {"PFP_BIG_GROUP_MEMBERS": "-1"}])
 def test_emu_wide_rows_and_chunked_emission(emu_factory, env):
     """The code paths taken by texts of 2^32 bases and more (64-bit row counters, emission in windows of rows, run

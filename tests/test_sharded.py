@@ -78,6 +78,15 @@ if rank == 0:
     bad = compare(res, oracle_run(seqs, w=6, p=11, U=4), 4, names=("dict", "occ", "parse", "last", "sai", "bwlast", "ilist", "bwsai", "bwt", "sa"))
     ok = 0 if bad else 1
     if bad: print("MISMATCH", bad, flush=True)
+# the same build again in -r mode (what bench.py runs by default): run samples stay sliced over the ranks
+sz, b, begin, rows = pfbwt_dist.sharded_build(ctx, lambda c: [c.feed(s, True) for s in mine], 6, torch.device("cpu"), sa=False, rssa=True)
+o = ctx.bwt_get()
+dist.all_gather_object(parts, (begin, rows, int(b.r), o["bwt"], o["ssa"], o["esa"]))
+if rank == 0:
+    parts.sort(key=lambda t: t[0])
+    res = {"r": sum(t[2] for t in parts), "bwt": np.concatenate([t[3] for t in parts]), "ssa": np.concatenate([t[4] for t in parts]), "esa": np.concatenate([t[5] for t in parts])}
+    bad = compare(res, oracle_run(seqs, w=6, p=11, U=4), 4, names=("bwt", "ssa", "esa"))
+    if bad: ok = 0; print("MISMATCH -r", bad, flush=True)
 t = torch.tensor([ok]); dist.all_reduce(t, op=dist.ReduceOp.MIN)
 dist.barrier(); dist.destroy_process_group()
 sys.exit(0 if int(t) == 1 else 1)
