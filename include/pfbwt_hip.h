@@ -74,6 +74,9 @@ uint64_t pfp_workspace_needed(pfp_ctx *ctx);
 int pfp_parse_feed(pfp_ctx *ctx, const uint8_t *bases, uint64_t len, int end_of_seq);
 /* same, but the bytes are already in device memory (one record, pad appended by the library) */
 int pfp_parse_feed_device(pfp_ctx *ctx, const void *d_bases, uint64_t len, int end_of_seq);
+/* `count` records of `len` bytes each, record k at d_bases + k*stride (device memory): the same as `count` calls of
+ * pfp_parse_feed_device(.., len, 1), done as one strided copy (a collection of equal-length haplotypes) */
+int pfp_parse_feed_device_batch(pfp_ctx *ctx, const void *d_bases, uint64_t count, uint64_t len, uint64_t stride);
 /* PfParser::finalize pfparser.hpp:484-517 (+ process_phrase :595-601 for every phrase): trigger scan,
  * phrase de-duplication, dictionary sort, ranks, occ, last, sai.  Results stay on the device. */
 int pfp_parse_finalize(pfp_ctx *ctx, pfp_parse_sizes *out);

@@ -438,11 +438,33 @@ template <typename SAT, typename EBT> __global__ __launch_bounds__(BLOCK) void k
                                                                                               uint64_t row_base, uint64_t run_base, uint64_t total_rows, uint64_t total_runs, SAT *ssa, SAT *esa)
 {
     __shared__ uint32_t red[4];
+    __shared__ uint32_t ebl[EMIT_LDS_SLOTS];     // samples-only mode: EB of the slots under this tile's rows, relative to the first
+    __shared__ uint32_t rng[2];
+    const EBT *EB = reinterpret_cast<const EBT *>(a.EB);
+    bool in_lds = false; uint32_t i0 = 0, ns = 0; uint64_t ebase = 0;
+    if (!sa) {   // the slot of a sampled row gives its suffix length: search the tile's slice of EB in LDS, not all of EB
+        const uint64_t b0 = (uint64_t)blockIdx.x * RUN_TILE;
+        const uint64_t first = row_base + b0 - ((row_base + b0) ? 1 : 0);      // includes the row in front of the tile
+        const uint64_t last = row_base + (b0 + RUN_TILE < rows ? b0 + RUN_TILE : rows) - 1;
+        if (threadIdx.x < 2) rng[threadIdx.x] = upper_bound_t<EBT>(EB, (uint32_t)a.dsize, (EBT)(threadIdx.x == 0 ? first : last)) - 1u;
+        __syncthreads();
+        i0 = rng[0]; ns = rng[1] - i0 + 1u; ebase = (uint64_t)EB[i0];
+        in_lds = ns <= (uint32_t)EMIT_LDS_SLOTS && last + 1 - ebase < 0xFFFFFFFFULL;
+        if (in_lds) for (uint32_t t = threadIdx.x; t < ns; t += BLOCK) ebl[t] = (uint32_t)((uint64_t)EB[i0 + t] - ebase);
+        __syncthreads();
+    }
     const uint64_t j0 = ((uint64_t)blockIdx.x * BLOCK + threadIdx.x) * RUN_PER_THREAD;
     uint32_t m = run_mask16(bwt, j0, rows, has_prev), tot;
     const uint32_t ex = block_excl_sum((uint32_t)__popc(m), red, &tot);
     uint64_t k = run_base + tilebase[blockIdx.x] + ex;
-    auto value = [&](uint64_t j) -> SAT { return sa ? *(sa + j) : sa_of_row<SAT, EBT>(a, *(qrow + j), row_base + j); };   // j may be -1 (as uint64) for the row in front
+    auto value = [&](uint64_t j) -> SAT {     // j may be -1 (as uint64) for the row in front
+        if (sa) return *(sa + j);
+        const uint64_t o = row_base + j;
+        if (!in_lds) return sa_of_row<SAT, EBT>(a, *(qrow + j), o);
+        if (o == 0) return (SAT)a.n;
+        const uint32_t slot = i0 + upper_bound_t<uint32_t>(ebl, ns, (uint32_t)(o - ebase)) - 1u;
+        return (SAT)((SAT)a.bwsai[*(qrow + j)] - (SAT)a.s_sl[slot]);
+    };
     while (m) {
         const int b = __ffs((int)m) - 1; m &= m - 1;
         const uint64_t j = j0 + b, o = row_base + j;

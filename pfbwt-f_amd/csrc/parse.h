@@ -183,6 +183,17 @@ __device__ __forceinline__ uint64_t ld8(const uint8_t *p) { uint64_t v; __builti
 constexpr uint32_t LONG_PHRASE = 2048; // phrases longer than this go to the workgroup-per-phrase kernels
 
 // one thread per phrase
+// The digits of the polynomial are the 8-byte little-endian words of the phrase (the last one masked to the bytes that
+// remain), not its bytes: one modular multiplication per 8 bases.  fingerprint = (sum_j word_j * B^(k-1-j)) * B + len.
+__device__ __forceinline__ uint64_t red61(uint64_t v) { const uint64_t r = (v & P61) + (v >> 61); return r >= P61 ? r - P61 : r; }
+__device__ __forceinline__ uint64_t hash_words(const uint8_t *s, uint32_t len, uint64_t B)
+{
+    uint64_t h = 0;
+    uint32_t i = 0;
+    for (; i + 8 <= len; i += 8) h = addmod61(mulmod61(h, B), red61(ld8(s + i)));
+    if (i < len) h = addmod61(mulmod61(h, B), red61(ld8(s + i) & ((1ULL << (8 * (len - i))) - 1ULL)));
+    return h;
+}
 __global__ __launch_bounds__(BLOCK) void k_phrase_hash(const uint8_t *Y, Spans sp, uint64_t m, uint64_t B,
                                                        uint64_t *keys, uint32_t *vals, uint32_t *longlist, uint32_t *nlong)
 {
@@ -191,24 +202,12 @@ __global__ __launch_bounds__(BLOCK) void k_phrase_hash(const uint8_t *Y, Spans s
     tpos_t ys; uint32_t len; phrase_span(sp, j, &ys, &len);
     vals[j] = (uint32_t)j;
     if (len > LONG_PHRASE) { longlist[atomicAdd(nlong, 1u)] = (uint32_t)j; keys[j] = 0; return; }
-    uint64_t h = 0;
-    const uint8_t *s = Y + ys;
-    uint32_t i = 0;
-    for (; i + 8 <= len; i += 8) {
-        uint64_t v = ld8(s + i);
-#pragma unroll
-        for (int b = 0; b < 8; ++b) { h = addmod61(mulmod61(h, B), v & 0xff); v >>= 8; }
-    }
-    if (i < len) {
-        uint64_t v = ld8(s + i);
-        for (; i < len; ++i) { h = addmod61(mulmod61(h, B), v & 0xff); v >>= 8; }
-    }
-    keys[j] = addmod61(mulmod61(h, B), len % P61);
+    keys[j] = addmod61(mulmod61(hash_words(Y + ys, len, B), B), len % P61);
 }
 
 // ---- long phrases (e.g. a 10 Mbp run of N is ONE phrase: wang_hash(0) % 100 != 0) ----
 // A host-built chunk table spreads every long phrase over workgroups of LONG_CHUNK bytes.
-constexpr uint32_t LONG_CHUNK = 16384;
+constexpr uint32_t LONG_CHUNK = 16384;   // a multiple of 8: chunks hold whole fingerprint words
 struct LongChunk { tpos_t a_off, b_off; uint32_t item; uint32_t len; }; // item index, two Y offsets of the chunk, chunk length
 
 // spans of listed phrases: out[2k] = ys, out[2k+1] = len
@@ -235,19 +234,17 @@ __global__ __launch_bounds__(BLOCK) void k_phrase_hash_long(const uint8_t *Y, co
 {
     __shared__ uint64_t part[BLOCK];
     const LongChunk ch = chunks[blockIdx.x];
-    const uint32_t sub = (ch.len + BLOCK - 1) / BLOCK;
+    const uint32_t sub = (((ch.len + BLOCK - 1) / BLOCK) + 7u) & ~7u;   // bytes per thread: whole words
     const uint32_t a = threadIdx.x * sub, b = (a + sub < ch.len) ? a + sub : ch.len;
-    uint64_t h = 0;
-    for (uint32_t i = a; i < b; ++i) h = addmod61(mulmod61(h, B), Y[ch.a_off + i]);
-    part[threadIdx.x] = h;
+    part[threadIdx.x] = a < ch.len ? hash_words(Y + ch.a_off + a, b - a, B) : 0;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const uint64_t Bc = powmod61(B, sub);
+        const uint64_t Bc = powmod61(B, sub / 8);
         uint64_t acc = 0;
         for (uint32_t t = 0; t < BLOCK; ++t) {
             const uint32_t ta = t * sub; if (ta >= ch.len) break;
             const uint32_t tl = (ta + sub < ch.len ? ta + sub : ch.len) - ta;
-            acc = addmod61(mulmod61(acc, tl == sub ? Bc : powmod61(B, tl)), part[t]);
+            acc = addmod61(mulmod61(acc, tl == sub ? Bc : powmod61(B, (tl + 7) / 8)), part[t]);
         }
         partial[blockIdx.x] = acc;
     }
@@ -259,7 +256,7 @@ __global__ __launch_bounds__(BLOCK) void k_phrase_hash_fold(const LongChunk *chu
     const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
     if (k >= nlong) return;
     uint64_t acc = 0;
-    for (uint32_t c = first[k]; c < first[k + 1]; ++c) acc = addmod61(mulmod61(acc, chunks[c].len == LONG_CHUNK ? Bchunk : powmod61(B, chunks[c].len)), partial[c]);
+    for (uint32_t c = first[k]; c < first[k + 1]; ++c) acc = addmod61(mulmod61(acc, chunks[c].len == LONG_CHUNK ? Bchunk : powmod61(B, (chunks[c].len + 7) / 8)), partial[c]);
     keys[longlist[k]] = addmod61(mulmod61(acc, B), (uint64_t)spans[2 * k + 1] % P61);
 }
 // one workgroup per chunk of a long pair: byte compare
@@ -273,24 +270,41 @@ __global__ __launch_bounds__(BLOCK) void k_dedup_long(const uint8_t *Y, const Lo
 
 // After sorting (key, j): head[i] = 1 where a new distinct phrase starts.  Equal fingerprints are
 // verified byte-for-byte against the predecessor; a mismatch (fingerprint collision) raises *collide.
+// DEDUP_LANES lanes share one pair: each reads 8 bytes of both phrases per step, so that a pair of ~100-byte phrases is
+// two coalesced 64-byte reads per phrase instead of a dozen dependent 8-byte reads by one lane.
+constexpr int DEDUP_LANES = 8;
 __global__ __launch_bounds__(BLOCK) void k_dedup_heads(const uint8_t *Y, Spans sp, const uint64_t *keys, const uint32_t *vals,
                                                        uint64_t m, uint32_t *head, uint32_t *longpairs, uint32_t *nlongpairs, uint32_t *collide)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= m) return;
-    if (i == 0 || keys[i] != keys[i - 1]) { head[i] = 1; return; }
-    tpos_t sa_, sb; uint32_t la, lb;
-    phrase_span(sp, vals[i - 1], &sa_, &la);
-    phrase_span(sp, vals[i], &sb, &lb);
-    if (la != lb) { head[i] = 1; atomicAdd(collide, 1u); return; }
-    if (la > LONG_PHRASE) { head[i] = 0; longpairs[atomicAdd(nlongpairs, 1u)] = (uint32_t)i; return; }
-    const uint8_t *a = Y + sa_, *b = Y + sb;
+    const uint64_t i = ((uint64_t)blockIdx.x * BLOCK + threadIdx.x) / DEDUP_LANES;
+    const uint32_t l = threadIdx.x % DEDUP_LANES;
+    bool cmp = false;
+    tpos_t sa_ = 0, sb = 0; uint32_t la = 0, lb = 0;
+    if (i < m) {
+        if (i == 0 || keys[i] != keys[i - 1]) { if (l == 0) head[i] = 1; }
+        else {
+            phrase_span(sp, vals[i - 1], &sa_, &la);
+            phrase_span(sp, vals[i], &sb, &lb);
+            if (la != lb) { if (l == 0) { head[i] = 1; atomicAdd(collide, 1u); } }
+            else if (la > LONG_PHRASE) { if (l == 0) { head[i] = 0; longpairs[atomicAdd(nlongpairs, 1u)] = (uint32_t)i; } }
+            else cmp = true;
+        }
+    }
     uint64_t diff = 0;
-    uint32_t k = 0;
-    for (; k + 8 <= la; k += 8) diff |= ld8(a + k) ^ ld8(b + k);
-    if (k < la) diff |= (ld8(a + k) ^ ld8(b + k)) & ((1ULL << (8 * (la - k))) - 1ULL);
-    head[i] = 0;
-    if (diff) { head[i] = 1; atomicAdd(collide, 1u); }
+    if (cmp) {
+        const uint8_t *a = Y + sa_, *b = Y + sb;
+        for (uint32_t k = 8 * l; k < la; k += 8 * DEDUP_LANES) {
+            uint64_t v = ld8(a + k) ^ ld8(b + k);
+            if (la - k < 8) v &= (1ULL << (8 * (la - k))) - 1ULL;
+            diff |= v;
+        }
+    }
+    const unsigned long long bm = __ballot(diff != 0);
+    if (cmp && l == 0) {
+        const bool differ = ((bm >> ((threadIdx.x & 63) / DEDUP_LANES * DEDUP_LANES)) & ((1ULL << DEDUP_LANES) - 1ULL)) != 0;
+        head[i] = differ ? 1u : 0u;
+        if (differ) atomicAdd(collide, 1u);
+    }
 }
 __global__ __launch_bounds__(BLOCK) void k_dedup_ids(const uint32_t *head, uint32_t *ex, uint64_t m)
 {

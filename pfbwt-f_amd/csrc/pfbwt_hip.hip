@@ -164,6 +164,22 @@ static int feed_common(pfp_ctx *c, const void *src, uint64_t len, int end_of_seq
 }
 int pfp_parse_feed(pfp_ctx *c, const uint8_t *bases, uint64_t len, int end_of_seq) { return feed_common(c, bases, len, end_of_seq, hipMemcpyHostToDevice); }
 int pfp_parse_feed_device(pfp_ctx *c, const void *d_bases, uint64_t len, int end_of_seq) { return feed_common(c, d_bases, len, end_of_seq, hipMemcpyDeviceToDevice); }
+int pfp_parse_feed_device_batch(pfp_ctx *c, const void *d_bases, uint64_t count, uint64_t len, uint64_t stride)
+{
+    if (!c || (!d_bases && count && len) || stride < len) return PFP_E_ARG;
+    if (!count) return PFP_OK;
+    if (!len) { for (uint64_t k = 0; k < count; ++k) PFP_TRY(feed_common(c, nullptr, 0, 1, hipMemcpyDeviceToDevice)); return PFP_OK; }
+    PFP_HIP(c, hipSetDevice(c->device));
+    if (c->stage != 0) reset_results(c);
+    const uint64_t pitch = len + (uint64_t)c->w, add = count * pitch;
+    if (c->n + add + (uint64_t)c->w + 64 >= ((c->flags & PFP_FLAG_U64) ? (1ULL << 40) : 0xFFFFFFFFULL)) return PFP_E_TOO_LARGE;
+    PFP_TRY(ensure_text(c, c->n + add + (uint64_t)c->w));
+    uint8_t *dst = c->tb + 16 + c->n;
+    PFP_HIP(c, hipMemcpy2DAsync(dst, (size_t)pitch, d_bases, (size_t)stride, (size_t)len, (size_t)count, hipMemcpyDeviceToDevice, c->stream));
+    PFP_HIP(c, hipMemset2DAsync(dst + len, (size_t)pitch, 'A', (size_t)c->w, (size_t)count, c->stream));   // the w 'A's of pfparser.hpp:335-337
+    c->n += add;
+    return PFP_OK;
+}
 
 // ---- dictionary suffix sort (shared by the parse and the --pfbwt-only path) ---------------------
 static int sort_dict_suffixes(pfp_ctx *c)
@@ -207,7 +223,7 @@ static int hash_long_phrases(pfp_ctx *c, const uint8_t *Y, Spans sp, const uint3
     double bytes = 0; for (auto &t : tab) bytes += t.len;
     PFP_LAUNCH(c, K_PHRASE_HASH_LONG, bytes, k_phrase_hash_long, (unsigned)tab.size(), Y, (const LongChunk *)d_tab, B, d_part);
     PFP_LAUNCH(c, K_MISC, tab.size() * 24, k_phrase_hash_fold, nblocks(nlong, BLOCK), (const LongChunk *)d_tab, (const uint32_t *)d_first, d_longlist, nlong,
-               (const tpos_t *)d_spans, (const uint64_t *)d_part, B, powmod61(B, LONG_CHUNK), keys);
+               (const tpos_t *)d_spans, (const uint64_t *)d_part, B, powmod61(B, LONG_CHUNK / 8), keys);
     PFP_HIP(c, hipStreamSynchronize(c->stream));   // tab / first are host vectors
     c->arena.release_hi(mk);
     return PFP_OK;
@@ -263,7 +279,7 @@ static int dedup_strings(pfp_ctx *c, const uint8_t *Y, Spans sp, uint64_t m, uin
         if (nlong) PFP_TRY(hash_long_phrases(c, Y, sp, longlist, nlong, B, hk0));
         BitRange full = {0, 64};
         PFP_TRY(radix_sort_pairs<uint64_t>(c, hk0, hv0, hk1, hv1, m, &full, 1, &sk, &sv));
-        PFP_LAUNCH(c, K_DEDUP_HEADS, total_bytes + m * 16, k_dedup_heads, gm, Y, sp, (const uint64_t *)sk, (const uint32_t *)sv, m, head, longpairs, d_u32 + 2, d_u32 + 3);
+        PFP_LAUNCH(c, K_DEDUP_HEADS, total_bytes + m * 16, k_dedup_heads, nblocks(m * DEDUP_LANES, BLOCK), Y, sp, (const uint64_t *)sk, (const uint32_t *)sv, m, head, longpairs, d_u32 + 2, d_u32 + 3);
         uint32_t nlp = 0; PFP_TRY(d2h_u32(c, d_u32 + 2, &nlp));
         if (nlp) PFP_TRY(compare_long_pairs(c, Y, sp, sv, longpairs, nlp, d_u32 + 3));
         uint32_t collide = 0; PFP_TRY(d2h_u32(c, d_u32 + 3, &collide));

@@ -68,6 +68,7 @@ def load_library(path=None):
     L.pfp_parse_bwt_get.argtypes = [vp, vp, vp, vp]
     L.pfp_bwt_load.argtypes = [vp, vp, u64, vp, u64, vp, vp, vp, u64, u64]
     L.pfp_bwt_build.argtypes = [vp, i32, i32, C.POINTER(BwtSizes)]
+    L.pfp_parse_feed_device_batch.argtypes = [vp, vp, u64, u64, u64]
     L.pfp_bwt_build_slice.argtypes = [vp, i32, i32, i32, i32, C.POINTER(BwtSizes), C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
     L.pfp_bwt_get.argtypes = [vp, vp, vp, vp, vp]
     L.pfp_bwt_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
@@ -153,6 +154,10 @@ class PfpContext:
         return out
 
     # ---- multi-GPU sharding
+    def feed_device_batch(self, dev_ptr, count, length, stride):
+        """`count` equal-length records that already sit in device memory, `stride` bytes apart"""
+        self._check(self.L.pfp_parse_feed_device_batch(self.h, C.c_void_p(int(dev_ptr)), int(count), int(length), int(stride)))
+
     def feed_left_context(self, w):
         """shard r > 0: the w 'A's that end the previous shard (pfparser.hpp:335-337)"""
         self.feed(b"A" * w, end_of_seq=False)

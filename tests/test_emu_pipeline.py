@@ -28,6 +28,37 @@ def test_emu_pipeline_matches_oracle_and_reference_digests(emu_factory, name, U)
         assert sha(img) == mf[k]["sha256"], k
 
 
+def test_emu_long_phrases(emu_factory):
+    """runs of N longer than the long-phrase threshold (2048): chunked fingerprints, chunked pair verification, the run
+    round of the suffix sorter; the same long phrase twice, and one of a different length"""
+    rng = np.random.default_rng(3)
+    rnd = lambda n: bytes(rng.choice(list(b"ACGT"), n).astype(np.uint8))
+    a = rnd(3000) + b"N" * 40001 + rnd(2500)
+    seqs = [a, a, rnd(1200) + b"N" * 20000 + rnd(900)]
+    ref = oracle_run(seqs, w=10, p=100, U=4)
+    res = engine_run(emu_factory, seqs, 10, 100, 4)
+    assert compare(res, ref, 4) == []
+
+
+def test_emu_feed_device_batch(emu_factory):
+    """pfp_parse_feed_device_batch == one pfp_parse_feed_device per record (the emulator's "device" memory is host memory)"""
+    rng = np.random.default_rng(8)
+    base = rng.choice(list(b"ACGT"), 3000).astype(np.uint8)
+    haps = np.stack([base.copy() for _ in range(5)])
+    for h in range(1, 5):
+        haps[h, rng.integers(0, 3000, 25)] = rng.choice(list(b"ACGT"), 25)
+    pad = np.zeros((5, 3100), np.uint8); pad[:, :3000] = haps            # stride > len
+    a = emu_factory(w=6, p=13, sai=True); b = emu_factory(w=6, p=13, sai=True)
+    a.feed_device_batch(pad.ctypes.data, 5, 3000, 3100)
+    for h in range(5):
+        b.feed_device(haps[h].ctypes.data, 3000, True)
+    sa_, sb = a.finalize(), b.finalize()
+    assert (sa_.n, sa_.m, sa_.dwords, sa_.dsize) == (sb.n, sb.m, sb.dwords, sb.dsize) == (5 * 3006, sb.m, sb.dwords, sb.dsize)
+    pa, pb = a.parse_get(), b.parse_get()
+    assert all(np.array_equal(pa[k], pb[k]) for k in pa)
+    a.close(); b.close()
+
+
 def test_emu_pfbwt_only_path(emu_factory):
     """--pfbwt-only: stage 2 from the on-disk arrays alone (pfp_bwt_load)."""
     man, recs = golden_case("w4p7")
