@@ -94,6 +94,8 @@ struct EmitArgs {
     const uint32_t *s_g0;   // per slot: first slot of its group of equal suffixes
     const uint32_t *gk;     // per group head slot: number of members
     const void *cnt;        // per slot: rows it produces (EBT)
+    const uint4 *sinfo;     // per slot, packed for the row kernel: { s_fb, rows, s_g0, members of the group (24 bits) | SF_* flags << 24 }
+    const uint32_t *tile_slot;  // slot that holds output row b * EMIT_TILE, b = 0 .. ceil(nout / EMIT_TILE) (last entry: dsize - 1)
     // rows of groups with many members are not ranked one by one: they are collected here and sorted by (group, q)
     uint64_t *big_keys; uint32_t *big_vals; unsigned long long *big_count;  // big_count[1] != 0: list overflow
     uint64_t big_cap, big_total;
@@ -185,19 +187,37 @@ __device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t *a, uint32_t 
 // tens of members and thousands of rows): ranking every row in every other member's ilist costs O(members) bisections
 // per row.  Their rows are instead collected as (group head slot, q) keys, sorted, and placed by their index inside
 // the group.  Groups with a whole-word member keep the ranking route (reference quirk handling lives there).
-template <typename EBT> __global__ __launch_bounds__(BLOCK) void k_big_mark(const EBT *cnt, const uint32_t *s_g0, const uint32_t *gk, const uint8_t *gfl, uint64_t dsize, uint32_t min_members, uint8_t *s_fl, unsigned long long *big_rows)
+template <typename EBT> __global__ __launch_bounds__(BLOCK) void k_big_mark(const EBT *cnt, const uint32_t *s_g0, const uint32_t *gk, const uint8_t *gfl, const uint32_t *s_fb, uint64_t dsize, uint32_t min_members, uint8_t *s_fl, uint4 *sinfo, unsigned long long *big_rows)
 {
     __shared__ unsigned long long red[4];
     const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     unsigned long long mine = 0;
-    if (i < dsize && (s_fl[i] & SF_MULTI)) {
+    if (i < dsize) {
+        uint8_t fl = s_fl[i];
         const uint32_t g0 = s_g0[i];
-        if (gfl[g0]) s_fl[i] |= SF_GFULL;
-        else if (gk[g0] > min_members) { s_fl[i] |= SF_BIG; mine = (unsigned long long)cnt[i]; }
+        uint32_t k = 1;
+        if (fl & SF_MULTI) {
+            k = gk[g0];
+            if (gfl[g0]) fl |= SF_GFULL;
+            else if (k > min_members) { fl |= SF_BIG; mine = (unsigned long long)cnt[i]; }
+            s_fl[i] = fl;
+        }
+        sinfo[i] = make_uint4(s_fb[i], (uint32_t)cnt[i], g0, (k < 0xFFFFFFu ? k : 0xFFFFFFu) | ((uint32_t)fl << 24));
     }
     unsigned long long tot;
     (void)block_excl_sum(mine, red, &tot);
     if (threadIdx.x == 0 && tot) atomicAdd(big_rows, tot);
+}
+// PFP_VERBOSE only: rows by (members of their group, rows of their group) in power-of-two buckets
+template <typename EBT> __global__ __launch_bounds__(BLOCK) void k_group_stats(const EBT *cnt, const EBT *EB, const uint32_t *s_g0, const uint32_t *gk, const uint8_t *s_fl, uint64_t dsize, uint64_t nout, unsigned long long *hist /*[8][8]*/)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= dsize || !cnt[i]) return;
+    uint32_t k = 1; uint64_t tg = (uint64_t)cnt[i];
+    if (s_fl[i] & SF_MULTI) { const uint32_t g0 = s_g0[i]; k = gk[g0]; tg = (g0 + k < dsize ? (uint64_t)EB[g0 + k] : nout) - (uint64_t)EB[g0]; }
+    int kb = 0; while (kb < 7 && (2u << kb) <= k) ++kb;          // k: 1, 2-3, 4-7, 8-15, 16-31, 32-63, 64-127, 128+
+    int tb = 0; while (tb < 7 && (1024ull << (2 * tb)) <= tg) ++tb;   // rows: <1K, <4K, <16K, <64K, <256K, <1M, <4M, more
+    atomicAdd(&hist[kb * 8 + tb], (unsigned long long)cnt[i]);
 }
 __global__ __launch_bounds__(BLOCK) void k_big_heads(const uint64_t *keys, uint64_t nb, uint32_t *headidx)
 {
@@ -222,31 +242,57 @@ template <typename SAT, typename EBT> __global__ __launch_bounds__(BLOCK) void k
 
 // Position of a row inside a group without whole-word members: gb + r + the number of occurrences of the OTHER members
 // that precede parse row q (pfbwt.hpp:137-181: the members' ilists are merged by value).  Everything comes from the
-// per-slot arrays (no SA / posinfo / winfo gathers); the bisections of up to four members run interleaved so that their
-// loads are in flight together.
-template <typename EBT> __device__ __forceinline__ uint64_t plain_group_pos(const EmitArgs &a, uint32_t i, uint32_t r, uint32_t q)
+// packed per-slot records (no SA / posinfo / winfo gathers); the bisections of up to four members run interleaved so
+// that their loads are in flight together.
+template <int W> __device__ __forceinline__ uint32_t rank_in_members(const EmitArgs &a, const uint32_t *mem /*W slots, ~0u = none*/, uint32_t q)
 {
-    const EBT *EB = reinterpret_cast<const EBT *>(a.EB), *CN = reinterpret_cast<const EBT *>(a.cnt);
-    const uint32_t g0 = a.s_g0[i], k = a.gk[g0];
-    uint64_t before = 0;
-    for (uint32_t s0 = 0; s0 < k; s0 += 4) {
-        const uint32_t *base[4]; uint32_t lo[4], hi[4];
+    const uint32_t *base[W]; uint32_t lo[W], len[W];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t s = g0 + s0 + j;
-            const bool on = s0 + j < k && s != i;
-            base[j] = a.ilist + (on ? a.s_fb[s] : 0u); lo[j] = 0; hi[j] = on ? (uint32_t)CN[s] : 0u;
-        }
-        while ((lo[0] < hi[0]) | (lo[1] < hi[1]) | (lo[2] < hi[2]) | (lo[3] < hi[3])) {
-            uint32_t v[4], mid[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { mid[j] = lo[j] + ((hi[j] - lo[j]) >> 1); v[j] = lo[j] < hi[j] ? base[j][mid[j]] : 0u; }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) if (lo[j] < hi[j]) { if (v[j] < q) lo[j] = mid[j] + 1; else hi[j] = mid[j]; }
-        }
-        before += (uint64_t)lo[0] + lo[1] + lo[2] + lo[3];
+    for (int j = 0; j < W; ++j) {
+        const uint4 S = mem[j] != ~0u ? a.sinfo[mem[j]] : make_uint4(0, 0, 0, 0);      // one 16-byte load per member: list start and length
+        base[j] = a.ilist + S.x; lo[j] = 0; len[j] = S.y;
     }
-    return (uint64_t)EB[g0] + before + r;
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < W; ++j) any |= len[j] != 0;
+    while (any) {      // number of list entries < q, all W bisections in step
+        uint32_t v[W], half[W];
+#pragma unroll
+        for (int j = 0; j < W; ++j) { half[j] = len[j] >> 1; v[j] = len[j] ? base[j][lo[j] + half[j]] : 0u; }
+        any = false;
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            const bool less = len[j] && v[j] < q;
+            lo[j] = less ? lo[j] + half[j] + 1 : lo[j];
+            len[j] = less ? len[j] - half[j] - 1 : half[j];
+            any |= len[j] != 0;
+        }
+    }
+    uint32_t before = 0;
+#pragma unroll
+    for (int j = 0; j < W; ++j) before += lo[j];
+    return before;
+}
+template <typename EBT> __device__ __forceinline__ uint64_t plain_group_pos(const EmitArgs &a, uint32_t i, uint32_t r, uint32_t q, uint32_t g0, uint32_t k)
+{
+    uint64_t before = 0;
+    if (k == 2) {                     // the common case: one other member, one plain bisection
+        const uint32_t other = (i == g0) ? g0 + 1 : g0;
+        before = rank_in_members<1>(a, &other, q);
+    } else if (k == 3) {
+        uint32_t mem[2]; int c = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 3; ++j) if (g0 + j != i) mem[c++ & 1] = g0 + j;
+        before = rank_in_members<2>(a, mem, q);
+    } else {
+        for (uint32_t s0 = 0; s0 < k; s0 += 4) {
+            uint32_t mem[4];
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) { const uint32_t s = g0 + s0 + j; mem[j] = (s0 + j < k && s != i) ? s : ~0u; }
+            before += rank_in_members<4>(a, mem, q);
+        }
+    }
+    return (uint64_t)reinterpret_cast<const EBT *>(a.EB)[g0] + before + r;
 }
 
 // position of a row inside a multi-word group (pfbwt.hpp:137-181) and whether a whole-word member
@@ -293,42 +339,87 @@ constexpr int EMIT_LDS_SLOTS = 4096;
 constexpr int EMIT_ROWS_IN_FLIGHT = PFP_EMIT_ROWS_IN_FLIGHT;
 static_assert(EMIT_PER_THREAD % EMIT_ROWS_IN_FLIGHT == 0, "rows per thread");
 
+// tile_slot[b] = the slot whose rows include output row b * EMIT_TILE (every slot marks the tile starts it covers)
+template <typename EBT> __global__ __launch_bounds__(BLOCK) void k_tile_slots(const EBT *cnt, const EBT *EB, uint64_t dsize, uint64_t ntiles, uint32_t *tile_slot)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i == 0) tile_slot[ntiles] = (uint32_t)(dsize - 1);
+    if (i >= dsize) return;
+    const uint64_t c = (uint64_t)cnt[i];
+    if (!c) return;
+    const uint64_t b0 = (uint64_t)EB[i], b1 = b0 + c;
+    for (uint64_t b = (b0 + EMIT_TILE - 1) / EMIT_TILE; b * EMIT_TILE < b1; ++b) tile_slot[b] = (uint32_t)i;
+}
+// last slot with EB <= o, bisecting only between the table entries around o
+template <typename EBT> __device__ __forceinline__ uint32_t slot_of_row(const EmitArgs &a, uint64_t o)
+{
+    const EBT *EB = reinterpret_cast<const EBT *>(a.EB);
+    const uint64_t tb = o / EMIT_TILE;
+    const uint32_t lo = a.tile_slot[tb], hi = a.tile_slot[tb + 1];
+    return lo + upper_bound_t<EBT>(EB + lo, hi - lo + 1u, (EBT)o) - 1u;
+}
+
 template <typename SAT, typename EBT> __global__ __launch_bounds__(BLOCK) void k_emit(EmitArgs a, uint8_t *bwt, SAT *sa, uint32_t *qrow /*or: parse-BWT row of every output row (samples-only mode)*/)
 {
     __shared__ uint32_t eb[EMIT_LDS_SLOTS];                  // EB[i0 + k] - EB[i0]
+    __shared__ uint32_t rs[EMIT_TILE];                       // slot (relative to i0) of every row of the tile
+    __shared__ uint32_t red[4];
     const EBT *EB = reinterpret_cast<const EBT *>(a.EB);
-    __shared__ uint32_t range[2];
-    const uint64_t o0 = a.e0 + (uint64_t)blockIdx.x * EMIT_TILE;
-    const uint64_t o1 = (o0 + EMIT_TILE < a.e1) ? o0 + EMIT_TILE : a.e1;   // exclusive
-    if (threadIdx.x < 2) {
-        const uint64_t o = threadIdx.x == 0 ? o0 : o1 - 1;
-        range[threadIdx.x] = upper_bound_t<EBT>(EB, (uint32_t)a.dsize, (EBT)o) - 1u;   // last slot with EB <= o
-    }
-    __syncthreads();
-    const uint32_t i0 = range[0], i1 = range[1];
+    // tiles are aligned to multiples of EMIT_TILE in the global row numbering, so that the slots under a tile come from
+    // the precomputed tile_slot table (k_tile_slots) instead of two 27-step bisections of EB per workgroup
+    const uint64_t tb = a.e0 / EMIT_TILE + blockIdx.x;
+    const uint64_t o0 = tb * EMIT_TILE > a.e0 ? tb * EMIT_TILE : a.e0;
+    const uint64_t o1 = ((tb + 1) * EMIT_TILE < a.e1) ? (tb + 1) * EMIT_TILE : a.e1;   // exclusive
+    const uint32_t i0 = a.tile_slot[tb], i1 = a.tile_slot[tb + 1];   // a superset of the slots of rows [o0, o1)
     const uint32_t ns = i1 - i0 + 1u;
     const uint64_t ebase = (uint64_t)EB[i0];
     const bool in_lds = ns <= (uint32_t)EMIT_LDS_SLOTS && o1 - ebase < 0xFFFFFFFFULL;
     if (in_lds) for (uint32_t k = threadIdx.x; k < ns; k += BLOCK) eb[k] = (uint32_t)((uint64_t)EB[i0 + k] - ebase);
+    for (int k = threadIdx.x; k < EMIT_TILE; k += BLOCK) rs[k] = 0;
     __syncthreads();
+    if (in_lds) {
+        // row -> slot without a search per row: every slot marks the row it starts at (the last of the slots that start
+        // at the same row wins: slots without rows keep EB unchanged), an inclusive max-scan spreads the marks
+        const uint32_t rel0 = (uint32_t)(o0 - ebase), nrow = (uint32_t)(o1 - o0);
+        for (uint32_t t = threadIdx.x; t < ns; t += BLOCK) {
+            const uint32_t e = eb[t];
+            if (e <= rel0) atomicMax(&rs[0], t);
+            else if (e - rel0 < nrow) atomicMax(&rs[e - rel0], t);
+        }
+        __syncthreads();
+        uint32_t loc[EMIT_PER_THREAD], run = 0;
+#pragma unroll
+        for (int j = 0; j < EMIT_PER_THREAD; ++j) { const uint32_t v = rs[threadIdx.x * EMIT_PER_THREAD + j]; run = v > run ? v : run; loc[j] = run; }
+        uint32_t tot;
+        const uint32_t inc = block_incl_max(run, red, &tot);
+        uint32_t prev = __shfl_up(inc, 1);                       // exclusive: the maximum over the threads in front
+        if ((threadIdx.x & 63) == 0) prev = 0;
+        __shared__ uint32_t wmax[BLOCK / WAVE];
+        if ((threadIdx.x & 63) == 63) wmax[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0 && threadIdx.x) prev = wmax[(threadIdx.x >> 6) - 1];
+#pragma unroll
+        for (int j = 0; j < EMIT_PER_THREAD; ++j) rs[threadIdx.x * EMIT_PER_THREAD + j] = loc[j] > prev ? loc[j] : prev;
+        __syncthreads();
+    }
     // EMIT_ROWS_IN_FLIGHT rows per thread are taken through the load stages together (slot search, per-slot fields,
     // ilist, bwsai): the kernel is bound by the latency of these dependent loads, not by bandwidth.
 #pragma unroll 1
     for (int k = 0; k < EMIT_PER_THREAD; k += EMIT_ROWS_IN_FLIGHT) {
-        uint64_t o[EMIT_ROWS_IN_FLIGHT]; uint32_t i[EMIT_ROWS_IN_FLIGHT], r[EMIT_ROWS_IN_FLIGHT], sl[EMIT_ROWS_IN_FLIGHT], fb[EMIT_ROWS_IN_FLIGHT], q[EMIT_ROWS_IN_FLIGHT];
-        uint8_t fl[EMIT_ROWS_IN_FLIGHT], pc[EMIT_ROWS_IN_FLIGHT]; bool on[EMIT_ROWS_IN_FLIGHT]; uint64_t sv[EMIT_ROWS_IN_FLIGHT];
+        uint64_t o[EMIT_ROWS_IN_FLIGHT]; uint32_t i[EMIT_ROWS_IN_FLIGHT], r[EMIT_ROWS_IN_FLIGHT], q[EMIT_ROWS_IN_FLIGHT];
+        uint4 S[EMIT_ROWS_IN_FLIGHT]; uint8_t fl[EMIT_ROWS_IN_FLIGHT]; bool on[EMIT_ROWS_IN_FLIGHT]; uint64_t sv[EMIT_ROWS_IN_FLIGHT];
 #pragma unroll
         for (int u = 0; u < EMIT_ROWS_IN_FLIGHT; ++u) {
             o[u] = o0 + (uint64_t)(k + u) * BLOCK + threadIdx.x;
             on[u] = o[u] < o1;
             const uint64_t oo = on[u] ? o[u] : o0;
-            if (in_lds) { const uint32_t j = upper_bound_t<uint32_t>(eb, ns, (uint32_t)(oo - ebase)) - 1u; i[u] = i0 + j; r[u] = (uint32_t)(oo - ebase) - eb[j]; }
+            if (in_lds) { const uint32_t j = rs[(uint32_t)(oo - o0)]; i[u] = i0 + j; r[u] = (uint32_t)(oo - ebase) - eb[j]; }
             else { i[u] = upper_bound_t<EBT>(EB, (uint32_t)a.dsize, (EBT)oo) - 1u; r[u] = (uint32_t)(oo - (uint64_t)EB[i[u]]); }
         }
 #pragma unroll
-        for (int u = 0; u < EMIT_ROWS_IN_FLIGHT; ++u) { fl[u] = a.s_fl[i[u]]; sl[u] = a.s_sl[i[u]]; fb[u] = a.s_fb[i[u]]; pc[u] = a.s_pc[i[u]]; }   // suff_len, pfbwt.hpp:83-85
+        for (int u = 0; u < EMIT_ROWS_IN_FLIGHT; ++u) { S[u] = a.sinfo[i[u]]; fl[u] = (uint8_t)(S[u].w >> 24); }
 #pragma unroll
-        for (int u = 0; u < EMIT_ROWS_IN_FLIGHT; ++u) q[u] = a.ilist[fb[u] + r[u]];                    // parse-BWT row of this occurrence
+        for (int u = 0; u < EMIT_ROWS_IN_FLIGHT; ++u) q[u] = a.ilist[S[u].x + r[u]];                   // parse-BWT row of this occurrence
 #pragma unroll
         for (int u = 0; u < EMIT_ROWS_IN_FLIGHT; ++u) sv[u] = (sa && on[u] && !(fl[u] & SF_BIG)) ? a.bwsai[q[u]] : 0ULL;
 #pragma unroll
@@ -346,19 +437,19 @@ template <typename SAT, typename EBT> __global__ __launch_bounds__(BLOCK) void k
                     basei = __shfl(basei, leader);
                     if (big) {
                         const unsigned long long idx = basei + (unsigned long long)__popcll(bm & (lane ? (~0ULL >> (64 - lane)) : 0ULL));
-                        if (idx < a.big_cap) { a.big_keys[idx] = ((uint64_t)a.s_g0[i[u]] << 32) | q[u]; a.big_vals[idx] = i[u]; }
+                        if (idx < a.big_cap) { a.big_keys[idx] = ((uint64_t)S[u].z << 32) | q[u]; a.big_vals[idx] = i[u]; }
                         else a.big_count[1] = 1;
                     }
                 }
             }
             if (!on[u] || big) continue;
             if (fl[u] & SF_GFULL) pos = multi_group_pos<EBT>(a, i[u], r[u], q[u], self_full, &full_emits_eow);
-            else if (fl[u] & SF_MULTI) pos = plain_group_pos<EBT>(a, i[u], r[u], q[u]);
-            const uint8_t c = self_full ? (full_emits_eow ? (uint8_t)EndOfWord : a.bwlast[q[u]]) : pc[u];   // pfbwt.hpp:116-128 / :132
+            else if (fl[u] & SF_MULTI) pos = plain_group_pos<EBT>(a, i[u], r[u], q[u], S[u].z, S[u].w & 0xFFFFFFu);
+            const uint8_t c = self_full ? (full_emits_eow ? (uint8_t)EndOfWord : a.bwlast[q[u]]) : a.s_pc[i[u]];   // pfbwt.hpp:116-128 / :132
             if (pos < a.w0 || pos >= a.w1) continue;                    // row of a boundary group that lands in another slice
             bwt[pos - a.w0] = c;
             if (sa) {
-                SAT v = (SAT)((SAT)sv[u] - (SAT)sl[u]);                 // UPDATE_SA, pfbwt.hpp:87-89
+                SAT v = (SAT)((SAT)sv[u] - (SAT)a.s_sl[i[u]]);          // UPDATE_SA, pfbwt.hpp:87-89 (suff_len :83-85)
                 if (pos == 0) v = (SAT)a.n;                             // src/pfbwt-f.cpp:301
                 sa[pos - a.w0] = v;
             }
@@ -375,10 +466,10 @@ template <typename EBT> __global__ __launch_bounds__(BLOCK) void k_slice_bounds(
 {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     const EBT *EB = reinterpret_cast<const EBT *>(a.EB);
-    const uint32_t il = upper_bound_t<EBT>(EB, (uint32_t)a.dsize, (EBT)lo) - 1u;
+    const uint32_t il = slot_of_row<EBT>(a, lo);
     out[0] = EB[a.posinfo[a.SA[il]].y];
     if (hi >= a.nout) { out[1] = a.nout; return; }
-    uint32_t s = upper_bound_t<EBT>(EB, (uint32_t)a.dsize, (EBT)(hi - 1)) - 1u;
+    uint32_t s = slot_of_row<EBT>(a, hi - 1);
     const uint32_t g = a.posinfo[a.SA[s]].y;
     while (s < a.dsize && a.posinfo[a.SA[s]].y == g) ++s;
     while (s < a.dsize && (uint64_t)EB[s] < hi) ++s;       // slots that produce no rows keep EB unchanged
@@ -405,8 +496,7 @@ __global__ __launch_bounds__(BLOCK) void k_run_count(const uint8_t *bwt, uint64_
 template <typename SAT, typename EBT> __device__ __forceinline__ SAT sa_of_row(const EmitArgs &a, uint32_t q, uint64_t o)
 {
     if (o == 0) return (SAT)a.n;                                     // src/pfbwt-f.cpp:301
-    const uint32_t slot = upper_bound_t<EBT>(reinterpret_cast<const EBT *>(a.EB), (uint32_t)a.dsize, (EBT)o) - 1u;
-    return (SAT)((SAT)a.bwsai[q] - (SAT)a.s_sl[slot]);
+    return (SAT)((SAT)a.bwsai[q] - (SAT)a.s_sl[slot_of_row<EBT>(a, o)]);
 }
 // Run starts of a window, 16 rows per thread: bit k of the result <=> row j0 + k (< rows) differs from the row in front
 // of it (pbwtc starts at 0, src/pfbwt-f.cpp:304).  Reads up to 15 bytes past the window (the BWT buffer is padded).
@@ -446,7 +536,7 @@ template <typename SAT, typename EBT> __global__ __launch_bounds__(BLOCK) void k
         const uint64_t b0 = (uint64_t)blockIdx.x * RUN_TILE;
         const uint64_t first = row_base + b0 - ((row_base + b0) ? 1 : 0);      // includes the row in front of the tile
         const uint64_t last = row_base + (b0 + RUN_TILE < rows ? b0 + RUN_TILE : rows) - 1;
-        if (threadIdx.x < 2) rng[threadIdx.x] = upper_bound_t<EBT>(EB, (uint32_t)a.dsize, (EBT)(threadIdx.x == 0 ? first : last)) - 1u;
+        if (threadIdx.x < 2) rng[threadIdx.x] = slot_of_row<EBT>(a, threadIdx.x == 0 ? first : last);
         __syncthreads();
         i0 = rng[0]; ns = rng[1] - i0 + 1u; ebase = (uint64_t)EB[i0];
         in_lds = ns <= (uint32_t)EMIT_LDS_SLOTS && last + 1 - ebase < 0xFFFFFFFFULL;

@@ -761,7 +761,7 @@ template <typename SAT, typename EBT> static int emit_and_sample(pfp_ctx *c, Emi
         }
         const uint64_t rows = w1 - w0;
         if (ea.big_total) PFP_HIP(c, hipMemsetAsync(ea.big_count, 0, 16, c->stream));
-        PFP_LAUNCH(c, K_EMIT, rows * (1 + (sa_at ? 8 + sizeof(SAT) : 0) + (q_at ? 4 : 0)) + rows * 10, (k_emit<SAT, EBT>), nblocks(ea.e1 - ea.e0, EMIT_TILE), ea, bwt_at, sa_at, q_at);
+        PFP_LAUNCH(c, K_EMIT, rows * (1 + (sa_at ? 8 + sizeof(SAT) : 0) + (q_at ? 4 : 0)) + rows * 10, (k_emit<SAT, EBT>), (unsigned)((ea.e1 - 1) / EMIT_TILE - ea.e0 / EMIT_TILE + 1), ea, bwt_at, sa_at, q_at);
         if (ea.big_total) {
             unsigned long long hb[2];
             PFP_HIP(c, hipMemcpyAsync(hb, ea.big_count, 16, hipMemcpyDeviceToHost, c->stream));
@@ -877,15 +877,33 @@ template <typename EBT> static int emit_stage(pfp_ctx *c, EmitArgs ea, int want_
     PFP_ALLOC_HI(c, s_g0, uint32_t, dsize); PFP_ALLOC_HI(c, gk, uint32_t, dsize); PFP_ALLOC_HI(c, gfl, uint8_t, dsize);
     PFP_HIP(c, hipMemsetAsync(gfl, 0, dsize, c->stream));
     ea.s_g0 = s_g0; ea.gk = gk; ea.cnt = cnt;
+    uint4 *sinfo; PFP_ALLOC_HI(c, sinfo, uint4, dsize); ea.sinfo = sinfo;
     PFP_LAUNCH(c, K_EMIT_COUNT, dsize * (30 + sizeof(EBT)), (k_emit_slots<EBT>), nblocks(dsize, BLOCK), ea, cnt, d_hard, (uint32_t *)ea.s_sl, (uint32_t *)ea.s_fb, (uint8_t *)ea.s_fl, (uint8_t *)ea.s_pc, s_g0, gk, gfl);
     static const long big_members = getenv("PFP_BIG_GROUP_MEMBERS") ? atol(getenv("PFP_BIG_GROUP_MEMBERS")) : (long)BIG_GROUP_MEMBERS;   // < 0: never
-    PFP_LAUNCH(c, K_EMIT_COUNT, dsize * 14, (k_big_mark<EBT>), nblocks(dsize, BLOCK), (const EBT *)cnt, (const uint32_t *)s_g0, (const uint32_t *)gk, (const uint8_t *)gfl, dsize, big_members >= 0 ? (uint32_t)big_members : 0xFFFFFFFFu, (uint8_t *)ea.s_fl, d_hard + 1);
+    PFP_LAUNCH(c, K_EMIT_COUNT, dsize * 14, (k_big_mark<EBT>), nblocks(dsize, BLOCK), (const EBT *)cnt, (const uint32_t *)s_g0, (const uint32_t *)gk, (const uint8_t *)gfl, (const uint32_t *)ea.s_fb, dsize, big_members >= 0 ? (uint32_t)big_members : 0xFFFFFFFFu, (uint8_t *)ea.s_fl, sinfo, d_hard + 1);
     PFP_TRY((device_scan<EBT, 0>(c, cnt, EB, dsize, d_tot)));
     EBT tot = 0; unsigned long long hardrows = 0, hh[2] = {0, 0};
     PFP_HIP(c, hipMemcpyAsync(hh, d_hard, 16, hipMemcpyDeviceToHost, c->stream));
     PFP_HIP(c, hipMemcpyAsync(&tot, d_tot, sizeof(EBT), hipMemcpyDeviceToHost, c->stream));
     PFP_HIP(c, hipStreamSynchronize(c->stream));
     hardrows = hh[0]; ea.big_total = hh[1];
+    {   // slot under every EMIT_TILE-th output row (k_emit, k_samples_tile, k_slice_bounds start their searches there)
+        const uint64_t ntiles = ((uint64_t)tot + EMIT_TILE - 1) / EMIT_TILE;
+        uint32_t *tile_slot; PFP_ALLOC_HI(c, tile_slot, uint32_t, ntiles + 1);
+        PFP_LAUNCH(c, K_EMIT_COUNT, dsize * 2 * sizeof(EBT) + ntiles * 4, (k_tile_slots<EBT>), nblocks(dsize, BLOCK), (const EBT *)cnt, (const EBT *)EB, dsize, ntiles, tile_slot);
+        ea.tile_slot = tile_slot;
+    }
+    static const bool verbose = getenv("PFP_VERBOSE") != nullptr;
+    if (verbose) {
+        unsigned long long *d_hist, hist[64]; PFP_ALLOC_HI(c, d_hist, unsigned long long, 64);
+        PFP_HIP(c, hipMemsetAsync(d_hist, 0, 512, c->stream));
+        PFP_LAUNCH(c, K_MISC, dsize * 20, (k_group_stats<EBT>), nblocks(dsize, BLOCK), (const EBT *)cnt, (const EBT *)EB, (const uint32_t *)s_g0, (const uint32_t *)gk, (const uint8_t *)ea.s_fl, dsize, (uint64_t)tot, d_hist);
+        PFP_HIP(c, hipMemcpyAsync(hist, d_hist, 512, hipMemcpyDeviceToHost, c->stream));
+        PFP_HIP(c, hipStreamSynchronize(c->stream));
+        fprintf(stderr, "[pfbwt_hip] rows by group members (rows) x group rows (cols: <1K <4K <16K <64K <256K <1M <4M more); hard %llu, sort-route %llu of %llu\n", hh[0], hh[1], (unsigned long long)tot);
+        static const char *kn[8] = {"1", "2-3", "4-7", "8-15", "16-31", "32-63", "64-127", "128+"};
+        for (int a = 0; a < 8; ++a) { fprintf(stderr, "[pfbwt_hip]  k %-7s", kn[a]); for (int b = 0; b < 8; ++b) fprintf(stderr, " %13llu", hist[a * 8 + b]); fprintf(stderr, "\n"); }
+    }
     const uint64_t nout = tot;
     if (nout < 2) return PFP_E_CORRUPT;
     if (c->n && nout != c->n + 1) return PFP_E_CORRUPT;         // emission must produce exactly n+1 rows
