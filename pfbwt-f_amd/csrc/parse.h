@@ -347,7 +347,29 @@ __global__ __launch_bounds__(BLOCK) void k_dict_build(const uint8_t *src, const 
     const uint64_t x0 = ((uint64_t)blockIdx.x * BLOCK + threadIdx.x) * 16;
     if (x0 >= dsize) return;
     uint32_t id = upper_bound_u32(ws, dwords + 1, (uint32_t)x0) - 1; // ws[id] <= x0
-    for (uint64_t x = x0; x < x0 + 16 && x < dsize; ++x) {
+    uint32_t wbeg = id < dwords ? ws[id] : 0u, wend = id < dwords ? ws[id + 1] : 0xFFFFFFFFu;
+    tpos_t sbeg = id < dwords ? srcstart[id] : 0;
+    if (x0 + 16 <= dsize) {        // whole 16-byte piece: bytes and word ids are assembled in registers and stored as 16-byte vectors
+        uint32_t bytes[4] = {0, 0, 0, 0}, ids[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const uint32_t x = (uint32_t)x0 + k;
+            while (id < dwords && x >= wend) { ++id; if (id < dwords) { wbeg = wend; wend = ws[id + 1]; sbeg = srcstart[id]; } }
+            uint32_t c;
+            if (id >= dwords) c = EndOfDict;
+            else c = (x + 1 == wend) ? (uint32_t)EndOfWord : (uint32_t)src[sbeg + (x - wbeg)];
+            bytes[k >> 2] |= c << (8 * (k & 3));
+            ids[k] = id;
+        }
+        *reinterpret_cast<uint4 *>(dict + x0) = make_uint4(bytes[0], bytes[1], bytes[2], bytes[3]);
+        if (wordid) {
+            uint4 *wo = reinterpret_cast<uint4 *>(wordid + x0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) wo[k] = make_uint4(ids[4 * k], ids[4 * k + 1], ids[4 * k + 2], ids[4 * k + 3]);
+        }
+        return;
+    }
+    for (uint64_t x = x0; x < dsize; ++x) {
         while (id < dwords && x >= ws[id + 1]) ++id;
         uint8_t c;
         if (id >= dwords) c = EndOfDict;

@@ -25,6 +25,7 @@ static int ensure_arena(pfp_ctx *c, uint64_t n_hint)
             if (want > cap) want = cap;
         }
     }
+    want &= ~(size_t)4095;     // both ends of the arena hand out 256-byte aligned blocks
     if (c->arena.base && c->arena.cap >= want) return PFP_OK;
     if (c->arena.base) { PFP_HIP(c, hipStreamSynchronize(c->stream)); PFP_HIP(c, hipFree(c->arena.base)); c->arena.base = nullptr; c->arena.cap = 0; }
     void *p = nullptr;

@@ -186,15 +186,24 @@ template <typename K> __global__ __launch_bounds__(BLOCK) void k_seg_hist(const 
     const uint64_t s0 = (uint64_t)blockIdx.x * tiles_per_seg * RS_TILE;
     uint64_t s1 = s0 + (uint64_t)tiles_per_seg * RS_TILE; if (s1 > n) s1 = n;
     constexpr int U = 8;                                  // independent loads in flight per thread
-    uint64_t i = s0 + threadIdx.x;
-    for (; i + (uint64_t)(U - 1) * BLOCK < s1; i += (uint64_t)U * BLOCK) {
-        K kk[U];
+    const int lane = threadIdx.x & 63;
+    for (uint64_t base = s0; base < s1; base += (uint64_t)U * BLOCK) {       // uniform trip count: the wave votes below
+        K kk[U]; bool ok[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) kk[u] = keys[i + (uint64_t)u * BLOCK];
+        for (int u = 0; u < U; ++u) { const uint64_t i = base + (uint64_t)u * BLOCK + threadIdx.x; ok[u] = i < s1; kk[u] = ok[u] ? keys[i] : (K)0; }
 #pragma unroll
-        for (int u = 0; u < U; ++u) atomicAdd(&h[(unsigned)(kk[u] >> shift) & (RS_RADIX - 1)], 1u);
+        for (int u = 0; u < U; ++u) {
+            // sorted or low-entropy input (a run of N, the later passes) gives a wave 64 equal digits: one add instead of 64
+            // serialised LDS atomics on the same counter
+            const unsigned d = (unsigned)(kk[u] >> shift) & (RS_RADIX - 1);
+            const unsigned long long act = __ballot(ok[u]);
+            if (!act) continue;
+            const int first = __ffsll((long long)act) - 1;
+            const unsigned d0 = __shfl(d, first);
+            if (__ballot(ok[u] && d == d0) == act) { if (lane == first) atomicAdd(&h[d0], (uint32_t)__popcll(act)); }
+            else if (ok[u]) atomicAdd(&h[d], 1u);
+        }
     }
-    for (; i < s1; i += BLOCK) atomicAdd(&h[(unsigned)(keys[i] >> shift) & (RS_RADIX - 1)], 1u);
     __syncthreads();
     seg[(size_t)blockIdx.x * RS_RADIX + threadIdx.x] = h[threadIdx.x];
 }
@@ -264,13 +273,27 @@ template <typename K, bool STAGE> __global__ __launch_bounds__(BLOCK) void k_seg
 #pragma unroll
         for (int w = 0; w < BLOCK / WAVE; ++w) wh[w][threadIdx.x] = 0;
         __syncthreads();
-        K k[ITEMS]; uint32_t v[ITEMS];
+        K k[ITEMS]; uint32_t v[ITEMS]; uint16_t rk[ITEMS];      // rk: rank among the wave's earlier pairs with the same digit
         const uint64_t base = tbase + (uint64_t)wave * (ITEMS * WAVE) + lane;
 #pragma unroll
         for (int it = 0; it < ITEMS; ++it) {
             const uint64_t i = base + (uint64_t)it * WAVE;
             k[it] = kn[it]; v[it] = vn[it];
-            if (i < n) atomicAdd(&wh[wave][(unsigned)(k[it] >> shift) & (RS_RADIX - 1)], 1u);
+            // count and rank in one step: the lanes holding the same digit are found with 8 votes, their leader advances
+            // the wave's counter once (no LDS atomics, no serialisation on equal digits)
+            const bool valid = i < n;
+            const unsigned d = (unsigned)(k[it] >> shift) & (RS_RADIX - 1);
+            unsigned long long peers = __ballot(valid);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                unsigned long long m = __ballot((d >> b) & 1);
+                peers &= ((d >> b) & 1) ? m : ~m;
+            }
+            const int leader = valid ? (__ffsll((long long)peers) - 1) : lane;
+            uint32_t old = 0;
+            if (valid && lane == leader) { old = wh[wave][d]; wh[wave][d] = old + (uint32_t)__popcll(peers); }
+            old = __shfl(old, leader);
+            rk[it] = (uint16_t)(old + (uint32_t)__popcll(peers & lt));
         }
         if (tl + 1 < tiles_per_seg) {
             const uint64_t nb = base + TILE;
@@ -297,18 +320,8 @@ template <typename K, bool STAGE> __global__ __launch_bounds__(BLOCK) void k_seg
             const uint64_t i = base + (uint64_t)it * WAVE;
             const bool valid = i < n;
             const unsigned d = (unsigned)(k[it] >> shift) & (RS_RADIX - 1);
-            unsigned long long peers = __ballot(valid);
-#pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                unsigned long long m = __ballot((d >> b) & 1);
-                peers &= ((d >> b) & 1) ? m : ~m;
-            }
-            const int leader = valid ? (__ffsll((long long)peers) - 1) : lane;
-            uint32_t old = 0;
-            if (valid && lane == leader) { old = wh[wave][d]; wh[wave][d] = old + (uint32_t)__popcll(peers); }
-            old = __shfl(old, leader);
             if (valid) {
-                const uint32_t li = old + (uint32_t)__popcll(peers & lt);
+                const uint32_t li = wh[wave][d] + rk[it];             // wave's first index for this digit + rank inside the wave
                 if (STAGE) { skeys[li] = k[it]; svals[li] = v[it]; }
                 else { const unsigned long long pos = gdelta[d] + li; okeys[pos] = k[it]; ovals[pos] = v[it]; }
             }
