@@ -34,6 +34,21 @@ __device__ __forceinline__ uint32_t norm_base(uint32_t c, bool ntoa)
     if (ntoa && !(c == 'A' || c == 'C' || c == 'G' || c == 'T')) c = 'A';
     return c;
 }
+// `count` records of `len` bytes, `stride` apart, packed one after the other with `w` 'A's behind each (the pad of
+// pfparser.hpp:335-337).  One thread moves 16 bytes; destination rows start at arbitrary byte offsets.
+__global__ __launch_bounds__(BLOCK) void k_feed_batch(const uint8_t *src, uint64_t count, uint64_t len, uint64_t stride, int w, uint8_t *dst)
+{
+    const uint64_t per_row = (len + 15) / 16;
+    const uint64_t idx = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (idx >= count * per_row) return;
+    const uint64_t row = idx / per_row, j = idx - row * per_row;
+    const uint8_t *s = src + row * stride + 16 * j;
+    uint8_t *d = dst + row * (len + (uint64_t)w) + 16 * j;
+    if (16 * j + 16 <= len) { uint4 v; __builtin_memcpy(&v, s, 16); __builtin_memcpy(d, &v, 16); }
+    else for (uint64_t k = 0; 16 * j + k < len; ++k) d[k] = s[k];
+    if (j == per_row - 1) for (int k = 0; k < w; ++k) dst[row * (len + (uint64_t)w) + len + k] = 'A';
+}
+
 // seq_nt4_ntoa_table, src/utils.c:139-161 (after toupper): A,N->0 C->1 G->2 T,'-'->3 else 5
 __device__ __forceinline__ uint32_t ntoa_code(uint32_t c)
 {

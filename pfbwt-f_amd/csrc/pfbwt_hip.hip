@@ -176,8 +176,9 @@ int pfp_parse_feed_device_batch(pfp_ctx *c, const void *d_bases, uint64_t count,
     if (c->n + add + (uint64_t)c->w + 64 >= ((c->flags & PFP_FLAG_U64) ? (1ULL << 40) : 0xFFFFFFFFULL)) return PFP_E_TOO_LARGE;
     PFP_TRY(ensure_text(c, c->n + add + (uint64_t)c->w));
     uint8_t *dst = c->tb + 16 + c->n;
-    PFP_HIP(c, hipMemcpy2DAsync(dst, (size_t)pitch, d_bases, (size_t)stride, (size_t)len, (size_t)count, hipMemcpyDeviceToDevice, c->stream));
-    PFP_HIP(c, hipMemset2DAsync(dst + len, (size_t)pitch, 'A', (size_t)c->w, (size_t)count, c->stream));   // the w 'A's of pfparser.hpp:335-337
+    const uint64_t pieces = count * ((len + 15) / 16);
+    if (pieces / BLOCK >= 0x7FFFFFFFULL) return PFP_E_TOO_LARGE;      // grid limit (2^31 workgroups = 8 Tbase)
+    PFP_LAUNCH(c, K_MISC, 2 * count * len, k_feed_batch, nblocks(pieces, BLOCK), (const uint8_t *)d_bases, count, len, stride, c->w, dst);
     c->n += add;
     return PFP_OK;
 }

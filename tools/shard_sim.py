@@ -67,10 +67,18 @@ want = list(range(a.ranks)) if a.slices == "all" else [int(x) for x in a.slices.
 ctx = pfbwt_hip.PfpContext(w=w, p=p, u64=True, sai=True)
 parts = {}
 for it, r in enumerate(want):
-    t0 = time.time(); sz = ctx.merge_shards(views); sync(); t1 = time.time()
-    ctx.parse_bwt(); sync(); t2 = time.time()
     if it == len(want) - 1:
         ctx.profile_enable(True); ctx.profile_reset()
+    t0 = time.time(); sz = ctx.merge_shards(views); sync(); t1 = time.time()
+    if it == len(want) - 1:
+        rowsp = sorted(ctx.profile(), key=lambda x: -x["ms"]); tot = sum(x["ms"] for x in rowsp)
+        print("  merge_shards kernels (%.1f ms):" % tot, ", ".join("%s %.1f" % (x["kernel"], x["ms"]) for x in rowsp[:10]), flush=True)
+        ctx.profile_reset()
+    ctx.parse_bwt(); sync(); t2 = time.time()
+    if it == len(want) - 1:
+        rowsp = sorted(ctx.profile(), key=lambda x: -x["ms"]); tot = sum(x["ms"] for x in rowsp)
+        print("  parse_bwt kernels (%.1f ms):" % tot, ", ".join("%s %.1f" % (x["kernel"], x["ms"]) for x in rowsp[:10]), flush=True)
+        ctx.profile_reset()
     b, beg, rows = ctx.bwt_build_slice(r, a.ranks, sa=a.sa, rssa=not a.sa); sync(); t3 = time.time()
     print("slice %d/%d: merged n=%d m=%d dwords=%d dsize=%d | merge %.3fs pbwt %.3fs slice-bwt %.3fs | rows [%d,+%d) runs %d  -> rank time %.3fs + parse %.3fs = %.3fs (%.2f Gbases/s at N=%d, all-gather excluded)"
           % (r, a.ranks, sz.n, sz.m, sz.dwords, sz.dsize, t1 - t0, t2 - t1, t3 - t2, beg, rows, b.r, t3 - t0, max(t_parse), t3 - t0 + max(t_parse),
