@@ -273,6 +273,32 @@ template <int W> __device__ __forceinline__ uint32_t rank_in_members(const EmitA
     for (int j = 0; j < W; ++j) before += lo[j];
     return before;
 }
+// the same for W lists with their own q each (the rows a thread has in flight are ranked together)
+template <int W> __device__ __forceinline__ void rank_lists(const EmitArgs &a, const uint32_t *mem /*W slots, ~0u = none*/, const uint32_t *q, uint32_t *out)
+{
+    const uint32_t *base[W]; uint32_t lo[W], len[W];
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+        const uint4 S = mem[j] != ~0u ? a.sinfo[mem[j]] : make_uint4(0, 0, 0, 0);
+        base[j] = a.ilist + S.x; lo[j] = 0; len[j] = S.y; any |= S.y != 0;
+    }
+    while (any) {
+        uint32_t v[W], half[W];
+#pragma unroll
+        for (int j = 0; j < W; ++j) { half[j] = len[j] >> 1; v[j] = len[j] ? base[j][lo[j] + half[j]] : 0u; }
+        any = false;
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            const bool less = len[j] && v[j] < q[j];
+            lo[j] = less ? lo[j] + half[j] + 1 : lo[j];
+            len[j] = less ? len[j] - half[j] - 1 : half[j];
+            any |= len[j] != 0;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < W; ++j) out[j] = lo[j];
+}
 template <typename EBT> __device__ __forceinline__ uint64_t plain_group_pos(const EmitArgs &a, uint32_t i, uint32_t r, uint32_t q, uint32_t g0, uint32_t k)
 {
     uint64_t before = 0;
@@ -337,6 +363,10 @@ constexpr int EMIT_LDS_SLOTS = 4096;
 #define PFP_EMIT_ROWS_IN_FLIGHT 2
 #endif
 constexpr int EMIT_ROWS_IN_FLIGHT = PFP_EMIT_ROWS_IN_FLIGHT;
+#ifndef PFP_EMIT_RANK_W
+#define PFP_EMIT_RANK_W 2
+#endif
+constexpr int EMIT_RANK_W = PFP_EMIT_RANK_W;     // member lists per row ranked at a time
 static_assert(EMIT_PER_THREAD % EMIT_ROWS_IN_FLIGHT == 0, "rows per thread");
 
 // tile_slot[b] = the slot whose rows include output row b * EMIT_TILE (every slot marks the tile starts it covers)
@@ -422,6 +452,30 @@ template <typename SAT, typename EBT> __global__ __launch_bounds__(BLOCK) void k
         for (int u = 0; u < EMIT_ROWS_IN_FLIGHT; ++u) q[u] = a.ilist[S[u].x + r[u]];                   // parse-BWT row of this occurrence
 #pragma unroll
         for (int u = 0; u < EMIT_ROWS_IN_FLIGHT; ++u) sv[u] = (sa && on[u] && !(fl[u] & SF_BIG)) ? a.bwsai[q[u]] : 0ULL;
+        // rows in ordinary multi-member groups: the bisections of all rows in flight run in one loop (EMIT_RANK_W lists per
+        // row at a time), so that a thread has EMIT_ROWS_IN_FLIGHT * EMIT_RANK_W dependent-load chains going instead of one
+        uint32_t before[EMIT_ROWS_IN_FLIGHT], gk_[EMIT_ROWS_IN_FLIGHT], maxk = 0;
+#pragma unroll
+        for (int u = 0; u < EMIT_ROWS_IN_FLIGHT; ++u) {
+            const bool plain = on[u] && (fl[u] & SF_MULTI) && !(fl[u] & (SF_GFULL | SF_BIG));
+            gk_[u] = plain ? (S[u].w & 0xFFFFFFu) : 0u; before[u] = 0;
+            maxk = gk_[u] > maxk ? gk_[u] : maxk;
+        }
+        for (uint32_t s0 = 0; s0 < maxk; s0 += EMIT_RANK_W) {
+            uint32_t mem[EMIT_ROWS_IN_FLIGHT * EMIT_RANK_W], qq[EMIT_ROWS_IN_FLIGHT * EMIT_RANK_W], res[EMIT_ROWS_IN_FLIGHT * EMIT_RANK_W];
+#pragma unroll
+            for (int u = 0; u < EMIT_ROWS_IN_FLIGHT; ++u)
+#pragma unroll
+                for (int j = 0; j < EMIT_RANK_W; ++j) {
+                    const uint32_t s = S[u].z + s0 + j;
+                    mem[u * EMIT_RANK_W + j] = (s0 + j < gk_[u] && s != i[u]) ? s : ~0u; qq[u * EMIT_RANK_W + j] = q[u];
+                }
+            rank_lists<EMIT_ROWS_IN_FLIGHT * EMIT_RANK_W>(a, mem, qq, res);
+#pragma unroll
+            for (int u = 0; u < EMIT_ROWS_IN_FLIGHT; ++u)
+#pragma unroll
+                for (int j = 0; j < EMIT_RANK_W; ++j) before[u] += res[u * EMIT_RANK_W + j];
+        }
 #pragma unroll
         for (int u = 0; u < EMIT_ROWS_IN_FLIGHT; ++u) {
             const bool self_full = (fl[u] & SF_FULL) != 0;
@@ -444,7 +498,7 @@ template <typename SAT, typename EBT> __global__ __launch_bounds__(BLOCK) void k
             }
             if (!on[u] || big) continue;
             if (fl[u] & SF_GFULL) pos = multi_group_pos<EBT>(a, i[u], r[u], q[u], self_full, &full_emits_eow);
-            else if (fl[u] & SF_MULTI) pos = plain_group_pos<EBT>(a, i[u], r[u], q[u], S[u].z, S[u].w & 0xFFFFFFu);
+            else if (fl[u] & SF_MULTI) pos = (uint64_t)EB[S[u].z] + before[u] + r[u];
             const uint8_t c = self_full ? (full_emits_eow ? (uint8_t)EndOfWord : a.bwlast[q[u]]) : a.s_pc[i[u]];   // pfbwt.hpp:116-128 / :132
             if (pos < a.w0 || pos >= a.w1) continue;                    // row of a boundary group that lands in another slice
             bwt[pos - a.w0] = c;
