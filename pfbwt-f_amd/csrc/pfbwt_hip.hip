@@ -763,7 +763,8 @@ template <typename SAT, typename EBT> static int emit_and_sample(pfp_ctx *c, Emi
         }
         const uint64_t rows = w1 - w0;
         if (ea.big_total) PFP_HIP(c, hipMemsetAsync(ea.big_count, 0, 16, c->stream));
-        PFP_LAUNCH(c, K_EMIT, rows * (1 + (sa_at ? 8 + sizeof(SAT) : 0) + (q_at ? 4 : 0)) + rows * 10, (k_emit<SAT, EBT>), (unsigned)((ea.e1 - 1) / EMIT_TILE - ea.e0 / EMIT_TILE + 1), ea, bwt_at, sa_at, q_at);
+        PFP_LAUNCH(c, K_EMIT, rows * (1 + 4 + (sa_at ? 8 + sizeof(SAT) : 0) + (q_at ? 4 : 0)),   // per row: BWT byte out, ilist entry in, (bwsai gather + SA out | parse row out)
+                   (k_emit<SAT, EBT>), (unsigned)((ea.e1 - 1) / EMIT_TILE - ea.e0 / EMIT_TILE + 1), ea, bwt_at, sa_at, q_at);
         if (ea.big_total) {
             unsigned long long hb[2];
             PFP_HIP(c, hipMemcpyAsync(hb, ea.big_count, 16, hipMemcpyDeviceToHost, c->stream));

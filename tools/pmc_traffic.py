@@ -3,7 +3,7 @@
 
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py ...
     rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python3 bench.py ...
-    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/pmc_traffic_latest.json
+    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/pmc_traffic_latest.json S-32G
 
 Units and the gfx950 correction follow /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3 section): both counters
 are in KiB-like units of 1024 B as printed by rocprofv3; FETCH_SIZE counts 128-B streaming requests at 64 B, so it is
@@ -28,9 +28,10 @@ def load(d, counter):
 
 def main():
     fetch_dir, write_dir, out = sys.argv[1:4]
+    workload = sys.argv[4] if len(sys.argv) > 4 else "S-32G"      # bench.py only quotes the file for the workload it was taken on
     ft, fn = load(fetch_dir, "FETCH_SIZE")
     wt, wn = load(write_dir, "WRITE_SIZE")
-    res = {}
+    res = {"_workload": workload}
     for k in sorted(set(ft) | set(wt), key=lambda k: -(2 * ft.get(k, 0) + wt.get(k, 0))):
         launches = max(fn.get(k, 0), wn.get(k, 0))
         if not launches:
@@ -40,7 +41,7 @@ def main():
                   "hbm_bytes_per_launch_raw": 1024.0 * (f_kb + w_kb),
                   "hbm_bytes_per_launch_corrected": 1024.0 * (2.0 * f_kb + w_kb)}
     json.dump(res, open(out, "w"), indent=1)
-    for k, v in list(res.items())[:12]:
+    for k, v in [kv for kv in res.items() if kv[0] != "_workload"][:12]:
         print("%-60s launches %5d  HBM bytes/launch raw %.3e corrected %.3e" % (k[:60], v["launches"], v["hbm_bytes_per_launch_raw"], v["hbm_bytes_per_launch_corrected"]))
 
 
