@@ -39,9 +39,10 @@ __device__ __forceinline__ uint32_t norm_base(uint32_t c, bool ntoa)
 __global__ __launch_bounds__(BLOCK) void k_feed_batch(const uint8_t *src, uint64_t count, uint64_t len, uint64_t stride, int w, uint8_t *dst)
 {
     const uint64_t per_row = (len + 15) / 16;
-    const uint64_t idx = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (idx >= count * per_row) return;
-    const uint64_t row = idx / per_row, j = idx - row * per_row;
+    const uint32_t blocks_per_row = (uint32_t)((per_row + BLOCK - 1) / BLOCK);      // a workgroup stays inside one record:
+    const uint64_t row = blockIdx.x / blocks_per_row;                                // one scalar division per workgroup
+    const uint64_t j = (uint64_t)(blockIdx.x - (uint32_t)row * blocks_per_row) * BLOCK + threadIdx.x;
+    if (row >= count || j >= per_row) return;
     const uint8_t *s = src + row * stride + 16 * j;
     uint8_t *d = dst + row * (len + (uint64_t)w) + 16 * j;
     if (16 * j + 16 <= len) { uint4 v; __builtin_memcpy(&v, s, 16); __builtin_memcpy(d, &v, 16); }

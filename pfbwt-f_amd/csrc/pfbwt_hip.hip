@@ -42,6 +42,7 @@ static int ensure_text(pfp_ctx *c, uint64_t need_n)
     if (c->tb && c->tb_cap >= need) return PFP_OK;
     size_t cap = c->tb_cap ? c->tb_cap : (size_t)1 << 20;
     while (cap < need) cap *= 2;
+    if (!c->tb && need > ((size_t)1 << 30)) cap = (need + ((size_t)1 << 20)) & ~(((size_t)1 << 20) - 1);   // a large first request (batched feed) is taken as is
     uint8_t *nb = nullptr;
     hipError_t e = hipMalloc((void **)&nb, cap);
     if (e != hipSuccess) { (void)hipGetLastError(); return PFP_E_NOMEM; }
@@ -176,9 +177,9 @@ int pfp_parse_feed_device_batch(pfp_ctx *c, const void *d_bases, uint64_t count,
     if (c->n + add + (uint64_t)c->w + 64 >= ((c->flags & PFP_FLAG_U64) ? (1ULL << 40) : 0xFFFFFFFFULL)) return PFP_E_TOO_LARGE;
     PFP_TRY(ensure_text(c, c->n + add + (uint64_t)c->w));
     uint8_t *dst = c->tb + 16 + c->n;
-    const uint64_t pieces = count * ((len + 15) / 16);
-    if (pieces / BLOCK >= 0x7FFFFFFFULL) return PFP_E_TOO_LARGE;      // grid limit (2^31 workgroups = 8 Tbase)
-    PFP_LAUNCH(c, K_MISC, 2 * count * len, k_feed_batch, nblocks(pieces, BLOCK), (const uint8_t *)d_bases, count, len, stride, c->w, dst);
+    const uint64_t blocks_per_row = ((len + 15) / 16 + BLOCK - 1) / BLOCK;
+    if (count * blocks_per_row >= 0x7FFFFFFFULL) return PFP_E_TOO_LARGE;      // grid limit (2^31 workgroups = 8 Tbase)
+    PFP_LAUNCH(c, K_MISC, 2 * count * len, k_feed_batch, count * blocks_per_row, (const uint8_t *)d_bases, count, len, stride, c->w, dst);
     c->n += add;
     return PFP_OK;
 }

@@ -38,6 +38,10 @@ def allgather_shards(ctx, device, group=None):
         pad = torch.empty(maxb, dtype=torch.uint8, device=device); pad[:buf.numel()] = buf; buf = pad
     recv = [torch.empty(maxb, dtype=torch.uint8, device=device) for _ in range(world)]
     dist.all_gather(recv, buf[:maxb].contiguous(), group=group)
+    if torch.device(device).type == "cuda":
+        # the collective runs on torch's / RCCL's stream, the engine reads the receive buffers on its own HIP stream:
+        # the host waits for the collective before the pointers are handed over
+        torch.cuda.synchronize(device)
     views = []
     for r in range(world):
         n, m, dw, ds, _ = (int(x) for x in metas[r])
