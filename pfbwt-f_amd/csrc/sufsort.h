@@ -79,6 +79,12 @@ __global__ __launch_bounds__(BLOCK) void k_ss_write_rank(const uint32_t *vals, c
     const uint64_t a = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (a < na) reinterpret_cast<uint32_t *>(rj)[2 * (uint64_t)vals[a]] = newrank[a];
 }
+// rank and jump of a re-sorted suffix in ONE 8-byte record write (the new jump travelled with the pair through the sort)
+__global__ __launch_bounds__(BLOCK) void k_ss_write_rank_jump(const uint32_t *vals, const uint32_t *newrank, const uint32_t *nj, uint64_t na, uint2 *rj)
+{
+    const uint64_t a = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (a < na) rj[vals[a]] = make_uint2(newrank[a], nj[a]);
+}
 __global__ __launch_bounds__(BLOCK) void k_ss_init_rj(const uint32_t *vals, const uint32_t *newrank, uint64_t N, uint32_t h0, uint2 *rj)
 {
     const uint64_t a = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -155,6 +161,177 @@ __global__ __launch_bounds__(BLOCK) void k_ss_runend_marks(const uint8_t *D, uin
     g[ip] = (x + 1 == N || D[x] != D[x + 1]) ? (uint32_t)ip : 0u;
 }
 
+// ---- sort of a doubling round ------------------------------------------------------------------------------------
+// The active list is in slot order: the members of a class (equal rank = equal high key part) are already contiguous,
+// only the order INSIDE every class is unknown.  Classes are small on the inputs that have many rounds with everything
+// active (a 1000-haplotype parse: ~1000 members per class), so a workgroup sorts whole classes inside LDS: the pairs
+// cross HBM once per round instead of once per radix pass (8 passes of 32 B for 58-bit keys).  Workgroup j owns the
+// classes that START in [j*CS_STEP, (j+1)*CS_STEP); they end where the first class of the next stripe starts.  A range
+// longer than one tile (a class with thousands of members) is left alone; those pairs are collected afterwards and go
+// through the ordinary radix sort.
+constexpr uint32_t CS_STEP = RS_TILE / 2;
+template <typename K> __global__ __launch_bounds__(BLOCK) void k_class_tile_sort(const K *keys, const uint32_t *vals, const uint32_t *nj, K *okeys, uint32_t *ovals, uint32_t *onj,
+                                                                                 uint64_t na, int lowbits, uint32_t max_range, uint8_t *done, unsigned long long *nsorted)
+{
+    constexpr int ITEMS = RS_ITEMS, TILE = RS_TILE;
+    __shared__ uint32_t wh[BLOCK / WAVE][RS_RADIX];
+    __shared__ K skeys[TILE];
+    __shared__ uint16_t sidx[TILE];                     // the payload inside LDS is the pair's index in the range; x and the new jump
+    __shared__ uint32_t red[4];                          // are fetched from the (cache-resident) input range when the range is written out
+    __shared__ uint32_t bound[2];
+    const uint64_t w0 = (uint64_t)blockIdx.x * CS_STEP;
+    if (threadIdx.x < 2) bound[threadIdx.x] = 0xFFFFFFFFu;
+    __syncthreads();
+    for (int which = 0; which < 2; ++which) {          // first class start at or after w0 (which = 0), w0 + CS_STEP (which = 1)
+        const uint64_t b = w0 + (uint64_t)which * CS_STEP;
+        for (uint32_t t = threadIdx.x; t < (uint32_t)TILE; t += BLOCK) {
+            const uint64_t a = b + t;
+            if (a > na) break;
+            const bool st = a == na || a == 0 || (keys[a] >> lowbits) != (keys[a - 1] >> lowbits);
+            if (st) { atomicMin(&bound[which], t); break; }
+        }
+    }
+    __syncthreads();
+    if (bound[0] >= CS_STEP) return;                      // no class starts in this stripe
+    const uint64_t s = w0 + bound[0];
+    if (s >= na) return;
+    if (bound[1] == 0xFFFFFFFFu) return;                  // the last class of the stripe runs on for more than a tile
+    const uint64_t e = w0 + CS_STEP + bound[1];
+    if (e - s > (uint64_t)max_range) return;
+    const uint32_t n = (uint32_t)(e - s);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;
+    const uint32_t base = (uint32_t)wave * (ITEMS * WAVE) + lane;
+    for (uint32_t j = threadIdx.x; j < n; j += BLOCK) { skeys[j] = keys[s + j]; sidx[j] = (uint16_t)j; }
+    __syncthreads();
+    const K lomask = lowbits >= 64 ? ~(K)0 : (((K)1 << lowbits) - 1);
+    const K hmin = skeys[0] >> lowbits, hspan = (skeys[n - 1] >> lowbits) - hmin;     // high parts are already in order
+    const int nlo = (lowbits + 7) / 8;
+    int nhi = 0; while (nhi < 8 && (hspan >> (8 * nhi))) ++nhi;
+    for (int p = 0; p < nlo + nhi; ++p) {
+        K k[ITEMS]; uint16_t v[ITEMS]; unsigned dg[ITEMS];
+#pragma unroll
+        for (int w = 0; w < BLOCK / WAVE; ++w) wh[w][threadIdx.x] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            const uint32_t i = base + (uint32_t)it * WAVE;
+            const bool valid = i < n;
+            k[it] = valid ? skeys[i] : (K)0; v[it] = valid ? sidx[i] : (uint16_t)0;
+            const unsigned d = p < nlo ? (unsigned)((k[it] & lomask) >> (8 * p)) & (RS_RADIX - 1) : (unsigned)(((k[it] >> lowbits) - hmin) >> (8 * (p - nlo))) & (RS_RADIX - 1);
+            unsigned long long peers = __ballot(valid);
+#pragma unroll
+            for (int bb = 0; bb < 8; ++bb) {
+                unsigned long long m = __ballot((d >> bb) & 1);
+                peers &= ((d >> bb) & 1) ? m : ~m;
+            }
+            const int leader = valid ? (__ffsll((long long)peers) - 1) : lane;
+            uint32_t old = 0;
+            if (valid && lane == leader) { old = wh[wave][d]; wh[wave][d] = old + (uint32_t)__popcll(peers); }
+            old = __shfl(old, leader);
+            dg[it] = d | ((old + (uint32_t)__popcll(peers & lt)) << 8);        // digit and rank inside the wave
+        }
+        __syncthreads();
+        {
+            const unsigned d = threadIdx.x;
+            uint32_t cw[BLOCK / WAVE]; uint32_t total = 0;
+#pragma unroll
+            for (int w = 0; w < BLOCK / WAVE; ++w) { cw[w] = wh[w][d]; total += cw[w]; }
+            uint32_t tt;
+            uint32_t run = block_excl_sum(total, red, &tt);
+#pragma unroll
+            for (int w = 0; w < BLOCK / WAVE; ++w) { wh[w][d] = run; run += cw[w]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            const uint32_t i = base + (uint32_t)it * WAVE;
+            if (i < n) { const uint32_t li = wh[wave][dg[it] & 255u] + (dg[it] >> 8); skeys[li] = k[it]; sidx[li] = v[it]; }
+        }
+        __syncthreads();
+    }
+    for (uint32_t j = threadIdx.x; j < n; j += BLOCK) {
+        const uint32_t src = sidx[j];
+        okeys[s + j] = skeys[j]; ovals[s + j] = vals[s + src]; onj[s + j] = nj[s + src]; done[s + j] = 1;
+    }
+    if (threadIdx.x == 0) atomicAdd(nsorted, (unsigned long long)n);
+}
+__global__ __launch_bounds__(BLOCK) void k_not_done(const uint8_t *done, uint64_t n, uint32_t *flag)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) flag[i] = done[i] ? 0u : 1u;
+}
+template <typename K> __global__ __launch_bounds__(BLOCK) void k_gather_pairs(const K *keys, const uint32_t *vals, const uint32_t *idx, uint64_t n, K *ok, uint32_t *ov)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) { ok[i] = keys[idx[i]]; ov[i] = vals[idx[i]]; }
+}
+template <typename K> __global__ __launch_bounds__(BLOCK) void k_scatter_pairs(const K *keys, const uint32_t *vals, const uint32_t *idx, uint64_t n, K *ok, uint32_t *ov)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) { ok[idx[i]] = keys[i]; ov[idx[i]] = vals[i]; }
+}
+__global__ __launch_bounds__(BLOCK) void k_gather_u32(const uint32_t *in, const uint32_t *idx, uint64_t n, uint32_t *out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) out[i] = in[idx[i]];
+}
+__global__ __launch_bounds__(BLOCK) void k_gather_jump(const uint32_t *vals, const uint32_t *idx, uint64_t n, const uint2 *rj, uint32_t *onj)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) onj[idx[i]] = rj[vals[i]].y;
+}
+// Sorts the na pairs of a round by (high part, low part); result in *sk / *sv.  nj[a] is the new jump of pair a: on the
+// LDS route it travels with the pair (*snj = its sorted copy, the caller writes rank and jump together); when the plain
+// radix sort is taken the jumps are applied to rj here, before the pair order is lost (*snj = nullptr).
+inline int class_segment_sort(pfp_ctx *c, uint64_t *k0, uint32_t *v0, const uint32_t *nj, uint64_t *k1, uint32_t *v1, uint32_t *onj, uint64_t na, int lowbits, int rbits,
+                              uint2 *rj, uint64_t **sk, uint32_t **sv, uint32_t **snj)
+{
+    BitRange rr = {0, lowbits + rbits};
+    const unsigned ga = nblocks(na, BLOCK);
+    *snj = nullptr;
+    static const long long min_na = getenv("PFP_CLASS_SORT_MIN") ? atoll(getenv("PFP_CLASS_SORT_MIN")) : 8ll * RS_TILE;   // < 0: never (tests: 1 = always)
+    if (min_na < 0 || na < (uint64_t)min_na) {
+        PFP_LAUNCH(c, K_SS_MAKE_KEYS, na * 12, k_ss_apply_jump, ga, (const uint32_t *)v0, nj, na, rj);
+        return radix_sort_pairs<uint64_t>(c, k0, v0, k1, v1, na, &rr, 1, sk, sv);
+    }
+    static const uint32_t max_range = getenv("PFP_CLASS_SORT_MAXRANGE") ? (uint32_t)atoi(getenv("PFP_CLASS_SORT_MAXRANGE")) : (uint32_t)RS_TILE;   // tests: smaller, to reach the large-class route
+    const size_t mk = c->arena.mark_hi();
+    uint8_t *done; unsigned long long *d_ns;
+    PFP_ALLOC_HI(c, done, uint8_t, na); PFP_ALLOC_HI(c, d_ns, unsigned long long, 1);
+    PFP_HIP(c, hipMemsetAsync(done, 0, na, c->stream));
+    PFP_HIP(c, hipMemsetAsync(d_ns, 0, 8, c->stream));
+    PFP_LAUNCH(c, K_RADIX_SCATTER, na * 64, (k_class_tile_sort<uint64_t>), nblocks(na, CS_STEP), (const uint64_t *)k0, (const uint32_t *)v0, nj, k1, v1, onj, na, lowbits, max_range, done, d_ns);
+    unsigned long long ns = 0;
+    PFP_HIP(c, hipMemcpyAsync(&ns, d_ns, 8, hipMemcpyDeviceToHost, c->stream));
+    PFP_HIP(c, hipStreamSynchronize(c->stream));
+    const uint64_t nl = na - ns;
+    static const bool verbose = getenv("PFP_VERBOSE") != nullptr;
+    if (verbose) fprintf(stderr, "[pfbwt_hip]   class sort: %llu pairs, %llu in classes too large for one tile%s\n", (unsigned long long)na, (unsigned long long)nl, nl > na / 2 ? " -> plain radix sort" : "");
+    if (nl > na / 2) {            // mostly large classes: one plain sort of everything (k0 / v0 / nj are still intact)
+        c->arena.release_hi(mk);
+        PFP_LAUNCH(c, K_SS_MAKE_KEYS, na * 12, k_ss_apply_jump, ga, (const uint32_t *)v0, nj, na, rj);
+        return radix_sort_pairs<uint64_t>(c, k0, v0, k1, v1, na, &rr, 1, sk, sv);
+    }
+    if (nl) {                      // the pairs of the large classes: collect, sort, put back (their positions are whole classes in order)
+        uint32_t *flag, *pos, *idx, *d_cnt, *lnj; uint64_t *lk0, *lk1; uint32_t *lv0, *lv1;
+        PFP_ALLOC_HI(c, flag, uint32_t, na); PFP_ALLOC_HI(c, pos, uint32_t, na); PFP_ALLOC_HI(c, idx, uint32_t, nl); PFP_ALLOC_HI(c, d_cnt, uint32_t, 1);
+        PFP_ALLOC_HI(c, lk0, uint64_t, nl); PFP_ALLOC_HI(c, lk1, uint64_t, nl); PFP_ALLOC_HI(c, lv0, uint32_t, nl); PFP_ALLOC_HI(c, lv1, uint32_t, nl); PFP_ALLOC_HI(c, lnj, uint32_t, nl);
+        PFP_LAUNCH(c, K_COMPACT, na * 5, k_not_done, ga, (const uint8_t *)done, na, flag);
+        PFP_TRY(device_compact(c, nullptr, flag, na, idx, pos, d_cnt));
+        PFP_LAUNCH(c, K_COMPACT, nl * 28, (k_gather_pairs<uint64_t>), nblocks(nl, BLOCK), (const uint64_t *)k0, (const uint32_t *)v0, (const uint32_t *)idx, nl, lk0, lv0);
+        PFP_LAUNCH(c, K_COMPACT, nl * 12, k_gather_u32, nblocks(nl, BLOCK), nj, (const uint32_t *)idx, nl, lnj);
+        PFP_LAUNCH(c, K_SS_MAKE_KEYS, nl * 12, k_ss_apply_jump, nblocks(nl, BLOCK), (const uint32_t *)lv0, (const uint32_t *)lnj, nl, rj);   // their jumps go to rj now, the sort loses the pairing
+        uint64_t *lsk; uint32_t *lsv;
+        PFP_TRY(radix_sort_pairs<uint64_t>(c, lk0, lv0, lk1, lv1, nl, &rr, 1, &lsk, &lsv));
+        PFP_LAUNCH(c, K_COMPACT, nl * 28, (k_scatter_pairs<uint64_t>), nblocks(nl, BLOCK), (const uint64_t *)lsk, (const uint32_t *)lsv, (const uint32_t *)idx, nl, k1, v1);
+        PFP_LAUNCH(c, K_COMPACT, nl * 16, k_gather_jump, nblocks(nl, BLOCK), (const uint32_t *)lsv, (const uint32_t *)idx, nl, (const uint2 *)rj, onj);
+    }
+    c->arena.release_hi(mk);
+    *sk = k1; *sv = v1; *snj = onj;
+    return PFP_OK;
+}
+
 // Sorts the N suffixes described by (keys,vals) [already filled: keys = h0-character prefixes, vals = x].
 // Outputs SA (slot -> x) and rank (x -> slot of its class head).  ws/wordid select dictionary semantics
 // (see k_ss_flag_active); D != nullptr additionally enables the run round (byte texts).
@@ -164,7 +341,7 @@ inline int suffix_sort_doubling(pfp_ctx *c, uint64_t N, uint64_t *k0, uint32_t *
                                 const uint32_t *ws, const uint32_t *wordid, const uint8_t *D, uint32_t *SA, uint2 *rj, int *rounds_out)
 {
     const size_t mk = c->arena.mark_hi();
-    uint32_t *head, *aux, *slots, *slots2, *d_cnt, *nj, *M = nullptr;
+    uint32_t *head, *aux, *slots, *slots2, *d_cnt, *nj, *onj = nullptr, *M = nullptr;
     PFP_ALLOC_HI(c, head, uint32_t, N);
     PFP_ALLOC_HI(c, aux, uint32_t, N);
     PFP_ALLOC_HI(c, slots, uint32_t, N);
@@ -184,7 +361,7 @@ inline int suffix_sort_doubling(pfp_ctx *c, uint64_t N, uint64_t *k0, uint32_t *
     int rounds = 1;
     const int rbits = bits_for(N);
     if (na > 0) {
-        PFP_ALLOC_HI(c, nj, uint32_t, na);
+        PFP_ALLOC_HI(c, nj, uint32_t, na); PFP_ALLOC_HI(c, onj, uint32_t, na);
         if (D) {   // run lengths for the run round
             PFP_ALLOC_HI(c, M, uint32_t, N);
             PFP_LAUNCH(c, K_SS_MAKE_KEYS, N * 5, k_ss_runend_marks, gN, D, N, M);
@@ -200,12 +377,12 @@ inline int suffix_sort_doubling(pfp_ctx *c, uint64_t N, uint64_t *k0, uint32_t *
         // build keys for the active list into k0/v0 (previous contents are dead: SA/rank/jump hold the state)
         PFP_LAUNCH(c, K_SS_MAKE_KEYS, (uint64_t)na * 36, k_ss_make_keys, ga, (const uint32_t *)slots, (const uint32_t *)SA, (const uint2 *)rj, (uint64_t)na, N,
                    run_round ? D : (const uint8_t *)nullptr, run_round ? (const uint32_t *)M : (const uint32_t *)nullptr, run_round ? 32 : rbits, k0, v0, nj);
-        PFP_LAUNCH(c, K_SS_MAKE_KEYS, (uint64_t)na * 12, k_ss_apply_jump, ga, (const uint32_t *)v0, (const uint32_t *)nj, (uint64_t)na, rj);
-        BitRange rr = {0, (run_round ? 32 : rbits) + rbits};
-        PFP_TRY(radix_sort_pairs<uint64_t>(c, k0, v0, k1, v1, na, &rr, 1, &sk, &sv));
+        uint32_t *snj = nullptr;
+        PFP_TRY(class_segment_sort(c, k0, v0, nj, k1, v1, onj, na, run_round ? 32 : rbits, rbits, rj, &sk, &sv, &snj));
         PFP_LAUNCH(c, K_SS_HEADS, (uint64_t)na * 28, k_ss_heads, ga, (const uint64_t *)sk, (const uint32_t *)sv, (const uint32_t *)slots, (uint64_t)na, SA, head, aux);
         PFP_TRY((device_scan<uint32_t, 1>(c, aux, aux, na, nullptr)));
-        PFP_LAUNCH(c, K_SS_WRITE_RANK, (uint64_t)na * 12, k_ss_write_rank, ga, (const uint32_t *)sv, (const uint32_t *)aux, (uint64_t)na, rj);
+        if (snj) PFP_LAUNCH(c, K_SS_WRITE_RANK, (uint64_t)na * 20, k_ss_write_rank_jump, ga, (const uint32_t *)sv, (const uint32_t *)aux, (const uint32_t *)snj, (uint64_t)na, rj);
+        else PFP_LAUNCH(c, K_SS_WRITE_RANK, (uint64_t)na * 12, k_ss_write_rank, ga, (const uint32_t *)sv, (const uint32_t *)aux, (uint64_t)na, rj);
         ++rounds;
         PFP_LAUNCH(c, K_SS_FLAG_ACTIVE, (uint64_t)na * 16, k_ss_flag_active, ga, (const uint32_t *)sv, (const uint32_t *)head, (uint64_t)na, (const uint2 *)rj, ws, wordid, keep);
         PFP_TRY(device_compact(c, slots, keep, na, slots2, head /*pos scratch*/, d_cnt));

@@ -106,7 +106,7 @@ F = lambda **kw: pfbwt_hip.PfpContext(lib=EMU_SO, **kw)
 import os, random
 man, recs = golden_case("w4p7")
 cases = [([s for _, s in recs], man["w"], man["p"])]
-if "PFP_BIG_GROUP_MEMBERS" in os.environ:       # a small "panel": many words share long suffixes -> groups with many members
+if "PFP_BIG_GROUP_MEMBERS" in os.environ or "PFP_CLASS_SORT_MIN" in os.environ:       # a small "panel": many words share long suffixes -> groups with many members
     rng = random.Random(5); base = [rng.choice("ACGT") for _ in range(1500)]; haps = []
     for h in range(7):
         b = list(base)
@@ -128,7 +128,7 @@ print("variant ok")
 @pytest.mark.parametrize("env", [{"PFP_FORCE_WIDE_ROWS": "1"}, {"PFP_EMIT_CHUNK_ROWS": "777"}, {"PFP_FORCE_WIDE_ROWS": "1", "PFP_EMIT_CHUNK_ROWS": "1000"},
                                  {"PFP_EMIT_CHUNK_ROWS": "777", "PFP_SAMPLE_CAP": "40"},
                                  {"PFP_BIG_GROUP_MEMBERS": "1"}, {"PFP_BIG_GROUP_MEMBERS": "2", "PFP_EMIT_CHUNK_ROWS": "5000"},
-                                 {"PFP_BIG_GROUP_MEMBERS": "-1"}])
+                                 {"PFP_BIG_GROUP_MEMBERS": "-1"}, {"PFP_CLASS_SORT_MIN": "1"}, {"PFP_CLASS_SORT_MIN": "1", "PFP_CLASS_SORT_MAXRANGE": "150"}])
 def test_emu_wide_rows_and_chunked_emission(emu_factory, env):
     """The code paths taken by texts of 2^32 bases and more (64-bit row counters, emission in windows of rows, run
     samples in two passes) and the sort route for groups of equal suffixes with many members, forced on small inputs: every output combination must still equal the oracle."""

@@ -148,3 +148,36 @@ def test_engine_ragged_inputs(gpu_ctx_factory):
     """empty records, records shorter than w, hundreds of tiny records, one-word parses"""
     from pfp_testlib import check_ragged
     check_ragged(gpu_ctx_factory)
+
+
+CLASS_SORT_CODE = r'''
+import sys
+sys.path.insert(0, sys.argv[1] + "/tests")
+from pfp_testlib import *
+from test_gpu_parity import synth
+import pfbwt_hip
+seqs = synth(77, 50000, 40)
+ref = oracle_run(seqs, w=10, p=20, U=8)
+res = engine_run(lambda **kw: pfbwt_hip.PfpContext(**kw), seqs, 10, 20, 8, sa=True, rssa=True)
+bad = compare(res, ref, 8)
+assert bad == [], bad
+print("class sort variant ok")
+'''
+
+
+@pytest.mark.parametrize("env", [{"PFP_CLASS_SORT_MIN": "1", "PFP_CLASS_SORT_MAXRANGE": "1930"}, {"PFP_CLASS_SORT_MIN": "1"}, {"PFP_CLASS_SORT_MIN": "-1"}])
+def test_doubling_round_sort_routes(env):
+    """the sort of a doubling round: classes sorted inside LDS tiles, classes too large for a tile collected and radix-sorted
+    (forced by a smaller range limit), and the plain radix sort alone -- every route must give the oracle's arrays"""
+    import subprocess, sys
+    e = dict(os.environ); e.update(env); e["PFP_VERBOSE"] = "1"
+    pr = subprocess.run([sys.executable, "-c", CLASS_SORT_CODE, ROOT], env=e, capture_output=True, text=True, timeout=900)
+    assert pr.returncode == 0 and "class sort variant ok" in pr.stdout, pr.stdout[-1500:] + pr.stderr[-3000:]
+    lines = [l for l in pr.stderr.splitlines() if "class sort:" in l]
+    if env.get("PFP_CLASS_SORT_MAXRANGE"):       # the mixed route really ran: some, but not most, pairs were in "large" classes
+        mixed = [l for l in lines if "plain radix" not in l and " 0 in classes" not in l]
+        assert mixed, lines[:10]
+    elif env["PFP_CLASS_SORT_MIN"] == "1":
+        assert lines, "class sort not taken"
+    else:
+        assert not lines
