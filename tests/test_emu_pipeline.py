@@ -125,13 +125,14 @@ print("variant ok")
 '''
 
 
-@pytest.mark.parametrize("env", [{"PFP_FORCE_WIDE_ROWS": "1"}, {"PFP_EMIT_CHUNK_ROWS": "777"}, {"PFP_FORCE_WIDE_ROWS": "1", "PFP_EMIT_CHUNK_ROWS": "1000"},
+@pytest.mark.parametrize("env", [{"PFP_FORCE_WIDE_ROWS": "1"}, {"PFP_FORCE_WIDE_ROWS": "1", "PFP_EMIT_CHUNK_ROWS": "1000"},
                                  {"PFP_EMIT_CHUNK_ROWS": "777", "PFP_SAMPLE_CAP": "40"},
-                                 {"PFP_BIG_GROUP_MEMBERS": "1"}, {"PFP_BIG_GROUP_MEMBERS": "2", "PFP_EMIT_CHUNK_ROWS": "5000"},
-                                 {"PFP_BIG_GROUP_MEMBERS": "-1"}, {"PFP_CLASS_SORT_MIN": "1"}, {"PFP_CLASS_SORT_MIN": "1", "PFP_CLASS_SORT_MAXRANGE": "150"}])
+                                 {"PFP_BIG_GROUP_MEMBERS": "1", "PFP_CLASS_SORT_MIN": "1"},
+                                 {"PFP_BIG_GROUP_MEMBERS": "2", "PFP_EMIT_CHUNK_ROWS": "5000", "PFP_CLASS_SORT_MIN": "1", "PFP_CLASS_SORT_MAXRANGE": "150"}])
 def test_emu_wide_rows_and_chunked_emission(emu_factory, env):
     """The code paths taken by texts of 2^32 bases and more (64-bit row counters, emission in windows of rows, run
-    samples in two passes) and the sort route for groups of equal suffixes with many members, forced on small inputs: every output combination must still equal the oracle."""
+    samples in two passes), the sort route for groups of equal suffixes with many members and the LDS class sort of the
+    doubling rounds, forced on small inputs: every output combination must still equal the oracle."""
     import sys
     from pfp_testlib import ROOT
     e = dict(os.environ); e.update(env)
