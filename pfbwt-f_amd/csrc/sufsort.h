@@ -201,7 +201,8 @@ template <typename K> __global__ __launch_bounds__(BLOCK) void k_class_tile_sort
     const uint32_t n = (uint32_t)(e - s);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;
-    const uint32_t base = (uint32_t)wave * (ITEMS * WAVE) + lane;
+    const uint32_t nit = (n + BLOCK - 1) / BLOCK;                 // pairs per thread this range needs (ranges are ~half a tile)
+    const uint32_t base = (uint32_t)wave * (nit * WAVE) + lane;   // wave w owns the contiguous pairs [w * nit * 64, (w + 1) * nit * 64)
     for (uint32_t j = threadIdx.x; j < n; j += BLOCK) { skeys[j] = keys[s + j]; sidx[j] = (uint16_t)j; }
     __syncthreads();
     const K lomask = lowbits >= 64 ? ~(K)0 : (((K)1 << lowbits) - 1);
@@ -215,6 +216,7 @@ template <typename K> __global__ __launch_bounds__(BLOCK) void k_class_tile_sort
         __syncthreads();
 #pragma unroll
         for (int it = 0; it < ITEMS; ++it) {
+            if ((uint32_t)it >= nit) break;                          // uniform
             const uint32_t i = base + (uint32_t)it * WAVE;
             const bool valid = i < n;
             k[it] = valid ? skeys[i] : (K)0; v[it] = valid ? sidx[i] : (uint16_t)0;
@@ -245,6 +247,7 @@ template <typename K> __global__ __launch_bounds__(BLOCK) void k_class_tile_sort
         __syncthreads();
 #pragma unroll
         for (int it = 0; it < ITEMS; ++it) {
+            if ((uint32_t)it >= nit) break;                          // uniform
             const uint32_t i = base + (uint32_t)it * WAVE;
             if (i < n) { const uint32_t li = wh[wave][dg[it] & 255u] + (dg[it] >> 8); skeys[li] = k[it]; sidx[li] = v[it]; }
         }
