@@ -576,10 +576,10 @@ __global__ __launch_bounds__(BLOCK) void k_run_tile_count(const uint8_t *bwt, ui
     if (threadIdx.x == 0) tilecnt[blockIdx.x] = tot;
 }
 // .ssa / .esa pairs, src/pfbwt-f.cpp:306-315 and :325-328, for a window of rows: row index = row_base + j, run index =
-// run_base + tilebase[tile] + rank inside the tile; total_rows / total_runs describe the whole output.  The SA value of
+// run_base + tilebase[tile] + rank inside the tile; total_rows / total_runs_plus1 - 1 describe the whole output.  The SA value of
 // row j is sa[j] (sa[-1] valid when has_prev) or, in samples-only mode (sa == nullptr), computed from qrow[j].
 template <typename SAT, typename EBT> __global__ __launch_bounds__(BLOCK) void k_samples_tile(EmitArgs a, const uint8_t *bwt, uint64_t rows, int has_prev, const uint32_t *tilebase, const SAT *sa, const uint32_t *qrow,
-                                                                                              uint64_t row_base, uint64_t run_base, uint64_t total_rows, uint64_t total_runs, SAT *ssa, SAT *esa)
+                                                                                              uint64_t row_base, uint64_t run_base, uint64_t total_rows, uint64_t total_runs_plus1 /*0: this window does not hold the last row*/, SAT *ssa, SAT *esa)
 {
     __shared__ uint32_t red[4];
     __shared__ uint32_t ebl[EMIT_LDS_SLOTS];     // samples-only mode: EB of the slots under this tile's rows, relative to the first
@@ -616,9 +616,11 @@ template <typename SAT, typename EBT> __global__ __launch_bounds__(BLOCK) void k
         if (o) { esa[2 * (k - 1)] = (SAT)(o - 1); esa[2 * (k - 1) + 1] = value(j - 1); }
         ++k;
     }
-    if (total_runs && j0 < rows && row_base + rows == total_rows && total_rows - 1 - row_base - j0 < RUN_PER_THREAD) {   // the last row of the output ends the last run
+    if (total_runs_plus1 && j0 < rows && row_base + rows == total_rows && total_rows - 1 - row_base - j0 < RUN_PER_THREAD) {   // the last row of the output ends the last run
+        // (index -1 when no run starts in this slice: esa then points one pair past the slice's first entry, see emit_and_sample)
+        const long long last = (long long)total_runs_plus1 - 2;
         const uint64_t j = rows - 1;
-        esa[2 * (total_runs - 1)] = (SAT)(row_base + j); esa[2 * (total_runs - 1) + 1] = value(j);
+        *(esa + 2 * last) = (SAT)(row_base + j); *(esa + 2 * last + 1) = value(j);
     }
 }
 

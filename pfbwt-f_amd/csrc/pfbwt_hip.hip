@@ -814,7 +814,7 @@ template <typename SAT, typename EBT> static int emit_and_sample(pfp_ctx *c, Emi
             if (!overflow && run_base + rc > cap) overflow = true;
             if (!overflow)
                 PFP_LAUNCH(c, K_SAMPLES, rows + (uint64_t)rc * (32 + 4 * sizeof(SAT)), (k_samples_tile<SAT, EBT>), ntiles, ea, (const uint8_t *)bw, rows, (int)cl, (const uint32_t *)tilebase, (const SAT *)nullptr,
-                           (const uint32_t *)(qtmp + cl), cs, run_base, total, ce == total ? run_base + rc : (uint64_t)0, ssa, esa_w);
+                           (const uint32_t *)(qtmp + cl), cs, run_base, total, ce == total ? run_base + rc + 1 : (uint64_t)0, ssa, esa_w);
             run_base += rc;
         }
         c->runs = run_base; c->esa_pairs = run_base - (s0 == 0 ? 1 : 0) + (s1 == total ? 1 : 0);
@@ -861,7 +861,7 @@ template <typename SAT, typename EBT> static int emit_and_sample(pfp_ctx *c, Emi
             PFP_TRY((device_scan<uint32_t, 0>(c, tilecnt, tilebase, ntiles, d_cnt)));
             uint32_t rc = 0; PFP_TRY(d2h_u32(c, d_cnt, &rc));
             PFP_LAUNCH(c, K_SAMPLES, rows + (uint64_t)rc * (32 + 4 * sizeof(SAT)), (k_samples_tile<SAT, EBT>), ntiles, ea, (const uint8_t *)bw, rows, (int)cl, (const uint32_t *)tilebase,
-                       sabuf ? (const SAT *)(sabuf + (cs - (s0 - lead))) : (const SAT *)nullptr, (const uint32_t *)(sabuf ? nullptr : qtmp + cl), cs, run_base, total, ce == total ? r : (uint64_t)0, ssa, esa_w);
+                       sabuf ? (const SAT *)(sabuf + (cs - (s0 - lead))) : (const SAT *)nullptr, (const uint32_t *)(sabuf ? nullptr : qtmp + cl), cs, run_base, total, ce == total ? r + 1 : (uint64_t)0, ssa, esa_w);
             run_base += rc;
         }
         if (run_base != r) return PFP_E_CORRUPT;

@@ -147,6 +147,15 @@ def test_sliced_emission_emu(emu_factory):
     sliced_samples(emu_factory, seqs, 4, 7, 4, 2, ref, sa=True)
 
 
+def test_sliced_samples_with_runless_slices_emu(emu_factory):
+    """a text whose BWT is a few long runs: most slices hold no run start at all (only the last row's run end in the last one)"""
+    seqs = [b"A" * 700 + b"C" * 500, b"A" * 900]
+    ref = oracle_run(seqs, w=4, p=7, U=8)
+    for ns in (4, 9):
+        sliced_samples(emu_factory, seqs, 4, 7, 8, ns, ref, sa=False)
+    sliced_samples(emu_factory, seqs, 4, 7, 8, 5, ref, sa=True)
+
+
 @pytest.mark.gpu
 def test_sliced_emission_gpu(gpu_ctx_factory):
     for seed, L, H, w, p, U in ((5, 200000, 4, 10, 100, 4), (6, 60000, 3, 4, 7, 8)):
