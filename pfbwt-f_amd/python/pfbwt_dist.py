@@ -36,8 +36,14 @@ def allgather_shards(ctx, device, group=None):
     maxb = int(max(int(m[4]) for m in metas))
     if buf.numel() < maxb:
         pad = torch.empty(maxb, dtype=torch.uint8, device=device); pad[:buf.numel()] = buf; buf = pad
-    recv = [torch.empty(maxb, dtype=torch.uint8, device=device) for _ in range(world)]
-    dist.all_gather(recv, buf[:maxb].contiguous(), group=group)
+    if dist.get_backend(group) == "nccl":
+        # one receive buffer, no staging copies inside the collective (the payloads are GBs on a 1000-haplotype collection)
+        flat = torch.empty(world * maxb, dtype=torch.uint8, device=device)
+        dist.all_gather_into_tensor(flat, buf[:maxb], group=group)
+        recv = [flat[r * maxb:(r + 1) * maxb] for r in range(world)]
+    else:
+        recv = [torch.empty(maxb, dtype=torch.uint8, device=device) for _ in range(world)]
+        dist.all_gather(recv, buf[:maxb].contiguous(), group=group)
     if torch.device(device).type == "cuda":
         # the collective runs on torch's / RCCL's stream, the engine reads the receive buffers on its own HIP stream:
         # the host waits for the collective before the pointers are handed over
