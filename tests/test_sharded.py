@@ -178,3 +178,39 @@ def test_sharded_merge_gpu(gpu_ctx_factory):
     seqs = synth(10, 60000, 4)
     ref = oracle_run(seqs, w=4, p=7, U=8)
     assert compare(sharded_single_process(gpu_ctx_factory, seqs, [[0], [1, 2], [3]], 4, 7, 8), ref, 8) == []
+
+
+NCCL_WORKER = r'''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.path.join(sys.argv[1], "tests")); sys.path.insert(0, os.path.join(sys.argv[1], "pfbwt-f_amd", "python"))
+from pfp_testlib import compare, oracle_run
+from test_sharded import synth
+import pfbwt_hip, pfbwt_dist
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+seqs = synth(21, 200000, 5)
+dev = torch.device("cuda", 0)
+d = [torch.from_numpy(np.frombuffer(s, np.uint8).copy()).to(dev) for s in seqs]
+ctx = pfbwt_hip.PfpContext(w=10, p=100, u64=True, sai=True, device=0)
+feed = lambda c: [c.feed_device(t.data_ptr(), t.numel(), True) for t in d]
+ref = oracle_run(seqs, w=10, p=100, U=8)
+for sa, rssa in ((True, False), (False, True)):
+    sz, b, begin, rows = pfbwt_dist.sharded_build(ctx, feed, 10, dev, sa=sa, rssa=rssa)
+    o = ctx.bwt_get()
+    res = {"n": sz.n, "m": sz.m, "dwords": sz.dwords, "dsize": sz.dsize, "r": int(b.r), "bwt": o["bwt"], "sa": o["sa"], "ssa": o["ssa"], "esa": o["esa"]}
+    bad = compare(res, ref, 8, names=("bwt", "sa") if sa else ("bwt", "ssa", "esa"))
+    assert bad == [] and begin == 0 and rows == sz.n + 1, bad
+dist.barrier(); dist.destroy_process_group()
+print("nccl world-1 ok")
+'''
+
+
+@pytest.mark.gpu
+def test_sharded_build_rccl_world1(tmp_path):
+    """pfbwt_dist.sharded_build through the RCCL backend on the one GPU of the test box (world size 1): the collective calls,
+    the hand-over of the receive buffer from torch's stream to the engine's stream, merge of a single shard, slice 0 of 1"""
+    script = tmp_path / "nccl_worker.py"
+    script.write_text(NCCL_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29653", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    pr = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, env=env, timeout=600)
+    assert pr.returncode == 0 and "nccl world-1 ok" in pr.stdout, pr.stdout[-2000:] + pr.stderr[-3000:]
