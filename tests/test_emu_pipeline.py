@@ -113,10 +113,10 @@ if "PFP_BIG_GROUP_MEMBERS" in os.environ or "PFP_CLASS_SORT_MIN" in os.environ: 
         for _ in range(40): b[rng.randrange(len(b))] = rng.choice("ACGT")
         haps.append("".join(b).encode())
     cases.append((haps, 4, 11))
-for seqs, w, p in cases:
-    for U in (8, 4):
+for ci, (seqs, w, p) in enumerate(cases):
+    for U in ((8, 4) if ci == 0 else (8,)):
         ref = oracle_run(seqs, w=w, p=p, U=U)
-        for sa, rssa in (((True, True), (False, True), (True, False), (False, False)) if U == 8 else ((True, True), (False, True))):
+        for sa, rssa in (((True, True), (False, True), (True, False), (False, False)) if (U == 8 and ci == 0) else ((True, True), (False, True))):
             res = engine_run(F, seqs, w, p, U, sa=sa, rssa=rssa)
             names = ["bwt"] + (["sa"] if sa else []) + (["ssa", "esa"] if rssa else [])
             bad = compare(res, ref, U, names=tuple(names))
