@@ -96,13 +96,17 @@ __global__ __launch_bounds__(BLOCK) void k_ss_init_rj(const uint32_t *vals, cons
 // ws/wordid != nullptr selects dictionary semantics: a class whose covered prefix [x, jump[x]) already
 // contains the terminator is a group of byte-identical suffixes and is final.
 __global__ __launch_bounds__(BLOCK) void k_ss_flag_active(const uint32_t *vals, const uint32_t *head, uint64_t na, const uint2 *rj, const uint32_t *jump_sorted /*nullable: jump of vals[a]*/,
-                                                          const uint32_t *ws, const uint32_t *wordid, uint32_t *keep)
+                                                          const uint64_t *dict_init_keys /*nullable: first call of a dictionary sort*/, const uint32_t *ws, const uint32_t *wordid, uint32_t *keep)
 {
     const uint64_t a = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (a >= na) return;
     const bool single = head[a] && (a + 1 == na || head[a + 1]);
     bool fin = single;
-    if (!fin && ws) {
+    if (!fin && dict_init_keys) {
+        // after the initial sort the covered prefix is the 16 characters of the key: it contains the word's terminator exactly
+        // when the last base-9 digit is 0 (padding behind a terminator) or the terminator itself (k_dict_init_keys) -- no gathers
+        fin = dict_init_keys[a] % 9u <= 1u;
+    } else if (!fin && ws) {
         const uint32_t x = vals[a];
         const uint32_t term = ws[wordid[x] + 1] - 1u;     // offset of the EndOfWord of x's word
         fin = (jump_sorted ? jump_sorted[a] : reinterpret_cast<const uint32_t *>(rj)[2 * (uint64_t)x + 1]) > term;
@@ -358,7 +362,7 @@ inline int suffix_sort_doubling(pfp_ctx *c, uint64_t N, uint64_t *k0, uint32_t *
     PFP_LAUNCH(c, K_SS_WRITE_RANK, N * 16, k_ss_init_rj, gN, (const uint32_t *)sv, (const uint32_t *)aux, N, h0, rj);
     // first active list
     uint32_t *keep = aux; // aux is free again after write_rank
-    PFP_LAUNCH(c, K_SS_FLAG_ACTIVE, N * 16, k_ss_flag_active, gN, (const uint32_t *)sv, (const uint32_t *)head, N, (const uint2 *)rj, (const uint32_t *)nullptr, ws, wordid, keep);
+    PFP_LAUNCH(c, K_SS_FLAG_ACTIVE, N * 16, k_ss_flag_active, gN, (const uint32_t *)sv, (const uint32_t *)head, N, (const uint2 *)rj, (const uint32_t *)nullptr, ws ? (const uint64_t *)sk : (const uint64_t *)nullptr, ws, wordid, keep);
     PFP_TRY(device_compact(c, nullptr, keep, N, slots, slots2, d_cnt));
     uint32_t na = 0; PFP_TRY(d2h_u32(c, d_cnt, &na));
     int rounds = 1;
@@ -387,7 +391,7 @@ inline int suffix_sort_doubling(pfp_ctx *c, uint64_t N, uint64_t *k0, uint32_t *
         if (snj) PFP_LAUNCH(c, K_SS_WRITE_RANK, (uint64_t)na * 20, k_ss_write_rank_jump, ga, (const uint32_t *)sv, (const uint32_t *)aux, (const uint32_t *)snj, (uint64_t)na, rj);
         else PFP_LAUNCH(c, K_SS_WRITE_RANK, (uint64_t)na * 12, k_ss_write_rank, ga, (const uint32_t *)sv, (const uint32_t *)aux, (uint64_t)na, rj);
         ++rounds;
-        PFP_LAUNCH(c, K_SS_FLAG_ACTIVE, (uint64_t)na * 16, k_ss_flag_active, ga, (const uint32_t *)sv, (const uint32_t *)head, (uint64_t)na, (const uint2 *)rj, (const uint32_t *)snj, ws, wordid, keep);
+        PFP_LAUNCH(c, K_SS_FLAG_ACTIVE, (uint64_t)na * 16, k_ss_flag_active, ga, (const uint32_t *)sv, (const uint32_t *)head, (uint64_t)na, (const uint2 *)rj, (const uint32_t *)snj, (const uint64_t *)nullptr, ws, wordid, keep);
         PFP_TRY(device_compact(c, slots, keep, na, slots2, head /*pos scratch*/, d_cnt));
         uint32_t *t = slots; slots = slots2; slots2 = t;
         PFP_TRY(d2h_u32(c, d_cnt, &na));
