@@ -356,7 +356,10 @@ template <typename EBT> __device__ __forceinline__ uint64_t multi_group_pos(cons
 // Output-stationary emission.  A workgroup owns EMIT_TILE consecutive rows; the slots they come from
 // are a contiguous range found by two binary searches per workgroup; that slice of EB goes to LDS and
 // every row finds its slot there.
-constexpr int EMIT_PER_THREAD = 8;
+#ifndef PFP_EMIT_PER_THREAD
+#define PFP_EMIT_PER_THREAD 8
+#endif
+constexpr int EMIT_PER_THREAD = PFP_EMIT_PER_THREAD;
 constexpr int EMIT_TILE = BLOCK * EMIT_PER_THREAD;
 constexpr int EMIT_LDS_SLOTS = 4096;
 #ifndef PFP_EMIT_ROWS_IN_FLIGHT

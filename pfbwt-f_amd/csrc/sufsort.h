@@ -220,7 +220,7 @@ template <typename K> __global__ __launch_bounds__(BLOCK) void k_class_tile_sort
         __syncthreads();
 #pragma unroll
         for (int it = 0; it < ITEMS; ++it) {
-            if ((uint32_t)it >= nit) break;                          // uniform
+            if ((uint32_t)it < nit) {                                  // uniform; no break: the loop must unroll (register arrays)
             const uint32_t i = base + (uint32_t)it * WAVE;
             const bool valid = i < n;
             k[it] = valid ? skeys[i] : (K)0; v[it] = valid ? sidx[i] : (uint16_t)0;
@@ -236,6 +236,7 @@ template <typename K> __global__ __launch_bounds__(BLOCK) void k_class_tile_sort
             if (valid && lane == leader) { old = wh[wave][d]; wh[wave][d] = old + (uint32_t)__popcll(peers); }
             old = __shfl(old, leader);
             dg[it] = d | ((old + (uint32_t)__popcll(peers & lt)) << 8);        // digit and rank inside the wave
+            }
         }
         __syncthreads();
         {
@@ -251,9 +252,8 @@ template <typename K> __global__ __launch_bounds__(BLOCK) void k_class_tile_sort
         __syncthreads();
 #pragma unroll
         for (int it = 0; it < ITEMS; ++it) {
-            if ((uint32_t)it >= nit) break;                          // uniform
             const uint32_t i = base + (uint32_t)it * WAVE;
-            if (i < n) { const uint32_t li = wh[wave][dg[it] & 255u] + (dg[it] >> 8); skeys[li] = k[it]; sidx[li] = v[it]; }
+            if ((uint32_t)it < nit && i < n) { const uint32_t li = wh[wave][dg[it] & 255u] + (dg[it] >> 8); skeys[li] = k[it]; sidx[li] = v[it]; }
         }
         __syncthreads();
     }
