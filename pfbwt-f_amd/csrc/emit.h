@@ -361,7 +361,10 @@ template <typename EBT> __device__ __forceinline__ uint64_t multi_group_pos(cons
 #endif
 constexpr int EMIT_PER_THREAD = PFP_EMIT_PER_THREAD;
 constexpr int EMIT_TILE = BLOCK * EMIT_PER_THREAD;
-constexpr int EMIT_LDS_SLOTS = 4096;
+#ifndef PFP_EMIT_LDS_SLOTS
+#define PFP_EMIT_LDS_SLOTS 4096
+#endif
+constexpr int EMIT_LDS_SLOTS = PFP_EMIT_LDS_SLOTS;
 #ifndef PFP_EMIT_ROWS_IN_FLIGHT
 #define PFP_EMIT_ROWS_IN_FLIGHT 2
 #endif
