@@ -1,0 +1,67 @@
+"""GPU parity of the instantiations the S-32G headline is timed on: 64-bit row counters
+(k_emit<u64,u64>, k_samples_tile<u64,u64>), emission in windows of rows, the one-pass sample route and its exact
+two-pass fallback, the sort route for groups with many members -- forced on inputs small enough for the oracle through
+the same environment switches bench.py's parity leg uses, on the PRODUCT library (hipcc, gfx950), in -s, -r and
+sliced mode.  Semantics under test: include/pfbwt.hpp:96-194, src/pfbwt-f.cpp:298-328."""
+import os
+import subprocess
+import sys
+import pytest
+from pfp_testlib import ROOT
+
+pytestmark = pytest.mark.gpu
+
+ROUTE_CODE = r'''
+import sys, os
+sys.path.insert(0, sys.argv[1] + "/tests")
+from pfp_testlib import *
+from test_gpu_parity import synth
+import numpy as np
+import pfbwt_hip
+lib = pfbwt_hip.load_library()
+assert lib.pfp_backend().decode() == "hip-gfx950"
+F = lambda **kw: pfbwt_hip.PfpContext(**kw)
+cases = [(synth(31, 120000, 6), 10, 100),           # a panel: multi-member groups, several windows at the forced chunk sizes
+         (synth(32, 40000, 12), 4, 11)]             # short phrases, many words per group (sort route when forced)
+for ci, (seqs, w, p) in enumerate(cases):
+    for U in (8, 4):
+        ref = oracle_run(seqs, w=w, p=p, U=U)
+        for sa, rssa in ((True, True), (False, True), (True, False), (False, False)):
+            res = engine_run(F, seqs, w, p, U, sa=sa, rssa=rssa)
+            names = ["bwt"] + (["sa"] if sa else []) + (["ssa", "esa"] if rssa else [])
+            bad = compare(res, ref, U, names=tuple(names))
+            assert bad == [] and res["r"] == ref["r"], (ci, U, sa, rssa, bad)
+        # sliced mode (multi-GPU emission): concatenated slices == the single-context output
+        for ns, sa in ((3, True), (5, False)):
+            parts = {"bwt": [], "sa": [], "ssa": [], "esa": []}; r = 0
+            for sl in range(ns):
+                c = F(w=w, p=p, u64=(U == 8), sai=True)
+                for s in seqs: c.feed(s, True)
+                c.finalize(); c.parse_bwt()
+                b, beg, rows = c.bwt_build_slice(sl, ns, sa=sa, rssa=True)
+                o = c.bwt_get(); c.close()
+                assert beg == sum(len(x) for x in parts["bwt"]) and rows == len(o["bwt"])
+                for k in parts:
+                    if o.get(k) is not None: parts[k].append(o[k])
+                r += b.r
+            res = {k: np.concatenate(v) for k, v in parts.items() if v}; res["r"] = r
+            bad = compare(res, ref, U, names=("bwt", "sa", "ssa", "esa") if sa else ("bwt", "ssa", "esa"))
+            assert bad == [], (ci, U, ns, sa, bad)
+print("routes ok")
+'''
+
+ENVS = [
+    {"PFP_FORCE_WIDE_ROWS": "1"},
+    {"PFP_FORCE_WIDE_ROWS": "1", "PFP_EMIT_CHUNK_ROWS": "100000"},
+    {"PFP_FORCE_WIDE_ROWS": "1", "PFP_EMIT_CHUNK_ROWS": "1000"},
+    {"PFP_EMIT_CHUNK_ROWS": "7777", "PFP_SAMPLE_CAP": "40"},
+    {"PFP_BIG_GROUP_MEMBERS": "1"},
+    {"PFP_BIG_GROUP_MEMBERS": "2", "PFP_FORCE_WIDE_ROWS": "1", "PFP_EMIT_CHUNK_ROWS": "50000"},
+]
+
+
+@pytest.mark.parametrize("env", ENVS, ids=lambda e: ",".join("%s=%s" % (k.replace("PFP_", ""), v) for k, v in e.items()))
+def test_forced_emission_routes_gpu(env):
+    e = dict(os.environ); e.update(env)
+    pr = subprocess.run([sys.executable, "-c", ROUTE_CODE, ROOT], env=e, capture_output=True, text=True, timeout=1500)
+    assert pr.returncode == 0 and "routes ok" in pr.stdout, pr.stdout[-1500:] + pr.stderr[-3000:]
