@@ -102,8 +102,19 @@ struct EmitArgs {
     uint64_t nout, n;
     uint64_t e0, e1;        // rows (in enumeration order) this launch walks
     uint64_t w0, w1;        // output positions this launch may write: [w0, w1) -> buffer index pos - w0 (multi-GPU slices)
+    // Run-aware emission (no full SA wanted): rows of a group whose members all have the same preceding byte are one run
+    // of that byte -- they are written by k_fill without looking at the occurrence lists.  Only the rows of the other
+    // ("special") slots -- whole words, groups with a whole-word member, groups with two or more distinct preceding
+    // bytes -- are enumerated row by row, through a compacted list of them: elist[j] = slot, cpos[slot] = number of
+    // special slots in front of it (= j for a special slot), ENB[j] = exclusive scan of their counts (ecount + 1 entries),
+    // etile_slot = tile table over j, qspec = their parse rows (index: ENB[cpos[group head]] - q0 + position inside
+    // the group).  special == 0: ENB == EB, elist == nullptr (identity), every row is enumerated.
+    const void *ENB; const uint32_t *etile_slot, *elist, *cpos; uint32_t ecount; int special; uint64_t q0;
+    const uint32_t *qspec;  // samples-only mode: parse rows of the special rows of this window
+    const uint32_t *gqf, *gql;   // per head slot of a uniform multi-member group: parse row of its first / last output row
 };
-constexpr uint8_t SF_MULTI = 1, SF_FULL = 2, SF_BIG = 4, SF_GFULL = 8;   // GFULL: some member of the group is a whole word
+constexpr uint8_t SF_MULTI = 1, SF_FULL = 2, SF_BIG = 4, SF_GFULL = 8, SF_NONUNI = 16;   // GFULL: some member of the group is a whole word; NONUNI: members with different preceding bytes
+__device__ __forceinline__ bool slot_is_special(uint32_t fl) { return (fl & (SF_FULL | SF_GFULL | SF_NONUNI)) != 0; }
 constexpr uint32_t BIG_GROUP_MEMBERS = 64;  // groups with more members than this take the sort route (measured: below ~64 ranking is faster)
 // posinfo[x] = { word id of dictionary offset x | 4-bit code of D[x-1] << 28 , class-head slot of x }: one 8-byte
 // gather per slot instead of three separate random reads (wordid, grank, D[x-1])
@@ -137,10 +148,12 @@ template <typename T> __device__ __forceinline__ uint32_t upper_bound_t(const T 
 // cnt = rows produced (occ of the word if suff_len > w, pfbwt.hpp:114), suffix length, ilist base,
 // preceding byte, whole-word flag (pfbwt.hpp:116), multi-word-group flag (pfbwt.hpp:137).
 template <typename EBT> __global__ __launch_bounds__(BLOCK) void k_emit_slots(EmitArgs a, EBT *cnt, unsigned long long *hard_rows, uint32_t *s_sl, uint32_t *s_fb, uint8_t *s_fl, uint8_t *s_pc,
-                                                                             uint32_t *s_g0, uint32_t *gk /*per head slot: members*/, uint8_t *gfl /*per head slot: has a whole-word member*/)
+                                                                             uint32_t *s_g0, uint32_t *gk /*per head slot: members*/, uint8_t *gfl /*per head slot: has a whole-word member*/,
+                                                                             uint8_t *gnu /*per head slot: members with different preceding bytes*/)
 {
-    __shared__ uint8_t hd[BLOCK + 1];
-    __shared__ uint32_t red[4];   // is slot (block base + t) the head of its class of equal suffixes
+    __shared__ uint8_t hd[BLOCK + 1];   // is slot (block base + t) the head of its class of equal suffixes
+    __shared__ uint8_t pcl[BLOCK + 1];  // preceding byte of slot (block base + t); 0xFF: whole word (its group is special anyway)
+    __shared__ uint32_t red[4];
     const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     const bool valid = i < a.dsize;
     uint32_t x = 0; uint2 P = make_uint2(0, 0);
@@ -148,7 +161,19 @@ template <typename EBT> __global__ __launch_bounds__(BLOCK) void k_emit_slots(Em
     hd[threadIdx.x] = (valid && P.y == (uint32_t)i) ? 1 : 0;
     if (threadIdx.x == 0) {
         const uint64_t nx = (uint64_t)(blockIdx.x + 1) * BLOCK;
-        hd[BLOCK] = (nx < a.dsize) ? (a.posinfo[a.SA[nx]].y == (uint32_t)nx ? 1 : 0) : 1;
+        uint8_t h = 1, hp = 0xFF;
+        if (nx < a.dsize) {
+            const uint32_t xn = a.SA[nx]; const uint2 Pn = a.posinfo[xn];
+            h = Pn.y == (uint32_t)nx ? 1 : 0;
+            if (!h) {   // the first slot of the next block continues a group of this block: its preceding byte
+                const uint32_t idn = Pn.x & WID_MASK;
+                if (idn < a.dwords) {
+                    const uint32_t wsn = a.winfo[idn].x;
+                    if (xn != wsn) { hp = dict_byte4(Pn.x >> 28); if (hp == Dollar && xn - 1 == wsn) hp = 0; }
+                }
+            }
+        }
+        hd[BLOCK] = h; pcl[BLOCK] = hp;
     }
     __syncthreads();
     const uint32_t id = P.x & WID_MASK;
@@ -164,11 +189,16 @@ template <typename EBT> __global__ __launch_bounds__(BLOCK) void k_emit_slots(Em
             else { pc = dict_byte4(P.x >> 28); if (pc == Dollar && x - 1 == wsid) pc = 0; }   // pfbwt.hpp:132 "gsa[i]-1 ? dict[..] : 0"
         }
     }
+    pcl[threadIdx.x] = (fl & SF_FULL) ? (uint8_t)0xFF : pc;
+    __syncthreads();
     if (valid) {
         cnt[i] = (EBT)c; s_sl[i] = sl; s_fb[i] = fb; s_fl[i] = fl; s_pc[i] = pc; s_g0[i] = P.y;
         if (fl & SF_MULTI) {
-            if (i + 1 >= a.dsize || hd[threadIdx.x + 1]) gk[P.y] = (uint32_t)i - P.y + 1u;     // last member: group size
+            const bool lastm = i + 1 >= a.dsize || hd[threadIdx.x + 1];
+            if (lastm) gk[P.y] = (uint32_t)i - P.y + 1u;     // last member: group size
             if (fl & SF_FULL) gfl[P.y] = 1;
+            // two neighbouring members with different preceding bytes: the group's rows are not one run (pfbwt.hpp:146-159)
+            else if (!lastm && pcl[threadIdx.x + 1] != 0xFF && pcl[threadIdx.x + 1] != pc) gnu[P.y] = 1;
         }
     }
     uint32_t tot;   // rows that sit in multi-word groups (the reference's "hard" bookkeeping, pfbwt.hpp:188)
@@ -187,7 +217,8 @@ __device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t *a, uint32_t 
 // tens of members and thousands of rows): ranking every row in every other member's ilist costs O(members) bisections
 // per row.  Their rows are instead collected as (group head slot, q) keys, sorted, and placed by their index inside
 // the group.  Groups with a whole-word member keep the ranking route (reference quirk handling lives there).
-template <typename EBT> __global__ __launch_bounds__(BLOCK) void k_big_mark(const EBT *cnt, const uint32_t *s_g0, const uint32_t *gk, const uint8_t *gfl, const uint32_t *s_fb, uint64_t dsize, uint32_t min_members, uint8_t *s_fl, uint4 *sinfo, unsigned long long *big_rows)
+template <typename EBT> __global__ __launch_bounds__(BLOCK) void k_big_mark(const EBT *cnt, const uint32_t *s_g0, const uint32_t *gk, const uint8_t *gfl, const uint8_t *gnu, const uint32_t *s_fb, const uint32_t *ilist, uint64_t dsize, uint32_t min_members,
+                                                                            int runaware, uint8_t *s_fl, uint4 *sinfo, EBT *cnt2 /*runaware: rows of the special slots*/, uint32_t *gqf, uint32_t *gql, unsigned long long *big_rows)
 {
     __shared__ unsigned long long red[4];
     const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -195,14 +226,26 @@ template <typename EBT> __global__ __launch_bounds__(BLOCK) void k_big_mark(cons
     if (i < dsize) {
         uint8_t fl = s_fl[i];
         const uint32_t g0 = s_g0[i];
+        const uint32_t c = (uint32_t)cnt[i], fb = s_fb[i];
         uint32_t k = 1;
         if (fl & SF_MULTI) {
             k = gk[g0];
             if (gfl[g0]) fl |= SF_GFULL;
-            else if (k > min_members) { fl |= SF_BIG; mine = (unsigned long long)cnt[i]; }
+            else {
+                if (gnu[g0]) fl |= SF_NONUNI;
+                // without a full SA only the groups that are not one run of a byte are merged at all
+                if (k > min_members && (!runaware || (fl & SF_NONUNI))) { fl |= SF_BIG; mine = (unsigned long long)cnt[i]; }
+            }
             s_fl[i] = fl;
         }
-        sinfo[i] = make_uint4(s_fb[i], (uint32_t)cnt[i], g0, (k < 0xFFFFFFu ? k : 0xFFFFFFu) | ((uint32_t)fl << 24));
+        sinfo[i] = make_uint4(fb, c, g0, (k < 0xFFFFFFu ? k : 0xFFFFFFu) | ((uint32_t)fl << 24));
+        if (runaware) {
+            const bool sp = slot_is_special(fl);
+            cnt2[i] = sp ? cnt[i] : (EBT)0;
+            if (!sp && (fl & SF_MULTI) && c) {   // one run: only its first and last row can be sampled (smallest / largest parse row of the members)
+                atomicMin(&gqf[g0], ilist[fb]); atomicMax(&gql[g0], ilist[fb + c - 1u]);
+            }
+        }
     }
     unsigned long long tot;
     (void)block_excl_sum(mine, red, &tot);
@@ -230,6 +273,7 @@ template <typename SAT, typename EBT> __global__ __launch_bounds__(BLOCK) void k
     if (t >= nb) return;
     const uint32_t g0 = (uint32_t)(keys[t] >> 32), q = (uint32_t)keys[t], i = vals[t];
     const uint64_t pos = (uint64_t)reinterpret_cast<const EBT *>(a.EB)[g0] + (t - tg[t]);
+    if (a.special && qrow) qrow[(uint64_t)reinterpret_cast<const EBT *>(a.ENB)[a.cpos[g0]] - a.q0 + (t - tg[t])] = q;   // every enumerated row, also outside the window
     if (pos < a.w0 || pos >= a.w1) return;
     bwt[pos - a.w0] = a.s_pc[i];                                // no whole-word member in these groups
     if (sa) {
@@ -237,7 +281,7 @@ template <typename SAT, typename EBT> __global__ __launch_bounds__(BLOCK) void k
         if (pos == 0) v = (SAT)a.n;
         sa[pos - a.w0] = v;
     }
-    if (qrow) qrow[pos - a.w0] = q;
+    if (qrow && !a.special) qrow[pos - a.w0] = q;
 }
 
 // Position of a row inside a group without whole-word members: gb + r + the number of occurrences of the OTHER members
@@ -401,16 +445,17 @@ template <typename SAT, typename EBT> __global__ __launch_bounds__(BLOCK) void k
     __shared__ uint32_t rs[EMIT_TILE];                       // slot (relative to i0) of every row of the tile
     __shared__ uint32_t red[4];
     const EBT *EB = reinterpret_cast<const EBT *>(a.EB);
+    const EBT *ENB = reinterpret_cast<const EBT *>(a.ENB);      // enumeration order: == EB unless only the special slots are walked
     // tiles are aligned to multiples of EMIT_TILE in the global row numbering, so that the slots under a tile come from
     // the precomputed tile_slot table (k_tile_slots) instead of two 27-step bisections of EB per workgroup
     const uint64_t tb = a.e0 / EMIT_TILE + blockIdx.x;
     const uint64_t o0 = tb * EMIT_TILE > a.e0 ? tb * EMIT_TILE : a.e0;
     const uint64_t o1 = ((tb + 1) * EMIT_TILE < a.e1) ? (tb + 1) * EMIT_TILE : a.e1;   // exclusive
-    const uint32_t i0 = a.tile_slot[tb], i1 = a.tile_slot[tb + 1];   // a superset of the slots of rows [o0, o1)
+    const uint32_t i0 = a.etile_slot[tb], i1 = a.etile_slot[tb + 1];   // a superset of the slots of rows [o0, o1)
     const uint32_t ns = i1 - i0 + 1u;
-    const uint64_t ebase = (uint64_t)EB[i0];
+    const uint64_t ebase = (uint64_t)ENB[i0];
     const bool in_lds = ns <= (uint32_t)EMIT_LDS_SLOTS && o1 - ebase < 0xFFFFFFFFULL;
-    if (in_lds) for (uint32_t k = threadIdx.x; k < ns; k += BLOCK) eb[k] = (uint32_t)((uint64_t)EB[i0 + k] - ebase);
+    if (in_lds) for (uint32_t k = threadIdx.x; k < ns; k += BLOCK) eb[k] = (uint32_t)((uint64_t)ENB[i0 + k] - ebase);
     for (int k = threadIdx.x; k < EMIT_TILE; k += BLOCK) rs[k] = 0;
     __syncthreads();
     if (in_lds) {
@@ -450,7 +495,11 @@ template <typename SAT, typename EBT> __global__ __launch_bounds__(BLOCK) void k
             on[u] = o[u] < o1;
             const uint64_t oo = on[u] ? o[u] : o0;
             if (in_lds) { const uint32_t j = rs[(uint32_t)(oo - o0)]; i[u] = i0 + j; r[u] = (uint32_t)(oo - ebase) - eb[j]; }
-            else { i[u] = upper_bound_t<EBT>(EB, (uint32_t)a.dsize, (EBT)oo) - 1u; r[u] = (uint32_t)(oo - (uint64_t)EB[i[u]]); }
+            else { i[u] = upper_bound_t<EBT>(ENB, a.ecount, (EBT)oo) - 1u; r[u] = (uint32_t)(oo - (uint64_t)ENB[i[u]]); }
+        }
+        if (a.elist) {
+#pragma unroll
+            for (int u = 0; u < EMIT_ROWS_IN_FLIGHT; ++u) i[u] = a.elist[i[u]];       // index in the list of special slots -> slot
         }
 #pragma unroll
         for (int u = 0; u < EMIT_ROWS_IN_FLIGHT; ++u) { S[u] = a.sinfo[i[u]]; fl[u] = (uint8_t)(S[u].w >> 24); }
@@ -503,8 +552,11 @@ template <typename SAT, typename EBT> __global__ __launch_bounds__(BLOCK) void k
                 }
             }
             if (!on[u] || big) continue;
-            if (fl[u] & SF_GFULL) pos = multi_group_pos<EBT>(a, i[u], r[u], q[u], self_full, &full_emits_eow);
-            else if (fl[u] & SF_MULTI) pos = (uint64_t)EB[S[u].z] + before[u] + r[u];
+            uint32_t g = i[u];                                          // slot whose EB / ENB entry the row's position counts from
+            if (fl[u] & SF_GFULL) { pos = multi_group_pos<EBT>(a, i[u], r[u], q[u], self_full, &full_emits_eow); g = S[u].z; }
+            else if (fl[u] & SF_MULTI) { pos = (uint64_t)EB[S[u].z] + before[u] + r[u]; g = S[u].z; }
+            else if (a.special) pos = (uint64_t)EB[i[u]] + r[u];
+            if (a.special && qrow) qrow[(uint64_t)ENB[a.cpos[g]] - a.q0 + (pos - (uint64_t)EB[g])] = q[u];   // every enumerated row, also outside the window
             const uint8_t c = self_full ? (full_emits_eow ? (uint8_t)EndOfWord : a.bwlast[q[u]]) : a.s_pc[i[u]];   // pfbwt.hpp:116-128 / :132
             if (pos < a.w0 || pos >= a.w1) continue;                    // row of a boundary group that lands in another slice
             bwt[pos - a.w0] = c;
@@ -513,7 +565,7 @@ template <typename SAT, typename EBT> __global__ __launch_bounds__(BLOCK) void k
                 if (pos == 0) v = (SAT)a.n;                             // src/pfbwt-f.cpp:301
                 sa[pos - a.w0] = v;
             }
-            if (qrow) qrow[pos - a.w0] = q[u];
+            if (qrow && !a.special) qrow[pos - a.w0] = q[u];
         }
     }
 }
@@ -526,15 +578,91 @@ template <typename EBT> __global__ __launch_bounds__(BLOCK) void k_slice_bounds(
 {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     const EBT *EB = reinterpret_cast<const EBT *>(a.EB);
+    const EBT *ENB = reinterpret_cast<const EBT *>(a.ENB);
     const uint32_t il = slot_of_row<EBT>(a, lo);
-    out[0] = EB[a.posinfo[a.SA[il]].y];
-    if (hi >= a.nout) { out[1] = a.nout; return; }
+    const uint32_t gh = a.posinfo[a.SA[il]].y;
+    out[0] = EB[gh];
+    out[2] = a.special ? (unsigned long long)ENB[a.cpos[gh]] : 0ULL;      // the same range in the enumeration of the special rows
+    if (hi >= a.nout) { out[1] = a.nout; out[3] = a.special ? (unsigned long long)ENB[a.ecount] : 0ULL; return; }
     uint32_t s = slot_of_row<EBT>(a, hi - 1);
     const uint32_t g = a.posinfo[a.SA[s]].y;
     while (s < a.dsize && a.posinfo[a.SA[s]].y == g) ++s;
     while (s < a.dsize && (uint64_t)EB[s] < hi) ++s;       // slots that produce no rows keep EB unchanged
     out[1] = s < a.dsize ? (uint64_t)EB[s] : a.nout;
+    out[3] = a.special ? (unsigned long long)ENB[s < a.dsize ? a.cpos[s] : a.ecount] : 0ULL;
 }
+
+// Run-aware emission, the bulk of the rows: a slot whose group is one run writes cnt copies of its preceding byte.  Output-
+// stationary: a thread owns 16 consecutive rows (aligned in the global row numbering -> one 16-byte store).  The slots
+// under a tile of 4096 rows come from tile_slot; those that produce rows (at most 4097: dictionary suffixes of length
+// <= w have none and come in clusters of thousands) are compacted into LDS with their first row relative to the tile;
+// a thread bisects that list for its first row and walks on from there.  The rows of special slots get the placeholder
+// s_pc too and are overwritten by k_emit afterwards (same stream).  bwt points at row a.w0 and (bwt - a.w0) is 16-byte
+// aligned (host).
+constexpr int FILL_PER_THREAD = 16, FILL_SUB = BLOCK * FILL_PER_THREAD;      // 4096 rows = 2 emission tiles
+static_assert(FILL_SUB % EMIT_TILE == 0, "fill tiles are whole emission tiles");
+template <typename EBT> __global__ __launch_bounds__(BLOCK) void k_fill(EmitArgs a, uint8_t *bwt, uint32_t subs_per_wg)
+{
+    __shared__ uint32_t eb[FILL_SUB + 2];       // first row (relative to the tile start, clamped to 0) of the k-th slot with rows
+    __shared__ uint8_t pcs[FILL_SUB + 2];
+    __shared__ uint32_t wcnt[BLOCK / WAVE];
+    const EBT *EB = reinterpret_cast<const EBT *>(a.EB);
+    const EBT *cnt = reinterpret_cast<const EBT *>(a.cnt);
+    const uint64_t ntiles = (a.nout + EMIT_TILE - 1) / EMIT_TILE;
+    const uint64_t st0 = a.w0 / FILL_SUB + (uint64_t)blockIdx.x * subs_per_wg;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;
+    for (uint32_t ss = 0; ss < subs_per_wg; ++ss) {
+        const uint64_t st = st0 + ss, tstart = st * FILL_SUB;
+        const uint64_t o0 = tstart > a.w0 ? tstart : a.w0;
+        const uint64_t o1 = tstart + FILL_SUB < a.w1 ? tstart + FILL_SUB : a.w1;
+        if (o0 >= o1) break;                                  // uniform
+        constexpr uint64_t TPS = FILL_SUB / EMIT_TILE;
+        const uint64_t t1 = (st + 1) * TPS < ntiles ? (st + 1) * TPS : ntiles;
+        const uint32_t i0 = a.tile_slot[st * TPS], i1 = a.tile_slot[t1];
+        const uint32_t ns = i1 - i0 + 1u;
+        uint32_t nz = 0;                                      // slots with rows so far (the same in every thread)
+        for (uint32_t k0 = 0; k0 < ns; k0 += BLOCK) {
+            const uint32_t k = k0 + threadIdx.x;
+            const bool has = k < ns && cnt[i0 + k] != 0;
+            const unsigned long long bal = __ballot(has);
+            __syncthreads();                                  // wcnt (and, first round, eb / pcs of the previous tile) are free
+            if (lane == 0) wcnt[wave] = (uint32_t)__popcll(bal);
+            __syncthreads();
+            uint32_t base = nz, tot = 0;
+#pragma unroll
+            for (int v = 0; v < BLOCK / WAVE; ++v) { const uint32_t cw = wcnt[v]; if (v < wave) base += cw; tot += cw; }
+            if (has) {
+                const uint64_t e = (uint64_t)EB[i0 + k];
+                const uint32_t pos = base + (uint32_t)__popcll(bal & lt);
+                eb[pos] = e > tstart ? (uint32_t)(e - tstart) : 0u; pcs[pos] = a.s_pc[i0 + k];
+            }
+            nz += tot;
+        }
+        if (threadIdx.x == 0) eb[nz] = 0xFFFFFFFFu;
+        __syncthreads();
+        const uint64_t ra = tstart + (uint64_t)threadIdx.x * FILL_PER_THREAD;
+        const uint64_t lo = ra > o0 ? ra : o0, hi = ra + FILL_PER_THREAD < o1 ? ra + FILL_PER_THREAD : o1;
+        if (lo >= hi) continue;
+        uint32_t wd[FILL_PER_THREAD / 4] = {0, 0, 0, 0};
+        uint32_t rel = (uint32_t)(lo - tstart);
+        uint32_t s = upper_bound_t<uint32_t>(eb, nz, rel) - 1u;      // last slot with rows that starts at or before rel (eb[0] == 0: the slot of the tile's first row)
+        uint32_t nxt = eb[s + 1], c = pcs[s];
+#pragma unroll
+        for (int j = 0; j < FILL_PER_THREAD; ++j) {
+            const uint64_t o = ra + j;
+            if (o >= lo && o < hi) {
+                while (rel >= nxt) { ++s; nxt = eb[s + 1]; c = pcs[s]; }      // every step moves at least one row on
+                wd[j >> 2] |= c << (8 * (j & 3));
+                ++rel;
+            }
+        }
+        uint8_t *dst = bwt + (ra - a.w0);                     // may point in front of the buffer when ra < w0: only rows in [lo, hi) are stored
+        if (lo == ra && hi == ra + FILL_PER_THREAD) *reinterpret_cast<uint4 *>(dst) = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+        else for (uint64_t o = lo; o < hi; ++o) { const int j = (int)(o - ra); dst[j] = (uint8_t)(wd[j >> 2] >> (8 * (j & 3))); }
+    }
+}
+
 // run count only (no samples wanted): workgroup reduction + one atomic per workgroup.  `bwt` points at the first
 // row to count; has_prev says whether bwt[-1] holds the row in front of it (slices > 0).
 __global__ __launch_bounds__(BLOCK) void k_run_count(const uint8_t *bwt, uint64_t nout, int has_prev, unsigned long long *runs)
@@ -610,10 +738,19 @@ template <typename SAT, typename EBT> __global__ __launch_bounds__(BLOCK) void k
     auto value = [&](uint64_t j) -> SAT {     // j may be -1 (as uint64) for the row in front
         if (sa) return *(sa + j);
         const uint64_t o = row_base + j;
-        if (!in_lds) return sa_of_row<SAT, EBT>(a, *(qrow + j), o);
-        if (o == 0) return (SAT)a.n;
-        const uint32_t slot = i0 + upper_bound_t<uint32_t>(ebl, ns, (uint32_t)(o - ebase)) - 1u;
-        return (SAT)((SAT)a.bwsai[*(qrow + j)] - (SAT)a.s_sl[slot]);
+        if (o == 0) return (SAT)a.n;                                     // src/pfbwt-f.cpp:301
+        const uint32_t slot = in_lds ? i0 + upper_bound_t<uint32_t>(ebl, ns, (uint32_t)(o - ebase)) - 1u : slot_of_row<EBT>(a, o);
+        uint32_t q;
+        if (!a.special) q = *(qrow + j);
+        else {   // run-aware emission: the parse row of a sampled row is looked up, not stored per row
+            const uint4 S = a.sinfo[slot]; const uint32_t fl = S.w >> 24;
+            if (slot_is_special(fl)) {
+                const uint32_t g = (fl & SF_MULTI) ? S.z : slot;
+                q = a.qspec[(uint64_t)reinterpret_cast<const EBT *>(a.ENB)[a.cpos[g]] - a.q0 + (o - (uint64_t)EB[g])];
+            } else if (!(fl & SF_MULTI)) q = a.ilist[S.x + (uint32_t)(o - (uint64_t)EB[slot])];
+            else q = (o == (uint64_t)EB[S.z]) ? a.gqf[S.z] : a.gql[S.z];          // a run of one byte: only its first and last row are ever sampled
+        }
+        return (SAT)((SAT)a.bwsai[q] - (SAT)a.s_sl[slot]);
     };
     while (m) {
         const int b = __ffs((int)m) - 1; m &= m - 1;

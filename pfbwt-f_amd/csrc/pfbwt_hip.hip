@@ -720,10 +720,23 @@ int pfp_bwt_load(pfp_ctx *c, const uint8_t *dict, uint64_t dsize, const void *oc
 }
 
 extern "C++" {
+__global__ __launch_bounds__(BLOCK) void k_flag_special(const uint8_t *s_fl, uint64_t dsize, uint32_t *flag)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < dsize) flag[i] = slot_is_special(s_fl[i]) ? 1u : 0u;
+}
+template <typename EBT> __global__ __launch_bounds__(BLOCK) void k_gather_counts(const EBT *cnt, const uint32_t *list, uint64_t n, EBT *out)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (j < n) out[j] = cnt[list[j]];
+}
+
 // Emission of the rows [s0, s1) of this slice (all rows when nslices == 1), in windows of at most `chunk_rows` rows so
-// that the per-window scratch (run flags, SA values needed only at run boundaries) stays bounded for texts of tens of
+// that the per-window scratch (parse rows of the enumerated rows, run counts) stays bounded for texts of tens of
 // Gbases.  Rows of a group of equal suffixes that straddles a window boundary are enumerated for both windows.
-template <typename SAT, typename EBT> static int emit_and_sample(pfp_ctx *c, EmitArgs ea, bool want_sa, bool want_rssa, int slice, int nslices)
+// ea.special != 0 (no full SA wanted): run-aware emission -- k_fill writes every row as a run of its slot's preceding
+// byte, k_emit walks only the rows of the special slots (tot2 of them), samples look their parse rows up.
+template <typename SAT, typename EBT> static int emit_and_sample(pfp_ctx *c, EmitArgs ea, bool want_sa, bool want_rssa, int slice, int nslices, uint64_t tot2)
 {
     const uint64_t total = ea.nout;
     const uint64_t s0 = total / (uint64_t)nslices * (uint64_t)slice + (total % (uint64_t)nslices) * (uint64_t)slice / (uint64_t)nslices;
@@ -735,7 +748,10 @@ template <typename SAT, typename EBT> static int emit_and_sample(pfp_ctx *c, Emi
     if (!chunk_rows) { const char *e = getenv("PFP_EMIT_CHUNK_ROWS"); chunk_rows = (e && atoll(e) > 0) ? (uint64_t)atoll(e) : (1ULL << 30); }
     const uint64_t nchunks = (nrows + chunk_rows - 1) / chunk_rows;
     const bool windowed = nslices > 1 || nchunks > 1;
-    uint8_t *bwtbuf; PFP_ALLOC_LO(c, bwtbuf, uint8_t, nrows + lead + 16);
+    const bool runaware = ea.special != 0;
+    // the byte of output row o lives at (bwtbuf - (s0 - lead)) + o, and that address is congruent to o modulo 16 (k_fill stores 16 aligned rows at a time)
+    uint8_t *bwtraw; PFP_ALLOC_LO(c, bwtraw, uint8_t, nrows + lead + 48);
+    uint8_t *bwtbuf = bwtraw + ((s0 - lead) & 15);
     c->d_bwt = bwtbuf + lead;
     const bool keep_sa = want_sa;                          // a full SA array for this slice lives in the arena
     SAT *sabuf = nullptr;
@@ -743,6 +759,25 @@ template <typename SAT, typename EBT> static int emit_and_sample(pfp_ctx *c, Emi
     c->d_sa = sabuf ? sabuf + lead : nullptr;
     c->d_ssa = c->d_esa = nullptr;
     unsigned long long *d_b; PFP_ALLOC_HI(c, d_b, unsigned long long, 6);
+    // windows: rows [cs - cl, ce) are written, [e0, e1) (all rows) resp. [q0, q1) (special rows) are enumerated for them
+    struct Win { uint64_t cs, ce, cl, e0, e1, q0, q1; };
+    std::vector<Win> wins((size_t)nchunks);
+    for (uint64_t ch = 0; ch < nchunks; ++ch) {
+        Win &wn = wins[(size_t)ch];
+        wn.cs = s0 + ch * chunk_rows; wn.ce = (wn.cs + chunk_rows < s1) ? wn.cs + chunk_rows : s1; wn.cl = wn.cs ? 1 : 0;
+        wn.e0 = 0; wn.e1 = total; wn.q0 = 0; wn.q1 = tot2;
+    }
+    if (windowed) {
+        unsigned long long *d_bounds; PFP_ALLOC_HI(c, d_bounds, unsigned long long, 4 * nchunks);
+        for (uint64_t ch = 0; ch < nchunks; ++ch)
+            PFP_LAUNCH(c, K_MISC, 64, (k_slice_bounds<EBT>), 1, ea, wins[(size_t)ch].cs - wins[(size_t)ch].cl, wins[(size_t)ch].ce, d_bounds + 4 * ch);
+        std::vector<unsigned long long> hb(4 * (size_t)nchunks);
+        PFP_HIP(c, hipMemcpyAsync(hb.data(), d_bounds, hb.size() * 8, hipMemcpyDeviceToHost, c->stream));
+        PFP_HIP(c, hipStreamSynchronize(c->stream));
+        for (uint64_t ch = 0; ch < nchunks; ++ch) { Win &wn = wins[(size_t)ch]; wn.e0 = hb[4 * ch]; wn.e1 = hb[4 * ch + 1]; wn.q0 = hb[4 * ch + 2]; wn.q1 = hb[4 * ch + 3]; }
+    }
+    uint64_t maxq = 0, maxrows = 0;
+    for (const Win &wn : wins) { if (wn.q1 - wn.q0 > maxq) maxq = wn.q1 - wn.q0; if (wn.ce - wn.cs > maxrows) maxrows = wn.ce - wn.cs; }
     // list of the rows of many-member groups (sorted per window instead of ranked row by row)
     uint64_t *bk0 = nullptr, *bk1 = nullptr; uint32_t *bv0 = nullptr, *bv1 = nullptr, *btg = nullptr;
     if (ea.big_total) {
@@ -752,20 +787,26 @@ template <typename SAT, typename EBT> static int emit_and_sample(pfp_ctx *c, Emi
     }
     ea.big_keys = bk0; ea.big_vals = bv0; ea.big_count = d_b + 4; ea.big_cap = ea.big_total;
     const BitRange big_ranges[2] = {{0, bits_for(c->nrows)}, {32, 32 + bits_for(ea.dsize)}};
-    // emits the rows whose output position lies in [w0, w1); bwt_at / sa_at point at position w0
-    auto emit_window = [&](uint64_t w0, uint64_t w1, uint8_t *bwt_at, SAT *sa_at, uint32_t *q_at) -> int {
-        ea.w0 = w0; ea.w1 = w1; ea.e0 = 0; ea.e1 = total;
-        if (windowed) {
-            PFP_LAUNCH(c, K_MISC, 64, (k_slice_bounds<EBT>), 1, ea, w0, w1, d_b);
-            unsigned long long hb[2];
-            PFP_HIP(c, hipMemcpyAsync(hb, d_b, 16, hipMemcpyDeviceToHost, c->stream));
-            PFP_HIP(c, hipStreamSynchronize(c->stream));
-            ea.e0 = hb[0]; ea.e1 = hb[1];
-        }
-        const uint64_t rows = w1 - w0;
+    static const uint32_t fill_subs = getenv("PFP_FILL_SUBS") ? (uint32_t)atoi(getenv("PFP_FILL_SUBS")) : 4u;
+    // emits the rows whose output position lies in [cs - cl, ce); bwt_at / sa_at point at that first position; q_at receives
+    // the parse row of every row written (all rows) resp. of every special row enumerated (run-aware)
+    auto emit_window = [&](const Win &wn, uint8_t *bwt_at, SAT *sa_at, uint32_t *q_at, bool fill) -> int {
+        ea.w0 = wn.cs - wn.cl; ea.w1 = wn.ce;
+        const uint64_t rows = ea.w1 - ea.w0;
         if (ea.big_total) PFP_HIP(c, hipMemsetAsync(ea.big_count, 0, 16, c->stream));
-        PFP_LAUNCH(c, K_EMIT, rows * (1 + 4 + (sa_at ? 8 + sizeof(SAT) : 0) + (q_at ? 4 : 0)),   // per row: BWT byte out, ilist entry in, (bwsai gather + SA out | parse row out)
-                   (k_emit<SAT, EBT>), (unsigned)((ea.e1 - 1) / EMIT_TILE - ea.e0 / EMIT_TILE + 1), ea, bwt_at, sa_at, q_at);
+        if (runaware) {
+            ea.e0 = wn.q0; ea.e1 = wn.q1; ea.q0 = wn.q0;
+            if (fill) {
+                const uint64_t nsub = (ea.w1 - 1) / FILL_SUB - ea.w0 / FILL_SUB + 1;
+                PFP_LAUNCH(c, K_FILL, rows, (k_fill<EBT>), nblocks(nsub, fill_subs), ea, bwt_at, fill_subs);
+            }
+            if (ea.e1 > ea.e0)
+                PFP_LAUNCH(c, K_EMIT, (ea.e1 - ea.e0) * (1 + 4 + (q_at ? 4 : 0)), (k_emit<SAT, EBT>), (unsigned)((ea.e1 - 1) / EMIT_TILE - ea.e0 / EMIT_TILE + 1), ea, bwt_at, (SAT *)nullptr, q_at);
+        } else {
+            ea.e0 = wn.e0; ea.e1 = wn.e1; ea.q0 = 0;
+            PFP_LAUNCH(c, K_EMIT, rows * (1 + 4 + (sa_at ? 8 + sizeof(SAT) : 0) + (q_at ? 4 : 0)),   // per row: BWT byte out, ilist entry in, (bwsai gather + SA out | parse row out)
+                       (k_emit<SAT, EBT>), (unsigned)((ea.e1 - 1) / EMIT_TILE - ea.e0 / EMIT_TILE + 1), ea, bwt_at, sa_at, q_at);
+        }
         if (ea.big_total) {
             unsigned long long hb[2];
             PFP_HIP(c, hipMemcpyAsync(hb, ea.big_count, 16, hipMemcpyDeviceToHost, c->stream));
@@ -782,17 +823,19 @@ template <typename SAT, typename EBT> static int emit_and_sample(pfp_ctx *c, Emi
         }
         return PFP_OK;
     };
+    auto bwt_of = [&](const Win &wn) -> uint8_t * { return bwtbuf + (wn.cs - wn.cl - (s0 - lead)); };   // position cs - cl
+    const uint64_t qcap = runaware ? maxq + 1 : maxrows + 1;     // parse rows kept per window
+    bool bwt_done = false;
     if (want_rssa && !keep_sa) {
-        // Samples only: ONE pass per window -- emit the BWT bytes and, per row, its parse-BWT row q into scratch, find the
-        // run starts, compute SA values for the 2r sampled rows only (k_samples_q), forget the q's.  r is not known in
+        // Samples only: ONE pass per window -- emit the BWT bytes and the parse rows q needed for sampling into scratch, find
+        // the run starts, compute SA values for the 2r sampled rows only (k_samples_tile), forget the q's.  r is not known in
         // advance, so the sample arrays get a capacity from the free workspace; if r exceeds it the exact two-pass
         // route below is taken.
         const size_t lo_mark = c->arena.mark_lo(), hi_mark = c->arena.mark_hi();
-        const uint64_t maxrows = nchunks == 1 ? nrows : chunk_rows;
         const uint64_t maxtiles = nblocks(maxrows, RUN_TILE);
         uint32_t *tilecnt, *tilebase, *d_cnt, *qtmp;
         PFP_ALLOC_HI(c, tilecnt, uint32_t, maxtiles); PFP_ALLOC_HI(c, tilebase, uint32_t, maxtiles); PFP_ALLOC_HI(c, d_cnt, uint32_t, 1);
-        PFP_ALLOC_HI(c, qtmp, uint32_t, maxrows + 1);
+        PFP_ALLOC_HI(c, qtmp, uint32_t, qcap);
         const size_t freeb = c->arena.hi > c->arena.lo + ((size_t)256 << 20) ? c->arena.hi - c->arena.lo - ((size_t)256 << 20) : 0;
         uint64_t cap = freeb / (4 * sizeof(SAT));
         if (cap > nrows) cap = nrows;
@@ -802,32 +845,34 @@ template <typename SAT, typename EBT> static int emit_and_sample(pfp_ctx *c, Emi
         SAT *ssa = samp, *esa = samp ? samp + 2 * cap : nullptr;
         SAT *esa_w = esa ? esa + 2 * lead : nullptr;      // slices > 0: the first run start of the slice closes a run of the previous slice
         uint64_t run_base = 0; bool overflow = cap == 0;
+        ea.qspec = qtmp;
         for (uint64_t ch = 0; ch < nchunks; ++ch) {
-            const uint64_t cs = s0 + ch * chunk_rows, ce = (cs + chunk_rows < s1) ? cs + chunk_rows : s1, rows = ce - cs;
-            const uint64_t cl = cs ? 1 : 0;
-            uint8_t *bw = bwtbuf + (cs - (s0 - lead));                       // first row of the window
-            PFP_TRY(emit_window(cs - cl, ce, bw - cl, (SAT *)nullptr, qtmp));
+            const Win &wn = wins[(size_t)ch];
+            const uint64_t rows = wn.ce - wn.cs;
+            uint8_t *bw = bwt_of(wn) + wn.cl;                                // first row of the window
+            PFP_TRY(emit_window(wn, bw - wn.cl, (SAT *)nullptr, qtmp, true));
             const uint64_t ntiles = nblocks(rows, RUN_TILE);
-            PFP_LAUNCH(c, K_RUNS, rows, k_run_tile_count, ntiles, (const uint8_t *)bw, rows, (int)cl, tilecnt);
+            PFP_LAUNCH(c, K_RUNS, rows, k_run_tile_count, ntiles, (const uint8_t *)bw, rows, (int)wn.cl, tilecnt);
             PFP_TRY((device_scan<uint32_t, 0>(c, tilecnt, tilebase, ntiles, d_cnt)));
             uint32_t rc = 0; PFP_TRY(d2h_u32(c, d_cnt, &rc));
             if (!overflow && run_base + rc > cap) overflow = true;
             if (!overflow)
-                PFP_LAUNCH(c, K_SAMPLES, rows + (uint64_t)rc * (32 + 4 * sizeof(SAT)), (k_samples_tile<SAT, EBT>), ntiles, ea, (const uint8_t *)bw, rows, (int)cl, (const uint32_t *)tilebase, (const SAT *)nullptr,
-                           (const uint32_t *)(qtmp + cl), cs, run_base, total, ce == total ? run_base + rc + 1 : (uint64_t)0, ssa, esa_w);
+                PFP_LAUNCH(c, K_SAMPLES, rows + (uint64_t)rc * (32 + 4 * sizeof(SAT)), (k_samples_tile<SAT, EBT>), ntiles, ea, (const uint8_t *)bw, rows, (int)wn.cl, (const uint32_t *)tilebase, (const SAT *)nullptr,
+                           (const uint32_t *)(qtmp + wn.cl), wn.cs, run_base, total, wn.ce == total ? run_base + rc + 1 : (uint64_t)0, ssa, esa_w);
             run_base += rc;
         }
         c->runs = run_base; c->esa_pairs = run_base - (s0 == 0 ? 1 : 0) + (s1 == total ? 1 : 0);
         c->arena.release_hi(hi_mark);
         if (!overflow) { c->d_ssa = ssa; c->d_esa = esa; return PFP_OK; }
         c->arena.release_lo(lo_mark);      // fall through: BWT bytes are complete, samples are redone with exact sizes
+        bwt_done = true;
     } else {
     // pass 1: BWT bytes (and SA values if a full SA is kept)
     for (uint64_t ch = 0; ch < nchunks; ++ch) {
-        const uint64_t cs = s0 + ch * chunk_rows, ce = (cs + chunk_rows < s1) ? cs + chunk_rows : s1;
-        const uint64_t cl = cs ? 1 : 0;
-        PFP_TRY(emit_window(cs - cl, ce, bwtbuf + (cs - cl - (s0 - lead)), sabuf ? sabuf + (cs - cl - (s0 - lead)) : (SAT *)nullptr, (uint32_t *)nullptr));
+        const Win &wn = wins[(size_t)ch];
+        PFP_TRY(emit_window(wn, bwt_of(wn), sabuf ? sabuf + (wn.cs - wn.cl - (s0 - lead)) : (SAT *)nullptr, (uint32_t *)nullptr, true));
     }
+    bwt_done = true;
     // runs (src/pfbwt-f.cpp:304-305): runs that start in this slice
     {
         unsigned long long *d_runs = d_b + 2;
@@ -845,23 +890,23 @@ template <typename SAT, typename EBT> static int emit_and_sample(pfp_ctx *c, Emi
         PFP_ALLOC_LO(c, ssa, SAT, 2 * r + 2); PFP_ALLOC_LO(c, esa, SAT, 2 * r + 4);
         c->d_ssa = ssa; c->d_esa = esa;
         SAT *esa_w = esa + 2 * lead;
-        const uint64_t maxrows = nchunks == 1 ? nrows : chunk_rows;
         const uint64_t maxtiles = nblocks(maxrows, RUN_TILE);
         uint32_t *tilecnt, *tilebase, *d_cnt, *qtmp = nullptr;
         PFP_ALLOC_HI(c, tilecnt, uint32_t, maxtiles); PFP_ALLOC_HI(c, tilebase, uint32_t, maxtiles); PFP_ALLOC_HI(c, d_cnt, uint32_t, 1);
-        if (!sabuf) PFP_ALLOC_HI(c, qtmp, uint32_t, maxrows + 1);
+        if (!sabuf) PFP_ALLOC_HI(c, qtmp, uint32_t, qcap);
+        ea.qspec = qtmp;
         uint64_t run_base = 0;
         for (uint64_t ch = 0; ch < nchunks; ++ch) {
-            const uint64_t cs = s0 + ch * chunk_rows, ce = (cs + chunk_rows < s1) ? cs + chunk_rows : s1, rows = ce - cs;
-            const uint64_t cl = cs ? 1 : 0;
-            uint8_t *bw = bwtbuf + (cs - (s0 - lead));                       // first row of the chunk
-            if (!sabuf) PFP_TRY(emit_window(cs - cl, ce, bw - cl, (SAT *)nullptr, qtmp));   // pass 2 of this window: the same rows again, now with their q
+            const Win &wn = wins[(size_t)ch];
+            const uint64_t rows = wn.ce - wn.cs;
+            uint8_t *bw = bwt_of(wn) + wn.cl;                                // first row of the chunk
+            if (!sabuf) PFP_TRY(emit_window(wn, bw - wn.cl, (SAT *)nullptr, qtmp, !bwt_done));   // pass 2 of this window: the same rows again, now with their q
             const uint64_t ntiles = nblocks(rows, RUN_TILE);
-            PFP_LAUNCH(c, K_RUNS, rows, k_run_tile_count, ntiles, (const uint8_t *)bw, rows, (int)cl, tilecnt);
+            PFP_LAUNCH(c, K_RUNS, rows, k_run_tile_count, ntiles, (const uint8_t *)bw, rows, (int)wn.cl, tilecnt);
             PFP_TRY((device_scan<uint32_t, 0>(c, tilecnt, tilebase, ntiles, d_cnt)));
             uint32_t rc = 0; PFP_TRY(d2h_u32(c, d_cnt, &rc));
-            PFP_LAUNCH(c, K_SAMPLES, rows + (uint64_t)rc * (32 + 4 * sizeof(SAT)), (k_samples_tile<SAT, EBT>), ntiles, ea, (const uint8_t *)bw, rows, (int)cl, (const uint32_t *)tilebase,
-                       sabuf ? (const SAT *)(sabuf + (cs - (s0 - lead))) : (const SAT *)nullptr, (const uint32_t *)(sabuf ? nullptr : qtmp + cl), cs, run_base, total, ce == total ? r + 1 : (uint64_t)0, ssa, esa_w);
+            PFP_LAUNCH(c, K_SAMPLES, rows + (uint64_t)rc * (32 + 4 * sizeof(SAT)), (k_samples_tile<SAT, EBT>), ntiles, ea, (const uint8_t *)bw, rows, (int)wn.cl, (const uint32_t *)tilebase,
+                       sabuf ? (const SAT *)(sabuf + (wn.cs - (s0 - lead))) : (const SAT *)nullptr, (const uint32_t *)(sabuf ? nullptr : qtmp + wn.cl), wn.cs, run_base, total, wn.ce == total ? r + 1 : (uint64_t)0, ssa, esa_w);
             run_base += rc;
         }
         if (run_base != r) return PFP_E_CORRUPT;
@@ -873,29 +918,65 @@ template <typename SAT, typename EBT> static int emit_and_sample(pfp_ctx *c, Emi
 template <typename EBT> static int emit_stage(pfp_ctx *c, EmitArgs ea, int want_sa, int want_rssa, int slice, int nslices)
 {
     const uint64_t dsize = c->dsize;
-    EBT *cnt, *EB, *d_tot; unsigned long long *d_hard;
+    static const bool no_runaware = getenv("PFP_NO_RUNAWARE") != nullptr;      // tests / measurements: every row enumerated, as with a full SA
+    const bool runaware = !want_sa && !no_runaware;
+    EBT *cnt, *EB, *d_tot, *cnt2 = nullptr; unsigned long long *d_hard;
     PFP_ALLOC_HI(c, cnt, EBT, dsize); PFP_ALLOC_HI(c, EB, EBT, dsize); PFP_ALLOC_HI(c, d_hard, unsigned long long, 2); PFP_ALLOC_HI(c, d_tot, EBT, 2);
     PFP_HIP(c, hipMemsetAsync(d_hard, 0, 16, c->stream));
     ea.EB = EB;
-    uint32_t *s_g0, *gk; uint8_t *gfl;
-    PFP_ALLOC_HI(c, s_g0, uint32_t, dsize); PFP_ALLOC_HI(c, gk, uint32_t, dsize); PFP_ALLOC_HI(c, gfl, uint8_t, dsize);
+    uint32_t *s_g0, *gk, *gqf = nullptr, *gql = nullptr; uint8_t *gfl, *gnu;
+    PFP_ALLOC_HI(c, s_g0, uint32_t, dsize); PFP_ALLOC_HI(c, gk, uint32_t, dsize); PFP_ALLOC_HI(c, gfl, uint8_t, dsize); PFP_ALLOC_HI(c, gnu, uint8_t, dsize);
     PFP_HIP(c, hipMemsetAsync(gfl, 0, dsize, c->stream));
-    ea.s_g0 = s_g0; ea.gk = gk; ea.cnt = cnt;
+    PFP_HIP(c, hipMemsetAsync(gnu, 0, dsize, c->stream));
+    if (runaware) {
+        PFP_ALLOC_HI(c, cnt2, EBT, dsize); PFP_ALLOC_HI(c, gqf, uint32_t, dsize); PFP_ALLOC_HI(c, gql, uint32_t, dsize);
+        PFP_HIP(c, hipMemsetAsync(gqf, 0xFF, dsize * 4, c->stream));
+        PFP_HIP(c, hipMemsetAsync(gql, 0, dsize * 4, c->stream));
+    }
+    ea.s_g0 = s_g0; ea.gk = gk; ea.cnt = cnt; ea.gqf = gqf; ea.gql = gql;
     uint4 *sinfo; PFP_ALLOC_HI(c, sinfo, uint4, dsize); ea.sinfo = sinfo;
-    PFP_LAUNCH(c, K_EMIT_COUNT, dsize * (30 + sizeof(EBT)), (k_emit_slots<EBT>), nblocks(dsize, BLOCK), ea, cnt, d_hard, (uint32_t *)ea.s_sl, (uint32_t *)ea.s_fb, (uint8_t *)ea.s_fl, (uint8_t *)ea.s_pc, s_g0, gk, gfl);
+    PFP_LAUNCH(c, K_EMIT_COUNT, dsize * (30 + sizeof(EBT)), (k_emit_slots<EBT>), nblocks(dsize, BLOCK), ea, cnt, d_hard, (uint32_t *)ea.s_sl, (uint32_t *)ea.s_fb, (uint8_t *)ea.s_fl, (uint8_t *)ea.s_pc, s_g0, gk, gfl, gnu);
     static const long big_members = getenv("PFP_BIG_GROUP_MEMBERS") ? atol(getenv("PFP_BIG_GROUP_MEMBERS")) : (long)BIG_GROUP_MEMBERS;   // < 0: never
-    PFP_LAUNCH(c, K_EMIT_COUNT, dsize * 14, (k_big_mark<EBT>), nblocks(dsize, BLOCK), (const EBT *)cnt, (const uint32_t *)s_g0, (const uint32_t *)gk, (const uint8_t *)gfl, (const uint32_t *)ea.s_fb, dsize, big_members >= 0 ? (uint32_t)big_members : 0xFFFFFFFFu, (uint8_t *)ea.s_fl, sinfo, d_hard + 1);
+    PFP_LAUNCH(c, K_EMIT_COUNT, dsize * 14, (k_big_mark<EBT>), nblocks(dsize, BLOCK), (const EBT *)cnt, (const uint32_t *)s_g0, (const uint32_t *)gk, (const uint8_t *)gfl, (const uint8_t *)gnu, (const uint32_t *)ea.s_fb, ea.ilist, dsize,
+               big_members >= 0 ? (uint32_t)big_members : 0xFFFFFFFFu, runaware ? 1 : 0, (uint8_t *)ea.s_fl, sinfo, cnt2, gqf, gql, d_hard + 1);
     PFP_TRY((device_scan<EBT, 0>(c, cnt, EB, dsize, d_tot)));
     EBT tot = 0; unsigned long long hardrows = 0, hh[2] = {0, 0};
     PFP_HIP(c, hipMemcpyAsync(hh, d_hard, 16, hipMemcpyDeviceToHost, c->stream));
     PFP_HIP(c, hipMemcpyAsync(&tot, d_tot, sizeof(EBT), hipMemcpyDeviceToHost, c->stream));
     PFP_HIP(c, hipStreamSynchronize(c->stream));
     hardrows = hh[0]; ea.big_total = hh[1];
-    {   // slot under every EMIT_TILE-th output row (k_emit, k_samples_tile, k_slice_bounds start their searches there)
+    {   // slot under every EMIT_TILE-th output row (k_emit, k_fill, k_samples_tile, k_slice_bounds start their searches there)
         const uint64_t ntiles = ((uint64_t)tot + EMIT_TILE - 1) / EMIT_TILE;
         uint32_t *tile_slot; PFP_ALLOC_HI(c, tile_slot, uint32_t, ntiles + 1);
         PFP_LAUNCH(c, K_EMIT_COUNT, dsize * 2 * sizeof(EBT) + ntiles * 4, (k_tile_slots<EBT>), nblocks(dsize, BLOCK), (const EBT *)cnt, (const EBT *)EB, dsize, ntiles, tile_slot);
         ea.tile_slot = tile_slot;
+    }
+    // enumeration order of k_emit: every row, or (run-aware) the rows of the special slots through a compacted list of them
+    ea.ENB = EB; ea.etile_slot = ea.tile_slot; ea.elist = nullptr; ea.cpos = nullptr; ea.ecount = (uint32_t)dsize; ea.special = 0; ea.q0 = 0; ea.qspec = nullptr;
+    uint64_t tot2 = 0;
+    if (runaware) {
+        uint32_t *flag, *cpos, *spl, *d_cnt;
+        PFP_ALLOC_HI(c, flag, uint32_t, dsize); PFP_ALLOC_HI(c, cpos, uint32_t, dsize + 1); PFP_ALLOC_HI(c, d_cnt, uint32_t, 1);
+        PFP_LAUNCH(c, K_EMIT_COUNT, dsize * 5, k_flag_special, nblocks(dsize, BLOCK), (const uint8_t *)ea.s_fl, dsize, flag);
+        PFP_TRY((device_scan<uint32_t, 0>(c, flag, cpos, dsize, d_cnt)));
+        uint32_t nsp = 0; PFP_TRY(d2h_u32(c, d_cnt, &nsp));
+        PFP_ALLOC_HI(c, spl, uint32_t, (size_t)nsp + 1);
+        if (nsp) PFP_LAUNCH(c, K_COMPACT, dsize * 12, k_compact_scatter, nblocks(dsize, BLOCK), (const uint32_t *)nullptr, (const uint32_t *)flag, (const uint32_t *)cpos, dsize, spl);
+        EBT *cntc, *ENBc;
+        PFP_ALLOC_HI(c, cntc, EBT, (size_t)nsp + 1); PFP_ALLOC_HI(c, ENBc, EBT, (size_t)nsp + 1);
+        if (nsp) {
+            PFP_LAUNCH(c, K_EMIT_COUNT, (uint64_t)nsp * (4 + 2 * sizeof(EBT)), (k_gather_counts<EBT>), nblocks(nsp, BLOCK), (const EBT *)cnt, (const uint32_t *)spl, (uint64_t)nsp, cntc);
+            PFP_TRY((device_scan<EBT, 0>(c, cntc, ENBc, nsp, ENBc + nsp)));
+            EBT t2 = 0;
+            PFP_HIP(c, hipMemcpyAsync(&t2, ENBc + nsp, sizeof(EBT), hipMemcpyDeviceToHost, c->stream));
+            PFP_HIP(c, hipStreamSynchronize(c->stream));
+            tot2 = (uint64_t)t2;
+            const uint64_t ntiles2 = (tot2 + EMIT_TILE - 1) / EMIT_TILE;
+            uint32_t *et; PFP_ALLOC_HI(c, et, uint32_t, ntiles2 + 1);
+            PFP_LAUNCH(c, K_EMIT_COUNT, (uint64_t)nsp * 2 * sizeof(EBT) + ntiles2 * 4, (k_tile_slots<EBT>), nblocks(nsp, BLOCK), (const EBT *)cntc, (const EBT *)ENBc, (uint64_t)nsp, ntiles2, et);
+            ea.etile_slot = et;
+        } else PFP_HIP(c, hipMemsetAsync(ENBc, 0, sizeof(EBT), c->stream));
+        ea.ENB = ENBc; ea.elist = spl; ea.cpos = cpos; ea.ecount = nsp; ea.special = 1;
     }
     static const bool verbose = getenv("PFP_VERBOSE") != nullptr;
     if (verbose) {
@@ -904,7 +985,8 @@ template <typename EBT> static int emit_stage(pfp_ctx *c, EmitArgs ea, int want_
         PFP_LAUNCH(c, K_MISC, dsize * 20, (k_group_stats<EBT>), nblocks(dsize, BLOCK), (const EBT *)cnt, (const EBT *)EB, (const uint32_t *)s_g0, (const uint32_t *)gk, (const uint8_t *)ea.s_fl, dsize, (uint64_t)tot, d_hist);
         PFP_HIP(c, hipMemcpyAsync(hist, d_hist, 512, hipMemcpyDeviceToHost, c->stream));
         PFP_HIP(c, hipStreamSynchronize(c->stream));
-        fprintf(stderr, "[pfbwt_hip] rows by group members (rows) x group rows (cols: <1K <4K <16K <64K <256K <1M <4M more); hard %llu, sort-route %llu of %llu\n", hh[0], hh[1], (unsigned long long)tot);
+        fprintf(stderr, "[pfbwt_hip] rows by group members (rows) x group rows (cols: <1K <4K <16K <64K <256K <1M <4M more); hard %llu, sort-route %llu of %llu; run-aware %d: %llu rows of %u special slots enumerated\n",
+                hh[0], hh[1], (unsigned long long)tot, (int)runaware, (unsigned long long)tot2, (unsigned)ea.ecount);
         static const char *kn[8] = {"1", "2-3", "4-7", "8-15", "16-31", "32-63", "64-127", "128+"};
         for (int a = 0; a < 8; ++a) { fprintf(stderr, "[pfbwt_hip]  k %-7s", kn[a]); for (int b = 0; b < 8; ++b) fprintf(stderr, " %13llu", hist[a * 8 + b]); fprintf(stderr, "\n"); }
     }
@@ -914,9 +996,9 @@ template <typename EBT> static int emit_stage(pfp_ctx *c, EmitArgs ea, int want_
     if (!c->n) c->n = nout - 1;
     ea.nout = nout; ea.n = c->n;
     c->nout = nout; c->hard = hardrows; c->easy = nout - hardrows;
-    if (c->flags & PFP_FLAG_U64) return emit_and_sample<uint64_t, EBT>(c, ea, want_sa != 0, want_rssa != 0, slice, nslices);
+    if (c->flags & PFP_FLAG_U64) return emit_and_sample<uint64_t, EBT>(c, ea, want_sa != 0, want_rssa != 0, slice, nslices, tot2);
     if (nout > 0xFFFFFFFFULL) return PFP_E_TOO_LARGE;           // 32-bit uint_t cannot hold the SA values (pfparser.hpp:326-331)
-    return emit_and_sample<uint32_t, EBT>(c, ea, want_sa != 0, want_rssa != 0, slice, nslices);
+    return emit_and_sample<uint32_t, EBT>(c, ea, want_sa != 0, want_rssa != 0, slice, nslices, tot2);
 }
 } // extern "C++"
 

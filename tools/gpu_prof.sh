@@ -1,0 +1,13 @@
+#!/bin/bash
+# usage (on the GPU box, from the repo root): tools/gpu_prof.sh <tag> [bench args...]
+# rocprofv3 kernel-trace summary of one bench.py run -> gpurun_out/<tag>_kernel_stats.csv + gpurun_out/<tag>.json
+tag=$1; shift
+root=${GRAFT_REPO_ROOT:-$(pwd)}
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/prof_$tag
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -- python3 $root/bench.py "$@" > $root/gpurun_out/$tag.json 2> $root/gpurun_out/$tag.err
+rc=$?
+f=$(find /tmp/prof_$tag -name "*kernel_stats.csv" | head -1)
+[ -n "$f" ] && cp $f $root/gpurun_out/${tag}_kernel_stats.csv
+cd $root
+exit $rc
