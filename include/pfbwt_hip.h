@@ -66,6 +66,11 @@ const char *pfp_strerror(int status);
 int pfp_error_detail(pfp_ctx *ctx, uint64_t *pos, int *ch);
 /* bytes of device workspace the last PFP_E_NOMEM call would have needed (estimate) */
 uint64_t pfp_workspace_needed(pfp_ctx *ctx);
+/* drop the fed text and every result, keep the context and its workspace.  A stage that fails leaves the
+ * context as it was before the call (workspace marks restored): after a failed pfp_parse_finalize the fed text
+ * is still there -- retry, append more, or pfp_reset; after PFP_E_NOMEM from pfp_bwt_build(want_sa = 1) a retry
+ * with want_sa = 0 or pfp_bwt_build_slice starts from the same state. */
+int pfp_reset(pfp_ctx *ctx);
 
 /* ---- stage 1: parse -------------------------------------------------------------------------- */
 /* PfParser::add_fasta inner loop, pfparser.hpp:335-352: append raw sequence bytes (host memory).
@@ -111,7 +116,10 @@ int pfp_merge_shards(pfp_ctx *ctx, int nshards, const pfp_shard_view *views, pfp
 /* ---- stage 2: BWT / SA ------------------------------------------------------------------------- */
 /* PrefixFreeBWT ctor pfbwt.hpp:64-81, for --pfbwt-only: upload .dict .occ .bwlast .ilist [.bwsai]
  * images (host memory).  Not needed when pfp_parse_finalize + pfp_parse_bwt ran in this context.
- * n_hint: the value of the .n file (src/pfbwt-f.cpp:282-285), sizes the workspace; 0 = unknown. */
+ * ilist and bwsai must hold nrows elements each, like bwlast (the caller compares the file sizes).
+ * n_hint: the value of the .n file (src/pfbwt-f.cpp:282-285), sizes the workspace and arms the
+ * "exactly n + 1 rows" check of the emission; 0 = unknown.  PFP_E_CORRUPT: the images are inconsistent
+ * (dictionary not terminated, word count != entries of occ, sum(occ) + 1 != nrows, an ilist entry >= nrows). */
 int pfp_bwt_load(pfp_ctx *ctx, const uint8_t *dict, uint64_t dsize, const void *occ, uint64_t dwords,
                  const uint8_t *bwlast, const void *ilist, const void *bwsai, uint64_t nrows, uint64_t n_hint);
 /* PrefixFreeBWT::generate_bwt_lcp pfbwt.hpp:96-194 (sort_dict_suffixes :206-223 = gsacak included)
@@ -137,20 +145,6 @@ int pfp_bwt_device_ptrs(pfp_ctx *ctx, const void **d_bwt, const void **d_sa, con
 int pfp_sacak_int_u32(const uint32_t *s, uint32_t *SA, uint32_t n, uint32_t k);
 int pfp_sacak_int_u64(const uint32_t *s, uint64_t *SA, uint64_t n, uint64_t k);
 
-/* ---- instrumentation ---------------------------------------------------------------------------- */
-/* per-kernel timing with hipEvents on the context's stream (off by default) */
-int pfp_profile_enable(pfp_ctx *ctx, int on);
-/* time only the launches of one kernel (name as reported by pfp_profile_get); keeps event overhead out of a timed run */
-int pfp_profile_select(pfp_ctx *ctx, const char *kernel_name);
-int pfp_profile_reset(pfp_ctx *ctx);
-/* idx-th record: kernel name, launches, total ms, algorithmic bytes; returns 0 or PFP_E_ARG past the end */
-int pfp_profile_get(pfp_ctx *ctx, int idx, const char **name, uint64_t *launches, double *ms, double *bytes);
-/* wall-clock milliseconds of the last call of each stage (host timer around a stream sync):
- * [0] parse_finalize [1] parse_bwt [2] bwt_build */
-int pfp_stage_ms(pfp_ctx *ctx, double out[3]);
-/* development aid: sorts n pseudo-random (key, value) pairs with `bits` significant key bits, returns the best
- * wall time of `reps` runs and the number of out-of-order neighbours (0 when ablate == 0) */
-int pfp_debug_sort(pfp_ctx *ctx, uint64_t n, int bits, int reps, int ablate, double *ms_out, uint32_t *unsorted_pairs);
 /* library build info: "hip-gfx950" for the product library */
 const char *pfp_backend(void);
 

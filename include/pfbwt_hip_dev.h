@@ -1,0 +1,31 @@
+/*
+ * include/pfbwt_hip_dev.h -- measurement and development entry points of libpfbwt_hip.so.  NOT part of the
+ * drop-in boundary (include/pfbwt_hip.h): nothing here stands in for a reference interface; bench.py and
+ * tools/ use it for the per-kernel HIP-event timings behind the roofline figures.
+ */
+#ifndef PFBWT_HIP_DEV_H
+#define PFBWT_HIP_DEV_H
+#include "pfbwt_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- instrumentation ---------------------------------------------------------------------------- */
+/* per-kernel timing with hipEvents on the context's stream (off by default) */
+int pfp_profile_enable(pfp_ctx *ctx, int on);
+/* time only the launches of one kernel (name as reported by pfp_profile_get); keeps event overhead out of a timed run */
+int pfp_profile_select(pfp_ctx *ctx, const char *kernel_name);
+int pfp_profile_reset(pfp_ctx *ctx);
+/* idx-th record: kernel name, launches, total ms, algorithmic bytes; returns 0 or PFP_E_ARG past the end */
+int pfp_profile_get(pfp_ctx *ctx, int idx, const char **name, uint64_t *launches, double *ms, double *bytes);
+/* wall-clock milliseconds of the last call of each stage (host timer around a stream sync):
+ * [0] parse_finalize [1] parse_bwt [2] bwt_build */
+int pfp_stage_ms(pfp_ctx *ctx, double out[3]);
+/* development aid: sorts n pseudo-random (key, value) pairs with `bits` significant key bits, returns the best
+ * wall time of `reps` runs and the number of out-of-order neighbours (must be 0) */
+int pfp_debug_sort(pfp_ctx *ctx, uint64_t n, int bits, int reps, double *ms_out, uint32_t *unsorted_pairs);
+#ifdef __cplusplus
+}
+#endif
+#endif

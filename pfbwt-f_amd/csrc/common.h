@@ -8,6 +8,7 @@
 #include <chrono>
 #include <vector>
 #include "../../include/pfbwt_hip.h"
+#include "../../include/pfbwt_hip_dev.h"
 
 namespace pfp {
 
@@ -103,7 +104,6 @@ struct pfp_ctx {
     std::vector<hipEvent_t> ev_pool;
     double stage_ms[3] = {0, 0, 0};
     int hip_err = 0;
-    int debug_ablate = 0;
     uint64_t hash_seed = 0x9E3779B97F4A7C15ULL;
 };
 
@@ -147,6 +147,10 @@ struct ProfScope {
     do {                                                                                          \
         pfp::ProfScope ps_((ctx), (id), (double)(bytes));                                         \
         hipLaunchKernelGGL(kernel, dim3((unsigned)(grid)), dim3(pfp::BLOCK), 0, (ctx)->stream, __VA_ARGS__); \
+        hipError_t le_ = hipGetLastError();            /* a rejected launch (grid, LDS size) must not pass as stale output */ \
+        if (le_ != hipSuccess) { (ctx)->hip_err = (int)le_; (ctx)->err_ch = (int)le_;                 \
+            fprintf(stderr, "[pfbwt_hip] launch of %s failed: %s (%s:%d)\n", #kernel, hipGetErrorString(le_), __FILE__, __LINE__); \
+            return PFP_E_HIP; }                                                                       \
     } while (0)
 
 #define PFP_HIP(ctx, expr)                                                                        \

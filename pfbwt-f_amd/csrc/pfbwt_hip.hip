@@ -123,6 +123,14 @@ int pfp_error_detail(pfp_ctx *c, uint64_t *pos, int *ch)
     return PFP_OK;
 }
 uint64_t pfp_workspace_needed(pfp_ctx *c) { return c ? (uint64_t)(c->arena.cap + c->arena.want) : 0; }
+int pfp_reset(pfp_ctx *c)
+{
+    if (!c) return PFP_E_ARG;
+    PFP_HIP(c, hipSetDevice(c->device));
+    PFP_HIP(c, hipStreamSynchronize(c->stream));
+    reset_results(c);
+    return PFP_OK;
+}
 
 int pfp_profile_enable(pfp_ctx *c, int on) { if (!c) return PFP_E_ARG; prof_collect(c); c->prof_on = on != 0; c->prof_mask = ~0ULL; return PFP_OK; }
 int pfp_profile_select(pfp_ctx *c, const char *kernel)
@@ -351,12 +359,34 @@ static int finish_parse(pfp_ctx *c, const uint32_t *occw)
     return PFP_OK;
 }
 
+// A stage that fails (PFP_E_NOMEM, PFP_E_INVALID_CHAR, ...) must leave the workspace as it found it, so that the
+// natural retry (a cheaper request, a larger workspace) does not start from a leaked high-water mark.
+struct ArenaGuard {
+    pfp_ctx *c; size_t lo, hi; bool armed = true;
+    explicit ArenaGuard(pfp_ctx *c_) : c(c_), lo(c_->arena.lo), hi(c_->arena.hi) {}
+    int done(int rc)
+    {
+        if (rc != PFP_OK && armed && c->arena.base) { (void)hipStreamSynchronize(c->stream); c->arena.lo = lo; c->arena.hi = hi; c->arena.failed = false; }
+        return rc;
+    }
+};
+
+static int parse_finalize_impl(pfp_ctx *c, pfp_parse_sizes *out);
 int pfp_parse_finalize(pfp_ctx *c, pfp_parse_sizes *out)
 {
     if (!c) return PFP_E_ARG;
     if (c->stage != 0) return PFP_E_STATE;
     if (c->n == 0) return PFP_E_ARG;
     PFP_HIP(c, hipSetDevice(c->device));
+    ArenaGuard g(c);
+    const int rc = g.done(parse_finalize_impl(c, out));
+    // after a failure the fed text is still there (stage 0): finalize can be retried (more workspace), more text can be
+    // appended, or pfp_reset drops it
+    if (rc != PFP_OK) { c->m = c->dwords = c->dsize = 0; c->gsa_valid = false; }
+    return rc;
+}
+static int parse_finalize_impl(pfp_ctx *c, pfp_parse_sizes *out)
+{
     HostTimer timer;
     const uint64_t n = c->n; const int w = c->w;
     PFP_TRY(ensure_arena(c, n));
@@ -463,10 +493,17 @@ int pfp_device_copy(pfp_ctx *c, void *d_dst, const void *d_src, uint64_t bytes)
     return PFP_OK;
 }
 
+static int merge_shards_impl(pfp_ctx *c, int nshards, const pfp_shard_view *v, pfp_parse_sizes *out);
 int pfp_merge_shards(pfp_ctx *c, int nshards, const pfp_shard_view *v, pfp_parse_sizes *out)
 {
     if (!c || nshards < 1 || !v) return PFP_E_ARG;
     PFP_HIP(c, hipSetDevice(c->device));
+    const int rc = merge_shards_impl(c, nshards, v, out);
+    if (rc != PFP_OK) reset_results(c);      // a failed merge leaves an empty context (the shards are untouched)
+    return rc;
+}
+static int merge_shards_impl(pfp_ctx *c, int nshards, const pfp_shard_view *v, pfp_parse_sizes *out)
+{
     HostTimer timer;
     const uint32_t w = (uint32_t)c->w;
     uint64_t ntot = 0, mtot = 0, dtot = 0, ctot = 0;
@@ -613,14 +650,22 @@ static int sort_int_suffixes(pfp_ctx *c, const uint32_t *dS, uint64_t N, uint64_
     return PFP_OK;
 }
 
+static int parse_bwt_impl(pfp_ctx *c);
 int pfp_parse_bwt(pfp_ctx *c)
 {
     if (!c) return PFP_E_ARG;
     if (c->stage < 1 || !c->d_parse) return PFP_E_STATE;
     if (c->m < 2) return PFP_E_ONE_WORD;                        // pfparser.hpp:390-392
     PFP_HIP(c, hipSetDevice(c->device));
-    HostTimer timer;
     c->arena.release_lo(c->lo_after_parse);
+    ArenaGuard g(c);
+    const int rc = g.done(parse_bwt_impl(c));
+    if (rc != PFP_OK) { c->stage = 1; c->d_bwlast = nullptr; c->d_ilist = nullptr; c->d_bwsai = nullptr; c->nrows = 0; }
+    return rc;
+}
+static int parse_bwt_impl(pfp_ctx *c)
+{
+    HostTimer timer;
     const uint64_t m = c->m, N = m + 1;
     const size_t mk = c->arena.mark_hi();
     PFP_LAUNCH(c, K_MISC, 4, k_set_u32, 1, c->d_parse, m, 0u);  // :407-410 (d_parse has m+1 slots)
@@ -672,13 +717,37 @@ static int upload_u32_from(pfp_ctx *c, const void *src, uint64_t cnt, bool u64, 
     return PFP_OK;
 }
 
+// consistency of a loaded file set (the emission gathers ilist[F[rank] + r], bwsai[q], bwlast[q] with these values as
+// indices: a truncated or mismatched set must become PFP_E_CORRUPT here, not an out-of-bounds device read there)
+__global__ __launch_bounds__(BLOCK) void k_load_check(const uint32_t *ilist, uint64_t nrows, const uint32_t *occ, uint64_t dwords, unsigned long long *out /*[0] sum of occ, [1] ilist entries >= nrows*/)
+{
+    __shared__ unsigned long long red[4];
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    unsigned long long tot;
+    (void)block_excl_sum((unsigned long long)(i < dwords ? occ[i] : 0u), red, &tot);
+    if (threadIdx.x == 0 && tot) atomicAdd(&out[0], tot);
+    (void)block_excl_sum((unsigned long long)((i < nrows && ilist[i] >= nrows) ? 1u : 0u), red, &tot);
+    if (threadIdx.x == 0 && tot) atomicAdd(&out[1], tot);
+}
+
+static int bwt_load_impl(pfp_ctx *c, const uint8_t *dict, uint64_t dsize, const void *occ, uint64_t dwords,
+                         const uint8_t *bwlast, const void *ilist, const void *bwsai, uint64_t nrows, uint64_t n_hint);
 int pfp_bwt_load(pfp_ctx *c, const uint8_t *dict, uint64_t dsize, const void *occ, uint64_t dwords,
                  const uint8_t *bwlast, const void *ilist, const void *bwsai, uint64_t nrows, uint64_t n_hint)
 {
     if (!c || !dict || !occ || !bwlast || !ilist || dsize < 2 || dwords < 1 || nrows < 2) return PFP_E_ARG;
     if (dsize + 64 >= 0xFFFFFFFFULL || nrows + 64 >= 0xFFFFFFFFULL) return PFP_E_TOO_LARGE;
+    if (dict[dsize - 1] != EndOfDict || dict[dsize - 2] != EndOfWord) return PFP_E_CORRUPT;       // pfbwt_io.hpp:71-82
+    if (n_hint && nrows > n_hint + 1) return PFP_E_CORRUPT;                                       // more phrases than text positions
     PFP_HIP(c, hipSetDevice(c->device));
     reset_results(c);
+    const int rc = bwt_load_impl(c, dict, dsize, occ, dwords, bwlast, ilist, bwsai, nrows, n_hint);
+    if (rc != PFP_OK) reset_results(c);
+    return rc;
+}
+static int bwt_load_impl(pfp_ctx *c, const uint8_t *dict, uint64_t dsize, const void *occ, uint64_t dwords,
+                         const uint8_t *bwlast, const void *ilist, const void *bwsai, uint64_t nrows, uint64_t n_hint)
+{
     // n (the .n file, src/pfbwt-f.cpp:282-285) sizes the outputs; without it assume n <= 4 * dsize
     PFP_TRY(ensure_arena(c, (n_hint ? n_hint : 4 * dsize) + dsize + nrows));
     c->arena.reset();
@@ -712,9 +781,18 @@ int pfp_bwt_load(pfp_ctx *c, const uint8_t *dict, uint64_t dsize, const void *oc
     uint32_t nw = 0; PFP_TRY(d2h_u32(c, d_cnt, &nw));
     if (nw != dwords) return PFP_E_CORRUPT;
     PFP_LAUNCH(c, K_MISC, dsize * 5, k_ws_from_flags, nblocks(dsize, BLOCK), (const uint8_t *)c->d_dict, dsize, (const uint32_t *)c->d_wordid, c->d_ws);
+    {   // sum(occ) + 1 == rows of the parse BWT (pfparser.hpp:452-462), every ilist entry is a row
+        unsigned long long *d_chk, chk[2];
+        PFP_ALLOC_HI(c, d_chk, unsigned long long, 2);
+        PFP_HIP(c, hipMemsetAsync(d_chk, 0, 16, c->stream));
+        PFP_LAUNCH(c, K_MISC, (nrows + dwords) * 4, k_load_check, nblocks(nrows > dwords ? nrows : dwords, BLOCK), (const uint32_t *)c->d_ilist, nrows, (const uint32_t *)c->d_occ, dwords, d_chk);
+        PFP_HIP(c, hipMemcpyAsync(chk, d_chk, 16, hipMemcpyDeviceToHost, c->stream));
+        PFP_HIP(c, hipStreamSynchronize(c->stream));
+        if (chk[0] + 1 != nrows || chk[1] != 0) return PFP_E_CORRUPT;
+    }
     PFP_HIP(c, hipStreamSynchronize(c->stream));
     c->arena.release_hi(mk);
-    c->d_wrank = nullptr; c->gsa_valid = false; c->stage = 2; c->n = 0;
+    c->d_wrank = nullptr; c->gsa_valid = false; c->stage = 2; c->n = n_hint;     // n known: the emission checks that it produces exactly n + 1 rows
     c->lo_after_pbwt = c->arena.mark_lo();
     return PFP_OK;
 }
@@ -1002,16 +1080,29 @@ template <typename EBT> static int emit_stage(pfp_ctx *c, EmitArgs ea, int want_
 }
 } // extern "C++"
 
+static int bwt_build_body(pfp_ctx *c, int want_sa, int want_rssa, int slice, int nslices, pfp_bwt_sizes *out);
 static int bwt_build_impl(pfp_ctx *c, int want_sa, int want_rssa, int slice, int nslices, pfp_bwt_sizes *out)
 {
     if (!c || nslices < 1 || slice < 0 || slice >= nslices) return PFP_E_ARG;
     if (c->stage < 2) return PFP_E_STATE;
     if ((want_sa || want_rssa) && !c->d_bwsai) return PFP_E_STATE;
     PFP_HIP(c, hipSetDevice(c->device));
-    HostTimer timer;
     c->arena.release_lo(c->lo_after_pbwt);
+    if (!c->gsa_valid) {   // gsacak, pfbwt.hpp:211 (--pfbwt-only: the loaded dictionary has not been sorted yet)
+        ArenaGuard gs(c);
+        const int rs = gs.done(sort_dict_suffixes(c));
+        if (rs != PFP_OK) { c->gsa_valid = false; return rs; }
+        c->lo_after_pbwt = c->arena.mark_lo();
+    }
+    ArenaGuard g(c);
+    const int rc = g.done(bwt_build_body(c, want_sa, want_rssa, slice, nslices, out));
+    if (rc != PFP_OK) { c->stage = 2; c->d_bwt = nullptr; c->d_sa = c->d_ssa = c->d_esa = nullptr; }   // e.g. PFP_E_NOMEM with want_sa: retry without, or in slices
+    return rc;
+}
+static int bwt_build_body(pfp_ctx *c, int want_sa, int want_rssa, int slice, int nslices, pfp_bwt_sizes *out)
+{
+    HostTimer timer;
     const size_t mk = c->arena.mark_hi();
-    if (!c->gsa_valid) { PFP_TRY(sort_dict_suffixes(c)); c->lo_after_pbwt = c->arena.mark_lo(); }   // gsacak, pfbwt.hpp:211
     const uint64_t dsize = c->dsize, dwords = c->dwords;
     uint32_t *F, *s_sl, *s_fb; uint8_t *s_fl, *s_pc; uint2 *posinfo; uint4 *winfo;
     if (dwords > WID_MASK) return PFP_E_TOO_LARGE;
@@ -1093,7 +1184,7 @@ __global__ __launch_bounds__(BLOCK) void k_debug_check_sorted(const uint64_t *ke
     const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i + 1 < n && keys[i] > keys[i + 1]) atomicAdd(bad, 1u);
 }
-int pfp_debug_sort(pfp_ctx *c, uint64_t n, int bits, int reps, int ablate, double *ms_out, uint32_t *unsorted_pairs)
+int pfp_debug_sort(pfp_ctx *c, uint64_t n, int bits, int reps, double *ms_out, uint32_t *unsorted_pairs)
 {
     if (!c || n < 2 || bits < 1 || bits > 64) return PFP_E_ARG;
     PFP_HIP(c, hipSetDevice(c->device));
@@ -1107,7 +1198,6 @@ int pfp_debug_sort(pfp_ctx *c, uint64_t n, int bits, int reps, int ablate, doubl
     for (int r = 0; r < reps; ++r) {
         PFP_LAUNCH(c, K_MISC, n * 12, k_debug_fill, nblocks(n, BLOCK), k0, v0, n, bits, (uint64_t)r * 7919);
         PFP_HIP(c, hipStreamSynchronize(c->stream));
-        (void)ablate;
         HostTimer t;
         int rc = radix_sort_pairs<uint64_t>(c, k0, v0, k1, v1, n, &br, 1, &sk, &sv);
         if (rc != PFP_OK) return rc;

@@ -6,8 +6,9 @@
 //   generate_bwt_lcp(out_fn) :96-194     pfp_bwt_build (dictionary suffix sort + emission on the GPU), then
 //                                        replays out_fn(out_fn_arg) once per row, in order, on the caller's
 //                                        thread -- exactly n+1 calls like the reference
-// Differences a caller can observe: `dif` is EASY1 for rows of single-word groups and HARD otherwise (the
-// reference also has EASY2); `sa` of row 0 already holds n (the CLI substitutes it anyway, pfbwt-f.cpp:301).
+// Differences a caller can observe: `dif` is always EASY1 (the engine reports the easy / hard totals, not a label per
+// row); `sa` of row 0 already holds n (the CLI substitutes it anyway, pfbwt-f.cpp:301); with rssa && !sa the `sa` field
+// is exact on run-boundary rows only (see generate_bwt_lcp).
 #ifndef PFBWTF_PFBWT_HPP
 #define PFBWTF_PFBWT_HPP
 #include <string>
@@ -53,6 +54,11 @@ template <template <typename, typename...> class ReadConType, template <typename
         if (verbose) fprintf(stderr, "loaded files\n");
         dsize = dict.size(); dwords = occ.size();
         if (dsize < 1) die("error: dictionary not loaded\n");
+        if (ilist.size() != bwlast.size() || (any_sa && bwsai.size() != bwlast.size())) {      // a truncated or mismatched file set
+            fprintf(stderr, "error: %s.{bwlast,ilist,bwsai} do not hold the same number of rows (%lu, %lu, %lu)\n", args.prefix.c_str(),
+                    (unsigned long)bwlast.size(), (unsigned long)ilist.size(), (unsigned long)bwsai.size());
+            exit(1);
+        }
         int st = 0, dev = 0;
         if (const char *e = getenv("PFBWT_DEVICE")) dev = atoi(e);
         ctx_ = pfp_create((int)w, 100, (M64 ? PFP_FLAG_U64 : 0u) | PFP_FLAG_SAI, dev, 0, &st);
@@ -85,11 +91,21 @@ template <template <typename, typename...> class ReadConType, template <typename
     template <typename Fn> void generate_bwt_lcp(Fn out_fn)
     {
         if (verbose) fprintf(stderr, "generating dict suffixes\n");
-        build(true);
+        // -r without -s: no full SA is built or copied (8 B per base; 256 GB at 32 Gbase).  The rows' SA values are
+        // taken from the run samples: exact on every run start and run end -- the only rows on which the reference's
+        // callback uses a.sa (src/pfbwt-f.cpp:306-315, 325-328) -- and 0 on the rows inside a run.
+        const bool sampled = build_rssa && !build_sa;
+        build(!sampled);
         if (verbose) fprintf(stderr, "processing words to build BWT\n");
         uint8_t pbwtc = 0;
+        size_t ks = 0, ke = 0;                          // next .ssa / .esa pair
         for (size_t i = 0; i < nout_; ++i) {
-            if (any_sa) out_fn(out_fn_arg((uint_t)i, sa_[i], pbwtc, bwt_[i]));      // UPDATE_SA, pfbwt.hpp:87-89
+            if (sampled) {
+                uint_t v = 0;
+                if (ks < r_ && ssa_[2 * ks] == (uint_t)i) v = ssa_[2 * ks++ + 1];
+                if (ke < r_ && esa_[2 * ke] == (uint_t)i) v = esa_[2 * ke++ + 1];
+                out_fn(out_fn_arg((uint_t)i, v, pbwtc, bwt_[i]));
+            } else if (any_sa) out_fn(out_fn_arg((uint_t)i, sa_[i], pbwtc, bwt_[i]));      // UPDATE_SA, pfbwt.hpp:87-89
             else out_fn(out_fn_arg(0, 0, pbwtc, bwt_[i]));                            // UPDATE_BWT, :91-92
             pbwtc = bwt_[i];
         }

@@ -12,6 +12,9 @@
 #include <vector>
 #include <zlib.h>
 #include "pfbwt_hip.h"
+extern "C" {
+#include "utils.h"          // special symbols, file extensions, die(), open_aux_file() at global scope like the reference's
+}
 
 #ifndef M64
 #define M64 0
@@ -25,24 +28,7 @@ typedef uint32_t uint_t;
 #endif
 typedef uint32_t int_text;
 
-#ifndef Dollar
-#define Dollar 2
-#define EndOfWord 1
-#define EndOfDict 0
-#endif
-#define EXTPARSE "parse"
-#define EXTOCC "occ"
-#define EXTDICT "dict"
-#define EXTBWLST "bwlast"
-#define EXTBWSAI "bwsai"
-#define EXTILIST "ilist"
-#define EXTSA "sa"
-#define EXTSSA "ssa"
-#define EXTESA "esa"
-
 namespace pfbwtf {
-
-[[noreturn]] inline void die(const char *s) { perror(s); exit(1); }
 
 // engine status -> the reference's message + exit(1)
 inline void engine_check(pfp_ctx *ctx, int st, const char *what)

@@ -34,6 +34,14 @@ struct PfParserParams {
     bool non_acgt_to_a = false;
 };
 
+// run of non-ACGT characters (pfparser.hpp:61-67); only filled by the reference's disabled --trim-non-acgt code
+// (:338-341), i.e. always empty -- kept so that run_parser (src/pfbwt-f.cpp:236-240) compiles unchanged
+struct ntab_entry {
+    size_t pos = 0;
+    size_t l = 0;
+    void clear() { pos = 0; l = 0; }
+};
+
 template <typename Hasher = WangHash> struct PfParser {
   public:
     using UIntType = uint_t;
@@ -147,6 +155,7 @@ template <typename Hasher = WangHash> struct PfParser {
     const std::vector<int_text> &get_parse_ranks() const { return parse_ranks_; }
     const std::vector<const char *> &get_sorted_phrases() const { return sorted_phrases_; }
     const std::vector<char> &get_dict_image() const { return dict_; }          // the .dict bytes (pfbwt_io.hpp:71-82)
+    const std::vector<ntab_entry> &get_ntab() const { return ntab_; }
     const std::vector<UIntType> &get_doc_starts() const { return doc_starts_; }
     const std::vector<std::string> &get_doc_names() const { return doc_names_; }
     const PfParserParams get_params() const { return params_; }
@@ -203,6 +212,7 @@ template <typename Hasher = WangHash> struct PfParser {
     std::vector<size_t> seq_ends_;
     std::vector<UIntType> doc_starts_;
     std::vector<std::string> doc_names_;
+    std::vector<ntab_entry> ntab_;
     size_t nseqs_ = 0;
     // results
     size_t n_ = 0;

@@ -72,10 +72,10 @@ Options parse_options(int argc, char **argv)
     }
     if (argc == optind + 1) o.in_fname.assign(argv[optind]);
     else { fprintf(stderr, "reading from stdin. Parsing might be a bit slow.\n"); o.in_fname.assign("-"); }
-    if (o.non_acgt_to_a && o.trim_non_acgt) pfbwtf::die("cannot have both --non-acgt-to-a and --trim-non-acgt options enabled at same time");
-    if (o.in_fname == "-" && o.output == "" && !o.pfbwt_only) pfbwtf::die("if reading from stdin, need a prefix for output files (-o, --output)");
+    if (o.non_acgt_to_a && o.trim_non_acgt) die("cannot have both --non-acgt-to-a and --trim-non-acgt options enabled at same time");
+    if (o.in_fname == "-" && o.output == "" && !o.pfbwt_only) die("if reading from stdin, need a prefix for output files (-o, --output)");
     if (o.in_fname != "-" && o.output == "") o.output = o.in_fname;
-    if (o.parse_only && o.pfbwt_only) pfbwtf::die("cannot simulatneously do parse_only and pfbwt_only");
+    if (o.parse_only && o.pfbwt_only) die("cannot simulatneously do parse_only and pfbwt_only");
     return o;
 }
 
@@ -84,12 +84,12 @@ FILE *open_out(const Options &o, const char *ext)
     if (o.stdout_ext == ext) return stdout;
     std::string name = o.output + "." + ext;
     FILE *f = fopen(name.c_str(), "wb");
-    if (f == NULL) pfbwtf::die(name.c_str());
+    if (f == NULL) die(name.c_str());
     return f;
 }
 template <typename T> void write_all(FILE *f, const std::vector<T> &v)
 {
-    if (v.size() && fwrite(v.data(), sizeof(T), v.size(), f) != v.size()) pfbwtf::die("could not write file");
+    if (v.size() && fwrite(v.data(), sizeof(T), v.size(), f) != v.size()) die("could not write file");
     if (f != stdout) fclose(f); else fflush(f);
 }
 
@@ -115,7 +115,7 @@ size_t run_parser(const Options &o, parser_t &p)
         });
     }
     FILE *nf = fopen((o.output + ".n").c_str(), "w");
-    if (nf == NULL) pfbwtf::die("n file");
+    if (nf == NULL) die("n file");
     fprintf(nf, "%lu\n", (unsigned long)n);
     fclose(nf);
     return n;
@@ -125,7 +125,7 @@ size_t read_n_file(const std::string &prefix)
 {
     FILE *f = fopen((prefix + ".n").c_str(), "r");
     unsigned long n = 0;
-    if (f == NULL || fscanf(f, "%lu", &n) != 1) pfbwtf::die("could not read '.n' file");
+    if (f == NULL || fscanf(f, "%lu", &n) != 1) die("could not read '.n' file");
     fclose(f);
     return n;
 }

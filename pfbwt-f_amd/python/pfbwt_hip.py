@@ -60,6 +60,7 @@ def load_library(path=None):
     L.pfp_error_detail.argtypes = [vp, C.POINTER(u64), C.POINTER(i32)]
     L.pfp_workspace_needed.restype = u64
     L.pfp_workspace_needed.argtypes = [vp]
+    L.pfp_reset.argtypes = [vp]
     L.pfp_parse_feed.argtypes = [vp, vp, u64, i32]
     L.pfp_parse_feed_device.argtypes = [vp, vp, u64, i32]
     L.pfp_parse_finalize.argtypes = [vp, C.POINTER(ParseSizes)]
@@ -123,6 +124,9 @@ class PfpContext:
             self.L.pfp_error_detail(self.h, C.byref(pos), C.byref(ch))
             raise PfpError(st, self.L.pfp_strerror(st).decode(), pos.value, ch.value)
 
+    def reset(self):
+        self._check(self.L.pfp_reset(self.h))
+
     # ---- stage 1
     def feed(self, bases, end_of_seq=True):
         a = np.frombuffer(bases, dtype=np.uint8) if isinstance(bases, (bytes, bytearray, memoryview)) else np.ascontiguousarray(bases, dtype=np.uint8)
@@ -182,6 +186,8 @@ class PfpContext:
         d = np.ascontiguousarray(dict_, np.uint8); o = np.ascontiguousarray(occ, self.udt)
         bl = np.ascontiguousarray(bwlast, np.uint8); il = np.ascontiguousarray(ilist, self.udt)
         bs = None if bwsai is None else np.ascontiguousarray(bwsai, self.udt)
+        if il.size != bl.size or (bs is not None and bs.size != bl.size):      # the ABI takes one row count for the three arrays
+            raise PfpError(E_CORRUPT, "bwlast / ilist / bwsai hold different numbers of rows")
         self._check(self.L.pfp_bwt_load(self.h, _ptr(d), d.size, _ptr(o), o.size, _ptr(bl), _ptr(il), _ptr(bs), bl.size, int(n_hint)))
 
     def bwt_build(self, sa=True, rssa=False):

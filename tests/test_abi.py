@@ -9,12 +9,21 @@ from pfp_testlib import ROOT
 
 LIB = os.path.join(ROOT, "pfbwt-f_amd", "lib", "libpfbwt_hip.so")
 HDR = os.path.join(ROOT, "include", "pfbwt_hip.h")
+HDRS = [HDR, os.path.join(ROOT, "include", "pfbwt_hip_dev.h")]
 
 
-def declared_symbols():
-    src = open(HDR).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(pfp_[a-z0-9_]+)\s*\(", src)))
+def declared_symbols(hdrs=HDRS):
+    out = set()
+    for h in hdrs:
+        src = open(h).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        out |= set(re.findall(r"\b(pfp_[a-z0-9_]+)\s*\(", src))
+    return sorted(out)
+
+
+def test_product_header_holds_no_development_hooks():
+    syms = declared_symbols([HDR])
+    assert not [s for s in syms if s.startswith("pfp_debug") or s.startswith("pfp_profile")], syms
 
 
 def test_header_declares_expected_entry_points():

@@ -138,3 +138,91 @@ def test_emu_wide_rows_and_chunked_emission(emu_factory, env):
     e = dict(os.environ); e.update(env)
     pr = subprocess.run([sys.executable, "-c", VARIANT_CODE, ROOT], env=e, capture_output=True, text=True, timeout=900)
     assert pr.returncode == 0 and "variant ok" in pr.stdout, pr.stdout[-1500:] + pr.stderr[-3000:]
+
+
+def test_emu_load_rejects_inconsistent_files(emu_factory):
+    """--pfbwt-only with a truncated .ilist, a wrong .occ, an unterminated .dict or an ilist entry past the last row:
+    PFP_E_CORRUPT at load time (these used to become out-of-bounds device reads in the emission)"""
+    import pfbwt_hip
+    man, recs = golden_case("w4p7")
+    ref = oracle_run([s for _, s in recs], w=man["w"], p=man["p"], U=8)
+    good = dict(dict_=ref["dict"], occ=ref["occ"], bwlast=ref["bwlast"], ilist=ref["ilist"], bwsai=ref["bwsai"], n_hint=ref["n"])
+
+    def expect_corrupt(**chg):
+        a = dict(good); a.update(chg)
+        ctx = emu_factory(w=man["w"], p=man["p"], u64=True)
+        with pytest.raises(pfbwt_hip.PfpError) as e:
+            ctx.bwt_load(**a)
+        assert e.value.status == pfbwt_hip.E_CORRUPT, e.value
+        ctx.close()
+
+    expect_corrupt(ilist=ref["ilist"][:-3])                               # truncated file
+    expect_corrupt(bwsai=ref["bwsai"][:10])
+    occ = ref["occ"].copy(); occ[3] += 5
+    expect_corrupt(occ=occ)                                               # sum(occ) + 1 != rows
+    il = ref["ilist"].copy(); il[7] = len(il) + 1000
+    expect_corrupt(ilist=il)                                              # entry past the last row
+    d = ref["dict"].copy(); d[-1] = 65
+    expect_corrupt(dict_=d)                                               # no EndOfDict
+    expect_corrupt(n_hint=5)                                              # more rows than text positions
+    # a wrong .n: caught by the "exactly n + 1 rows" check of the emission
+    ctx = emu_factory(w=man["w"], p=man["p"], u64=True)
+    a = dict(good); a["n_hint"] = ref["n"] + 17
+    ctx.bwt_load(**a)
+    with pytest.raises(pfbwt_hip.PfpError) as e:
+        ctx.bwt_build(sa=True, rssa=False)
+    assert e.value.status == pfbwt_hip.E_CORRUPT
+    ctx.close()
+
+
+def test_emu_failed_stage_leaves_context_usable(emu_factory):
+    """a stage that fails restores the workspace marks.  (1) PFP_E_NOMEM from bwt_build(sa=True) in a small
+    workspace, then the cheaper request in the SAME context succeeds and is bit-exact; (2) a rejected text
+    (invalid character) followed by pfp_reset and a good text."""
+    import pfbwt_hip
+    man, recs = golden_case("mult_chroms_fa")
+    seqs = [s for _, s in recs]
+    ref = oracle_run(seqs, w=man["w"], p=man["p"], U=8)
+
+    def attempt(ws, sa_first):
+        """outcome of [bwt_build(sa=True)] + bwt_build(sa=False) in one context with `ws` bytes of workspace"""
+        ctx = emu_factory(w=man["w"], p=man["p"], u64=True, workspace_bytes=ws)
+        try:
+            for s in seqs:
+                ctx.feed(s, True)
+            try:
+                ctx.finalize(); ctx.parse_bwt()
+                if sa_first:
+                    try:
+                        ctx.bwt_build(sa=True, rssa=True)
+                        return "sa fits"
+                    except pfbwt_hip.PfpError as e:
+                        assert e.status == pfbwt_hip.E_NOMEM
+                b = ctx.bwt_build(sa=False, rssa=False)
+            except pfbwt_hip.PfpError as e:
+                assert e.status == pfbwt_hip.E_NOMEM
+                return "nomem"
+            assert np.array_equal(ctx.bwt_get()["bwt"], ref["bwt"]) and b.r == ref["r"]
+            return "bwt ok"
+        finally:
+            ctx.close()
+
+    lo, hi = 50_000, 64_000_000                    # smallest workspace in which the BWT-only build succeeds (fresh context)
+    assert attempt(hi, False) == "bwt ok"
+    while hi - lo > 4096:
+        mid = (lo + hi) // 2
+        if attempt(mid, False) == "bwt ok": hi = mid
+        else: lo = mid
+    # in that workspace the full-SA request does not fit; the cheaper request after the failure must behave like in a fresh context
+    assert attempt(hi, True) == "bwt ok", "PFP_E_NOMEM from bwt_build(sa=True) left the workspace unusable for the cheaper request"
+    ctx = emu_factory(w=man["w"], p=man["p"], u64=True)
+    ctx.feed(b"ACGTRRACGT" * 30, True)
+    with pytest.raises(pfbwt_hip.PfpError) as e:
+        ctx.finalize()
+    assert e.value.status == pfbwt_hip.E_INVALID_CHAR
+    ctx.reset()
+    for s in seqs:
+        ctx.feed(s, True)
+    sz = ctx.finalize(); ctx.parse_bwt(); ctx.bwt_build(sa=True, rssa=True)
+    assert sz.n == ref["n"] and np.array_equal(ctx.bwt_get()["sa"], ref["sa"])
+    ctx.close()

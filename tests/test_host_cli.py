@@ -75,13 +75,19 @@ def check_stages_and_merge(B, tmp):
         assert sha_f(po + "." + e) == mf[e]["sha256"], e
     si = os.path.join(tmp, "si")
     with open(fa, "rb") as fi, open(si + ".stdout", "wb") as fo:                                    # stdin input, -c bwt
-        pr = subprocess.run([B["pfbwt-f64"], "-s", "-w", "10", "-p", "20", "-o", si, "-c", "bwt"], stdin=fi, stdout=fo, stderr=subprocess.PIPE)
+        pr = subprocess.run([B["pfbwt-f64"], "-s", "-w", "10", "-p", "20", "-o", si, "--stdout", "bwt"], stdin=fi, stdout=fo, stderr=subprocess.PIPE)
     assert pr.returncode == 0
     assert sha_f(si + ".stdout") == mf["bwt"]["sha256"] and sha_f(si + ".sa") == mf["sa"]["sha256"]
     # BWT only (no SA): same .bwt
     nb = os.path.join(tmp, "nb")
     run([B["pfbwt-f64"], "-w", "10", "-p", "20", "-o", nb, fa])
     assert sha_f(nb + ".bwt") == mf["bwt"]["sha256"] and not os.path.exists(nb + ".sa")
+    # -r without -s: run samples only (generate_bwt_lcp takes the rows' SA values from the samples, no full SA on the host)
+    ro = os.path.join(tmp, "ro")
+    run([B["pfbwt-f64"], "-r", "-w", "10", "-p", "20", "-o", ro, fa])
+    for e in ("bwt", "ssa", "esa"):
+        assert sha_f(ro + "." + e) == mf[e]["sha256"], e
+    assert not os.path.exists(ro + ".sa")
     # merge_pfp: three records parsed separately, merged == the single parse (tests/test_parser.cpp:188-234)
     mf = manifest("mult_chroms_fa")["files"]["u64"]
     parts = []
@@ -117,4 +123,46 @@ def test_cli_emu(tmp_path):
 def test_cli_gpu(tmp_path):
     B = bins("gpu")
     check_cli(B, str(tmp_path), [(n, exe, U) for n in ("edge", "w4p7", "mult_chroms_fa", "single_chrom", "mult_chroms", "panel8") for exe, U in (("pfbwt-f64", 8), ("pfbwt-f", 4))])
+    check_stages_and_merge(B, str(tmp_path))
+
+
+# ---- the drop-in claim itself: the reference's UNCHANGED src/pfbwt-f.cpp and src/merge_pfp.cpp on top of the mirror ----
+REF = "/root/reference"
+MIRROR_INC = ["-I" + os.path.join(ROOT, "pfbwt-f_amd", "host", "include"), "-I" + os.path.join(ROOT, "include")]
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "src")), reason="reference tree not present (GPU box)")
+@pytest.mark.parametrize("src", ["pfbwt-f.cpp", "merge_pfp.cpp"])
+@pytest.mark.parametrize("m64", [[], ["-DM64"]])
+def test_reference_cli_sources_compile_against_mirror(src, m64):
+    """g++ -fsyntax-only of the reference's own CLI sources with pfbwt-f_amd/host/include in place of the reference's
+    include/ (INTEGRATION.md section A): global die / open_aux_file, PfParser::get_ntab, run_pfbwt's template-template
+    parameters -- everything those files name must exist in the mirror"""
+    pr = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-w"] + m64 + MIRROR_INC + [os.path.join(REF, "src", src)], capture_output=True, text=True)
+    assert pr.returncode == 0, pr.stderr[-3000:]
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "src")), reason="reference tree not present (GPU box)")
+def test_reference_cli_dropin_emu(tmp_path):
+    """the same sources BUILT against the mirror and run (engine = tests/emu on the CPU): every file equals the digests of
+    the files the reference itself wrote"""
+    subprocess.run(["make", "-C", os.path.join(ROOT, "pfbwt-f_amd"), "emu"], check=True, stdout=subprocess.DEVNULL)
+    d = os.path.join(ROOT, "tests", "emu", "build")
+    B = {}
+    for name, src, m64 in (("pfbwt-f", "pfbwt-f.cpp", []), ("pfbwt-f64", "pfbwt-f.cpp", ["-DM64"]), ("merge_pfp", "merge_pfp.cpp", ["-DM64"])):
+        B[name] = os.path.join(d, "ref-" + name + "-emu")
+        run(["g++", "-O1", "-std=c++17", "-w"] + m64 + MIRROR_INC + ["-o", B[name], os.path.join(REF, "src", src), "-L" + d, "-lpfbwt_emu", "-lz", "-lpthread", "-Wl,-rpath,$ORIGIN"])
+    check_cli(B, str(tmp_path), [("edge", "pfbwt-f64", 8), ("mult_chroms_fa", "pfbwt-f", 4)])
+    check_stages_and_merge(B, str(tmp_path))
+
+
+@pytest.mark.gpu
+def test_reference_cli_dropin_gpu(tmp_path):
+    """oracle/_ref/dropin-*: the reference's unchanged CLI sources compiled (in the build container, oracle/Makefile
+    `dropin`) against the mirror and linked with libpfbwt_hip.so, run here on the MI355X"""
+    d = os.path.join(ROOT, "oracle", "_ref")
+    B = {"pfbwt-f": os.path.join(d, "dropin-pfbwt-f"), "pfbwt-f64": os.path.join(d, "dropin-pfbwt-f64"), "merge_pfp": os.path.join(d, "dropin-merge_pfp")}
+    if not all(os.path.exists(p) for p in B.values()):
+        pytest.skip("oracle/_ref/dropin-* not built (needs /root/reference at build time)")
+    check_cli(B, str(tmp_path), [(n, exe, U) for n in ("edge", "w4p7", "mult_chroms_fa", "single_chrom", "panel8") for exe, U in (("pfbwt-f64", 8), ("pfbwt-f", 4))])
     check_stages_and_merge(B, str(tmp_path))
