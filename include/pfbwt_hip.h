@@ -77,6 +77,12 @@ int pfp_reset(pfp_ctx *ctx);
  * end_of_seq != 0 closes the record: the w 'A's of :335-337 are appended.  Case folding, the
  * optional non-ACGT->A mapping and the validity check of hash.hpp:30-31 happen on the device. */
 int pfp_parse_feed(pfp_ctx *ctx, const uint8_t *bases, uint64_t len, int end_of_seq);
+/* `count` records of `len` bytes each, record k at bases + k*stride (host memory): the same as `count` calls of
+ * pfp_parse_feed(.., len, 1).  Ingest (include/kseq.h:228 reads 16 KiB at a time): page-locked
+ * (hipHostMalloc / hipHostRegister) memory is moved by one strided DMA transfer; pageable memory goes through the
+ * context's two 32 MiB pinned staging buffers, the host copy into one overlapping the transfer of the other.
+ * Both feed calls return when the caller's buffer may be reused. */
+int pfp_parse_feed_batch(pfp_ctx *ctx, const uint8_t *bases, uint64_t count, uint64_t len, uint64_t stride);
 /* same, but the bytes are already in device memory (one record, pad appended by the library) */
 int pfp_parse_feed_device(pfp_ctx *ctx, const void *d_bases, uint64_t len, int end_of_seq);
 /* `count` records of `len` bytes each, record k at d_bases + k*stride (device memory): the same as `count` calls of

@@ -25,6 +25,12 @@ int pfp_stage_ms(pfp_ctx *ctx, double out[3]);
 /* development aid: sorts n pseudo-random (key, value) pairs with `bits` significant key bits, returns the best
  * wall time of `reps` runs and the number of out-of-order neighbours (must be 0) */
 int pfp_debug_sort(pfp_ctx *ctx, uint64_t n, int bits, int reps, double *ms_out, uint32_t *unsorted_pairs);
+/* position-weighted checksum of `bytes` bytes of device memory that sit at `global_offset` of a larger logical buffer:
+ * out[0..1] = sum over bytes of (byte + 1) * mix_k(global position) mod 2^64.  Checksums of the pieces of a buffer add
+ * up (mod 2^64) to the checksum of the whole: tools/big_check_slices.py compares the sliced (multi-GPU) outputs of a
+ * 32 Gbase build with the single-context output this way, without moving them off the device. */
+int pfp_debug_checksum(pfp_ctx *ctx, const void *d_buf, uint64_t bytes, uint64_t global_offset, uint64_t out[2]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -104,6 +104,9 @@ struct pfp_ctx {
     std::vector<hipEvent_t> ev_pool;
     double stage_ms[3] = {0, 0, 0};
     int hip_err = 0;
+    // --- ingest: pageable host memory goes through two pinned staging buffers, so that the host-side copy of chunk
+    //     k + 1 overlaps the DMA of chunk k (pinned sources are copied directly)
+    uint8_t *hstage[2] = {nullptr, nullptr}; hipEvent_t hstage_ev[2] = {nullptr, nullptr}; bool hstage_used[2] = {false, false};
     uint64_t hash_seed = 0x9E3779B97F4A7C15ULL;
 };
 

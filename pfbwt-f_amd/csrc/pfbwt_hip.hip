@@ -110,6 +110,7 @@ void pfp_destroy(pfp_ctx *c)
     prof_collect(c);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->tb) (void)hipFree(c->tb);
+    for (int k = 0; k < 2; ++k) { if (c->hstage[k]) (void)hipHostFree(c->hstage[k]); if (c->hstage_ev[k]) (void)hipEventDestroy(c->hstage_ev[k]); }
     if (c->arena.base) (void)hipFree(c->arena.base);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -154,6 +155,36 @@ int pfp_profile_get(pfp_ctx *c, int idx, const char **name, uint64_t *launches, 
 int pfp_stage_ms(pfp_ctx *c, double out[3]) { if (!c || !out) return PFP_E_ARG; for (int i = 0; i < 3; ++i) out[i] = c->stage_ms[i]; return PFP_OK; }
 
 // ---- stage 1: feeding ---------------------------------------------------------------------------
+constexpr size_t STAGE_BYTES = (size_t)32 << 20;
+static bool host_pointer_is_pinned(const void *p)
+{
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) == hipSuccess) return a.type == hipMemoryTypeHost;
+    (void)hipGetLastError();      // an ordinary malloc'd pointer is reported as an error
+    return false;
+}
+// host memory -> device: pinned sources directly, pageable ones through the staging ring (kseq's 16 KiB reads of
+// include/kseq.h:228 become 32 MiB DMA transfers; the memcpy into one buffer overlaps the transfer of the other)
+static int h2d_copy(pfp_ctx *c, uint8_t *dst, const uint8_t *src, uint64_t len)
+{
+    if (!len) return PFP_OK;
+    if (host_pointer_is_pinned(src)) { PFP_HIP(c, hipMemcpyAsync(dst, src, (size_t)len, hipMemcpyHostToDevice, c->stream)); return PFP_OK; }
+    if (len <= ((size_t)1 << 16)) { PFP_HIP(c, hipMemcpyAsync(dst, src, (size_t)len, hipMemcpyHostToDevice, c->stream)); PFP_HIP(c, hipStreamSynchronize(c->stream)); return PFP_OK; }
+    for (int k = 0; k < 2; ++k) if (!c->hstage[k]) {
+        PFP_HIP(c, hipHostMalloc((void **)&c->hstage[k], STAGE_BYTES, hipHostMallocDefault));
+        PFP_HIP(c, hipEventCreate(&c->hstage_ev[k]));
+    }
+    int k = 0;
+    for (uint64_t off = 0; off < len; off += STAGE_BYTES, k ^= 1) {
+        const size_t chunk = (size_t)(len - off < STAGE_BYTES ? len - off : STAGE_BYTES);
+        if (c->hstage_used[k]) PFP_HIP(c, hipEventSynchronize(c->hstage_ev[k]));      // the transfer that last used this buffer is done
+        memcpy(c->hstage[k], src + off, chunk);
+        PFP_HIP(c, hipMemcpyAsync(dst + off, c->hstage[k], chunk, hipMemcpyHostToDevice, c->stream));
+        PFP_HIP(c, hipEventRecord(c->hstage_ev[k], c->stream));
+        c->hstage_used[k] = true;
+    }
+    return PFP_OK;
+}
 static int feed_common(pfp_ctx *c, const void *src, uint64_t len, int end_of_seq, hipMemcpyKind kind)
 {
     if (!c || (!src && len)) return PFP_E_ARG;
@@ -163,7 +194,8 @@ static int feed_common(pfp_ctx *c, const void *src, uint64_t len, int end_of_seq
     // pfparser.hpp:326-331: the 32-bit build stops at 2^32 bases; the 64-bit build here at 2^40 (device positions are 64-bit)
     if (c->n + add + (uint64_t)c->w + 64 >= ((c->flags & PFP_FLAG_U64) ? (1ULL << 40) : 0xFFFFFFFFULL)) return PFP_E_TOO_LARGE;
     PFP_TRY(ensure_text(c, c->n + add + (uint64_t)c->w));
-    if (len) PFP_HIP(c, hipMemcpyAsync(c->tb + 16 + c->n, src, (size_t)len, kind, c->stream));
+    if (len && kind == hipMemcpyHostToDevice) PFP_TRY(h2d_copy(c, c->tb + 16 + c->n, (const uint8_t *)src, len));
+    else if (len) PFP_HIP(c, hipMemcpyAsync(c->tb + 16 + c->n, src, (size_t)len, kind, c->stream));
     c->n += len;
     if (end_of_seq) {   // the w 'A's of pfparser.hpp:335-337
         PFP_HIP(c, hipMemsetAsync(c->tb + 16 + c->n, 'A', (size_t)c->w, c->stream));
@@ -188,6 +220,28 @@ int pfp_parse_feed_device_batch(pfp_ctx *c, const void *d_bases, uint64_t count,
     const uint64_t blocks_per_row = ((len + 15) / 16 + BLOCK - 1) / BLOCK;
     if (count * blocks_per_row >= 0x7FFFFFFFULL) return PFP_E_TOO_LARGE;      // grid limit (2^31 workgroups = 8 Tbase)
     PFP_LAUNCH(c, K_MISC, 2 * count * len, k_feed_batch, count * blocks_per_row, (const uint8_t *)d_bases, count, len, stride, c->w, dst);
+    c->n += add;
+    return PFP_OK;
+}
+
+int pfp_parse_feed_batch(pfp_ctx *c, const uint8_t *bases, uint64_t count, uint64_t len, uint64_t stride)
+{
+    if (!c || (!bases && count && len) || stride < len) return PFP_E_ARG;
+    if (!count) return PFP_OK;
+    if (!len || !host_pointer_is_pinned(bases)) {      // pageable memory: record by record through the staging ring
+        for (uint64_t k = 0; k < count; ++k) PFP_TRY(feed_common(c, bases + k * stride, len, 1, hipMemcpyHostToDevice));
+        return PFP_OK;
+    }
+    PFP_HIP(c, hipSetDevice(c->device));
+    if (c->stage != 0) reset_results(c);
+    const uint64_t pitch = len + (uint64_t)c->w, add = count * pitch;
+    if (c->n + add + (uint64_t)c->w + 64 >= ((c->flags & PFP_FLAG_U64) ? (1ULL << 40) : 0xFFFFFFFFULL)) return PFP_E_TOO_LARGE;
+    PFP_TRY(ensure_text(c, c->n + add + (uint64_t)c->w));
+    uint8_t *dst = c->tb + 16 + c->n;
+    // pinned host memory: ONE strided DMA transfer for the whole collection, the pads of pfparser.hpp:335-337 by a strided fill
+    PFP_HIP(c, hipMemcpy2DAsync(dst, (size_t)pitch, bases, (size_t)stride, (size_t)len, (size_t)count, hipMemcpyHostToDevice, c->stream));
+    PFP_HIP(c, hipMemset2DAsync(dst + len, (size_t)pitch, 'A', (size_t)c->w, (size_t)count, c->stream));
+    PFP_HIP(c, hipStreamSynchronize(c->stream));      // the caller may reuse its buffer
     c->n += add;
     return PFP_OK;
 }
@@ -1168,6 +1222,42 @@ int pfp_bwt_device_ptrs(pfp_ctx *c, const void **d_bwt, const void **d_sa, const
     if (d_sa) *d_sa = c->d_sa;
     if (d_ssa) *d_ssa = c->d_ssa;
     if (d_esa) *d_esa = c->d_esa;
+    return PFP_OK;
+}
+
+// ---- development aid: position-weighted checksum of a device buffer (sum over bytes of (byte + 1) * mix(global position),
+// two independent mixes, modulo 2^64): the checksums of the pieces of a buffer add up to the checksum of the whole, so
+// outputs that live sliced over several builds / GPUs can be compared with a single-context output without moving them
+__device__ __forceinline__ uint64_t mix64(uint64_t z) { z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL; return z ^ (z >> 31); }
+__global__ __launch_bounds__(BLOCK) void k_checksum(const uint8_t *p, uint64_t bytes, uint64_t offset, unsigned long long *out)
+{
+    __shared__ unsigned long long red[4];
+    const uint64_t i0 = ((uint64_t)blockIdx.x * BLOCK + threadIdx.x) * 16;
+    unsigned long long a = 0, b = 0;
+    for (int k = 0; k < 16 && i0 + k < bytes; ++k) {
+        const uint64_t pos = offset + i0 + k, v = (uint64_t)p[i0 + k] + 1;
+        a += v * mix64(pos * 0x9E3779B97F4A7C15ULL + 1); b += v * mix64(pos * 0xD6E8FEB86659FD93ULL + 7);
+    }
+    unsigned long long ta, tb;
+    (void)block_excl_sum(a, red, &ta); (void)block_excl_sum(b, red, &tb);
+    if (threadIdx.x == 0) { atomicAdd(&out[0], ta); atomicAdd(&out[1], tb); }
+}
+int pfp_debug_checksum(pfp_ctx *c, const void *d_buf, uint64_t bytes, uint64_t global_offset, uint64_t out[2])
+{
+    if (!c || (!d_buf && bytes) || !out) return PFP_E_ARG;
+    PFP_HIP(c, hipSetDevice(c->device));
+    unsigned long long *d_out; PFP_HIP(c, hipMalloc((void **)&d_out, 16));
+    PFP_HIP(c, hipMemsetAsync(d_out, 0, 16, c->stream));
+    const uint64_t per = (uint64_t)1 << 34;            // pieces of 16 GiB keep the grid below 2^31 workgroups
+    for (uint64_t off = 0; off < bytes; off += per) {
+        const uint64_t nb = bytes - off < per ? bytes - off : per;
+        PFP_LAUNCH(c, K_MISC, nb, k_checksum, nblocks(nb, 16 * BLOCK), (const uint8_t *)d_buf + off, nb, global_offset + off, d_out);
+    }
+    unsigned long long h[2];
+    PFP_HIP(c, hipMemcpyAsync(h, d_out, 16, hipMemcpyDeviceToHost, c->stream));
+    PFP_HIP(c, hipStreamSynchronize(c->stream));
+    PFP_HIP(c, hipFree(d_out));
+    out[0] = h[0]; out[1] = h[1];
     return PFP_OK;
 }
 

@@ -69,10 +69,22 @@ def sharded_build(ctx, feed_local, w, device, sa=True, rssa=False, group=None):
     4. every rank emits its own slice of the output rows (pfp_bwt_build_slice): .bwt / .sa stay distributed in HBM.
     feed_local(ctx) feeds this rank's sequences.  Returns (parse sizes, bwt sizes of the slice, first row, rows)."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    if rank > 0:
-        ctx.feed_left_context(w)
-    feed_local(ctx)
-    ctx.finalize()
+    err = None
+    try:
+        if rank > 0:
+            ctx.feed_left_context(w)
+        feed_local(ctx)
+        sz_local = ctx.finalize()
+        if sz_local.m < 2 and world > 1:      # pfp_merge_shards needs the first and the last phrase of a shard to be different phrases
+            raise ValueError("shard of rank %d has a single phrase (no trigger window inside it): give it more sequence or use fewer ranks" % rank)
+    except Exception as e:      # an invalid character, a shard that is too small, ...: every rank must learn of it BEFORE the
+        err = e                  # collective, or the healthy ranks would wait in the all-gather for ever
+    ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=device)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+    if err is not None:
+        raise err
+    if int(ok.item()) == 0:
+        raise RuntimeError("sharded_build: another rank failed to parse its shard")
     views, keep = allgather_shards(ctx, device, group)
     sz = ctx.merge_shards(views)     # the local parse is consumed through its copy in `keep`
     del keep, views

@@ -62,6 +62,7 @@ def load_library(path=None):
     L.pfp_workspace_needed.argtypes = [vp]
     L.pfp_reset.argtypes = [vp]
     L.pfp_parse_feed.argtypes = [vp, vp, u64, i32]
+    L.pfp_parse_feed_batch.argtypes = [vp, vp, u64, u64, u64]
     L.pfp_parse_feed_device.argtypes = [vp, vp, u64, i32]
     L.pfp_parse_finalize.argtypes = [vp, C.POINTER(ParseSizes)]
     L.pfp_parse_get.argtypes = [vp, vp, vp, vp, vp, vp]
@@ -131,6 +132,10 @@ class PfpContext:
     def feed(self, bases, end_of_seq=True):
         a = np.frombuffer(bases, dtype=np.uint8) if isinstance(bases, (bytes, bytearray, memoryview)) else np.ascontiguousarray(bases, dtype=np.uint8)
         self._check(self.L.pfp_parse_feed(self.h, _ptr(a) if a.size else None, a.size, 1 if end_of_seq else 0))
+
+    def feed_host_batch(self, host_ptr, count, length, stride):
+        """`count` equal-length records in host memory (pinned: one strided DMA transfer; pageable: staging ring)"""
+        self._check(self.L.pfp_parse_feed_batch(self.h, C.c_void_p(int(host_ptr)), int(count), int(length), int(stride)))
 
     def feed_device(self, dptr, nbytes, end_of_seq=True):
         self._check(self.L.pfp_parse_feed_device(self.h, C.c_void_p(int(dptr)), int(nbytes), 1 if end_of_seq else 0))
@@ -204,9 +209,18 @@ class PfpContext:
         self.bsizes, self._want, self._rows, self.esa_pairs = b, (bool(sa), bool(rssa)), rows.value, ep.value
         return b, beg.value, rows.value
 
-    def bwt_get(self):
+    def bwt_get(self, out=None):
+        """copies the results to host arrays; `out` may hold caller-owned (e.g. page-locked) arrays bwt / sa / ssa / esa that
+        are at least as large as needed"""
         b = self.bsizes
         sa, rssa = self._want
+        if out is not None:
+            need = {"bwt": self._rows, "sa": self._rows if sa else None, "ssa": 2 * b.r if rssa else None, "esa": 2 * getattr(self, "esa_pairs", b.r) if rssa else None}
+            for k, cnt in need.items():
+                if cnt is not None and (out.get(k) is None or out[k].size < cnt or out[k].dtype != (np.uint8 if k == "bwt" else self.udt)):
+                    raise ValueError("bwt_get: out[%r] missing, too small or of the wrong type" % k)
+            self._check(self.L.pfp_bwt_get(self.h, _ptr(out["bwt"]), _ptr(out["sa"]) if sa else None, _ptr(out["ssa"]) if rssa else None, _ptr(out["esa"]) if rssa else None))
+            return out
         out = {"bwt": np.empty(self._rows, np.uint8), "sa": np.empty(self._rows, self.udt) if sa else None,
                "ssa": np.empty(2 * b.r, self.udt) if rssa else None, "esa": np.empty(2 * getattr(self, "esa_pairs", b.r), self.udt) if rssa else None}
         self._check(self.L.pfp_bwt_get(self.h, _ptr(out["bwt"]), _ptr(out["sa"]), _ptr(out["ssa"]), _ptr(out["esa"])))

@@ -61,8 +61,10 @@ from test_sharded import synth
 import pfbwt_hip, pfbwt_dist
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
-seqs = synth(7, 3000, 2 * world)
-mine = seqs[2 * rank: 2 * rank + 2]
+seqs = synth(7, 3000, 5)
+seqs = [seqs[0], seqs[1][:1700], seqs[2][:37], seqs[3], seqs[4][:2211]]      # unequal shards: rank 0 holds four records (one shorter
+mine = seqs[:4] if rank == 0 else seqs[4:]                                    # than a phrase), rank 1 a single one
+assert world == 2
 ctx = pfbwt_hip.PfpContext(lib=EMU_SO, w=6, p=11, u64=False, sai=True)
 sz, b, begin, rows = pfbwt_dist.sharded_build(ctx, lambda c: [c.feed(s, True) for s in mine], 6, torch.device("cpu"), sa=True)
 o = ctx.bwt_get()
@@ -87,6 +89,16 @@ if rank == 0:
     res = {"r": sum(t[2] for t in parts), "bwt": np.concatenate([t[3] for t in parts]), "ssa": np.concatenate([t[4] for t in parts]), "esa": np.concatenate([t[5] for t in parts])}
     bad = compare(res, oracle_run(seqs, w=6, p=11, U=4), 4, names=("bwt", "ssa", "esa"))
     if bad: ok = 0; print("MISMATCH -r", bad, flush=True)
+# a rank whose shard is rejected (invalid character): EVERY rank must raise, nobody may wait in the all-gather
+bad = [seqs[4][:500] + b"R" + seqs[4][500:1000]]
+try:
+    pfbwt_dist.sharded_build(ctx, lambda c: [c.feed(s, True) for s in (bad if rank == 1 else mine)], 6, torch.device("cpu"), sa=True)
+    ok = 0; print("rank %d: no error raised" % rank, flush=True)
+except pfbwt_hip.PfpError as e:
+    if rank != 1 or e.status != pfbwt_hip.E_INVALID_CHAR: ok = 0; print("rank %d: unexpected %r" % (rank, e), flush=True)
+except RuntimeError as e:
+    if rank != 0: ok = 0; print("rank %d: unexpected %r" % (rank, e), flush=True)
+ctx.reset()
 t = torch.tensor([ok]); dist.all_reduce(t, op=dist.ReduceOp.MIN)
 dist.barrier(); dist.destroy_process_group()
 sys.exit(0 if int(t) == 1 else 1)
