@@ -25,14 +25,14 @@ enum KernelId {
     K_TRIGGER_SCAN, K_PHRASE_ENDS, K_PHRASE_HASH, K_PHRASE_HASH_LONG, K_DEDUP_HEADS, K_DEDUP_LONG,
     K_DICT_BUILD, K_RADIX_HIST, K_RADIX_SCATTER, K_SCAN_REDUCE, K_SCAN_SPINE, K_SCAN_APPLY,
     K_SS_INIT_KEYS, K_SS_HEADS, K_SS_MAKE_KEYS, K_SS_WRITE_RANK, K_SS_FLAG_ACTIVE, K_COMPACT,
-    K_WORD_RANK, K_PARSE_RANKS, K_DICT_SORTED, K_PBWT_ROWS, K_EMIT_COUNT, K_EMIT, K_RUNS, K_SAMPLES, K_MISC, K_EMIT_BIG, K_FILL,
+    K_WORD_RANK, K_PARSE_RANKS, K_DICT_SORTED, K_PBWT_ROWS, K_EMIT_COUNT, K_EMIT, K_RUNS, K_SAMPLES, K_MISC, K_EMIT_BIG, K_FILL, K_CLASS_SORT,
     K_COUNT_
 };
 static const char *const kernel_names[K_COUNT_] = {
     "trigger_scan", "phrase_ends", "phrase_hash", "phrase_hash_long", "dedup_heads", "dedup_long",
     "dict_build", "radix_hist", "radix_scatter", "scan_reduce", "scan_spine", "scan_apply",
     "ss_init_keys", "ss_heads", "ss_make_keys", "ss_write_rank", "ss_flag_active", "compact",
-    "word_rank", "parse_ranks", "dict_sorted", "pbwt_rows", "emit_count", "emit", "runs", "samples", "misc", "emit_big", "fill"};
+    "word_rank", "parse_ranks", "dict_sorted", "pbwt_rows", "emit_count", "emit", "runs", "samples", "misc", "emit_big", "fill", "class_sort"};
 
 struct ProfRec { uint64_t launches = 0; double ms = 0, bytes = 0; };
 

@@ -259,7 +259,7 @@ static int sort_dict_suffixes(pfp_ctx *c)
     PFP_LAUNCH(c, K_SS_INIT_KEYS, N * 13, k_dict_init_keys, nblocks(N, DK_TILE), (const uint8_t *)c->d_dict, N, k0, v0);
     BitRange full = {0, DK_KEY_BITS};
     int rounds = 0;
-    PFP_TRY(suffix_sort_doubling(c, N, k0, v0, k1, v1, &full, 1, DK_CHARS, c->d_ws, c->d_wordid, c->d_dict, c->d_gsa, c->d_grank, &rounds));
+    PFP_TRY(suffix_sort_doubling<true>(c, N, k0, v0, k1, v1, &full, 1, DK_CHARS, c->d_dict, c->d_gsa, (uint32_t *)nullptr, c->d_grank, &rounds));
     c->arena.release_hi(mk);
     c->gsa_valid = true;
     return PFP_OK;
@@ -690,7 +690,7 @@ int pfp_parse_get(pfp_ctx *c, uint8_t *dict, void *occ, uint32_t *parse, uint8_t
 }
 
 // suffix array of S[0..N) (S[N-1] == 0 unique smallest), integer alphabet with values <= maxsym
-static int sort_int_suffixes(pfp_ctx *c, const uint32_t *dS, uint64_t N, uint64_t maxsym, uint32_t *SA, uint2 *rank, int *rounds)
+static int sort_int_suffixes(pfp_ctx *c, const uint32_t *dS, uint64_t N, uint64_t maxsym, uint32_t *SA, uint32_t *rank, int *rounds)
 {
     const size_t mk = c->arena.mark_hi();
     uint64_t *k0, *k1; uint32_t *v0, *v1;
@@ -699,7 +699,7 @@ static int sort_int_suffixes(pfp_ctx *c, const uint32_t *dS, uint64_t N, uint64_
     PFP_LAUNCH(c, K_SS_INIT_KEYS, N * 16, k_int_init_keys, nblocks(N, BLOCK), dS, N, k0, v0);
     const int sb = bits_for(maxsym);
     BitRange rr[2] = {{0, sb}, {32, 32 + sb}};
-    PFP_TRY(suffix_sort_doubling(c, N, k0, v0, k1, v1, rr, 2, 2, nullptr, nullptr, nullptr, SA, rank, rounds));
+    PFP_TRY(suffix_sort_doubling<false>(c, N, k0, v0, k1, v1, rr, 2, 2, (const uint8_t *)nullptr, SA, rank, (uint2 *)nullptr, rounds));
     c->arena.release_hi(mk);
     return PFP_OK;
 }
@@ -723,12 +723,12 @@ static int parse_bwt_impl(pfp_ctx *c)
     const uint64_t m = c->m, N = m + 1;
     const size_t mk = c->arena.mark_hi();
     PFP_LAUNCH(c, K_MISC, 4, k_set_u32, 1, c->d_parse, m, 0u);  // :407-410 (d_parse has m+1 slots)
-    uint32_t *SAP, *W, *rowid, *W2, *rowid2; uint2 *rk;
+    uint32_t *SAP, *W, *rowid, *W2, *rowid2, *rk;
     PFP_ALLOC_LO(c, c->d_bwlast, uint8_t, N);
     PFP_ALLOC_LO(c, c->d_ilist, uint32_t, N);
     const bool sai = (c->flags & PFP_FLAG_SAI) != 0;
     if (sai) PFP_ALLOC_LO(c, c->d_bwsai, tpos_t, N); else c->d_bwsai = nullptr;
-    PFP_ALLOC_HI(c, SAP, uint32_t, N); PFP_ALLOC_HI(c, rk, uint2, N);
+    PFP_ALLOC_HI(c, SAP, uint32_t, N); PFP_ALLOC_HI(c, rk, uint32_t, N);
     PFP_ALLOC_HI(c, W, uint32_t, N); PFP_ALLOC_HI(c, rowid, uint32_t, N);
     PFP_ALLOC_HI(c, W2, uint32_t, N); PFP_ALLOC_HI(c, rowid2, uint32_t, N);
     int rounds = 0;
@@ -1315,7 +1315,7 @@ static int sacak_int_impl(const uint32_t *s, void *SA, uint64_t n, uint64_t k, b
     int rounds = -1;
     do {
         if (ensure_arena(c, n) != PFP_OK) break;
-        uint32_t *dS = (uint32_t *)c->arena.alloc_lo(n * 4), *dSA = (uint32_t *)c->arena.alloc_lo(n * 4); uint2 *dR = (uint2 *)c->arena.alloc_lo(n * 8);
+        uint32_t *dS = (uint32_t *)c->arena.alloc_lo(n * 4), *dSA = (uint32_t *)c->arena.alloc_lo(n * 4), *dR = (uint32_t *)c->arena.alloc_lo(n * 4);
         if (!dS || !dSA || !dR) break;
         if (hipMemcpy(dS, s, n * 4, hipMemcpyHostToDevice) != hipSuccess) break;
         int r = 0;

@@ -39,15 +39,17 @@ __global__ __launch_bounds__(BLOCK) void k_dict_init_keys(const uint8_t *D, uint
 #pragma unroll 1
     for (int k = 0; k < DK_PER_THREAD; ++k) {
         const uint32_t l = (uint32_t)k * BLOCK + threadIdx.x;
-        uint64_t key = 0; bool stop = false;
+        uint64_t key = 0; bool stop = false; uint32_t off = DK_CHARS;
 #pragma unroll
         for (int j = 0; j < DK_CHARS; ++j) {
             const uint32_t cc = tile[l + j];
             key = key * 9u + (stop ? 0u : cc);
+            if (!stop && cc <= 1) off = (uint32_t)j + 1u;
             stop = stop || cc <= 1;                      // the terminator itself is part of the key, nothing after it
         }
+        // bits 56..60: length of the prefix the key covers = jump offset (never past the byte behind the terminator)
         const uint64_t x = t0 + l;
-        if (x < dsize) { keys[x] = key; vals[x] = (uint32_t)x; }
+        if (x < dsize) { keys[x] = key | ((uint64_t)off << 56); vals[x] = (uint32_t)x; }
     }
 }
 
@@ -60,100 +62,15 @@ __global__ __launch_bounds__(BLOCK) void k_int_init_keys(const uint32_t *S, uint
     vals[x] = (uint32_t)x;
 }
 
-// after a sort of the active list: head flags, SA write-back, head slot for the max-scan
-__global__ __launch_bounds__(BLOCK) void k_ss_heads(const uint64_t *keys, const uint32_t *vals, const uint32_t *slots /*nullable: identity*/, uint64_t na,
-                                                    uint32_t *SA, uint32_t *head, uint32_t *headslot)
+// after the initial sort of all N suffixes: head flags, SA, head slot for the max-scan
+__global__ __launch_bounds__(BLOCK) void k_ss_heads(const uint64_t *keys, const uint32_t *vals, uint64_t na, uint64_t keymask, uint32_t *SA, uint32_t *head, uint32_t *headslot)
 {
     const uint64_t a = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (a >= na) return;
-    const uint32_t slot = slots ? slots[a] : (uint32_t)a;
-    const uint32_t hd = (a == 0 || keys[a] != keys[a - 1]) ? 1u : 0u;
-    SA[slot] = vals[a];
+    const uint32_t hd = (a == 0 || (keys[a] & keymask) != (keys[a - 1] & keymask)) ? 1u : 0u;
+    SA[a] = vals[a];
     head[a] = hd;
-    headslot[a] = hd ? slot : 0u;
-}
-// rj[x] = { rank: slot of the class head of suffix x, jump: end of its covered prefix } -- one 8-byte record so
-// that the doubling step costs two random gathers (x and jump[x]) instead of four
-__global__ __launch_bounds__(BLOCK) void k_ss_write_rank(const uint32_t *vals, const uint32_t *newrank, uint64_t na, uint2 *rj)
-{
-    const uint64_t a = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (a < na) reinterpret_cast<uint32_t *>(rj)[2 * (uint64_t)vals[a]] = newrank[a];
-}
-// rank and jump of a re-sorted suffix in ONE 8-byte record write (the new jump travelled with the pair through the sort)
-__global__ __launch_bounds__(BLOCK) void k_ss_write_rank_jump(const uint32_t *vals, const uint32_t *newrank, const uint32_t *nj, uint64_t na, uint2 *rj)
-{
-    const uint64_t a = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (a < na) rj[vals[a]] = make_uint2(newrank[a], nj[a]);
-}
-__global__ __launch_bounds__(BLOCK) void k_ss_init_rj(const uint32_t *vals, const uint32_t *newrank, uint64_t N, uint32_t h0, uint2 *rj)
-{
-    const uint64_t a = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (a >= N) return;
-    const uint64_t x = vals[a];
-    rj[x] = make_uint2(newrank[a], (uint32_t)(x + h0 < N ? x + h0 : N));
-}
-// keep[a] = 1 while the class of element a still has to be refined.
-// ws/wordid != nullptr selects dictionary semantics: a class whose covered prefix [x, jump[x]) already
-// contains the terminator is a group of byte-identical suffixes and is final.
-__global__ __launch_bounds__(BLOCK) void k_ss_flag_active(const uint32_t *vals, const uint32_t *head, uint64_t na, const uint2 *rj, const uint32_t *jump_sorted /*nullable: jump of vals[a]*/,
-                                                          const uint64_t *dict_init_keys /*nullable: first call of a dictionary sort*/, const uint32_t *ws, const uint32_t *wordid, uint32_t *keep)
-{
-    const uint64_t a = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (a >= na) return;
-    const bool single = head[a] && (a + 1 == na || head[a + 1]);
-    bool fin = single;
-    if (!fin && dict_init_keys) {
-        // after the initial sort the covered prefix is the 16 characters of the key: it contains the word's terminator exactly
-        // when the last base-9 digit is 0 (padding behind a terminator) or the terminator itself (k_dict_init_keys) -- no gathers
-        fin = dict_init_keys[a] % 9u <= 1u;
-    } else if (!fin && ws) {
-        const uint32_t x = vals[a];
-        const uint32_t term = ws[wordid[x] + 1] - 1u;     // offset of the EndOfWord of x's word
-        fin = (jump_sorted ? jump_sorted[a] : reinterpret_cast<const uint32_t *>(rj)[2 * (uint64_t)x + 1]) > term;
-    }
-    keep[a] = fin ? 0u : 1u;
-}
-// Doubling with pointer jumping: rank[x] orders suffix x by its covered prefix [x, jump[x]); the next
-// key is (rank[x], rank[jump[x]]) and the covered prefix grows to [x, jump[jump[x]]).
-// Run round (M != nullptr, first refinement of a byte text): a suffix whose first RUN_MIN characters
-// are one repeated character c sits inside a run c^d; ordering such suffixes by plain doubling takes
-// log2(d) rounds with the whole run active (a 10 Mbp run of N: 20 rounds x 10 M suffixes).  Instead the
-// whole run is consumed at once: c^d a... is ordered among the suffixes starting with c by
-// t = d if a < c, 2^32-1-d if a > c  (a = first character after the run), and jump = x + d.
-constexpr uint32_t RUN_MIN = DK_CHARS;
-__global__ __launch_bounds__(BLOCK) void k_ss_make_keys(const uint32_t *slots, const uint32_t *SA, const uint2 *rj, uint64_t na, uint64_t N,
-                                                        const uint8_t *D, const uint32_t *M, int lowbits, uint64_t *keys, uint32_t *vals, uint32_t *nj)
-{
-    const uint64_t a = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (a >= na) return;
-    const uint32_t x = SA[slots[a]];
-    const uint2 P = rj[x];
-    uint32_t low, nx;
-    bool run = false;
-    if (M) {
-        const uint32_t ip = (uint32_t)(N - 1 - x);
-        const uint32_t d = ip - M[ip] + 1u;                 // length of the run of D[x] that starts at x
-        if (d >= RUN_MIN && D[x] > EndOfWord) {
-            const uint64_t e = (uint64_t)x + d;
-            const uint8_t nxt = e < N ? D[e] : (uint8_t)0;
-            low = nxt < D[x] ? d : 0xFFFFFFFFu - d;
-            nx = (uint32_t)(e < N ? e : N);
-            run = true;
-        }
-    }
-    if (!run) {
-        const uint32_t y = P.y;
-        const uint2 Q = y < N ? rj[y] : make_uint2(0u, (uint32_t)N);
-        low = Q.x; nx = Q.y;
-    }
-    keys[a] = ((uint64_t)P.x << lowbits) | low;      // (rank, refinement) packed tightly: 2*bits(N) key bits
-    vals[a] = x;
-    nj[a] = nx;
-}
-__global__ __launch_bounds__(BLOCK) void k_ss_apply_jump(const uint32_t *vals, const uint32_t *nj, uint64_t na, uint2 *rj)
-{
-    const uint64_t a = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (a < na) reinterpret_cast<uint32_t *>(rj)[2 * (uint64_t)vals[a] + 1] = nj[a];
+    headslot[a] = hd ? (uint32_t)a : 0u;
 }
 // i' = N-1-x: g[i'] = i' where x is the last position of a run of equal bytes, else 0.  The inclusive
 // max-scan M of g gives, for every x, the nearest run end at or after x: runlen(x) = i' - M[i'] + 1.
@@ -165,56 +82,99 @@ __global__ __launch_bounds__(BLOCK) void k_ss_runend_marks(const uint8_t *D, uin
     g[ip] = (x + 1 == N || D[x] != D[x + 1]) ? (uint32_t)ip : 0u;
 }
 
-// ---- sort of a doubling round ------------------------------------------------------------------------------------
-// The active list is in slot order: the members of a class (equal rank = equal high key part) are already contiguous,
-// only the order INSIDE every class is unknown.  Classes are small on the inputs that have many rounds with everything
-// active (a 1000-haplotype parse: ~1000 members per class), so a workgroup sorts whole classes inside LDS: the pairs
-// cross HBM once per round instead of once per radix pass (8 passes of 32 B for 58-bit keys).  Workgroup j owns the
-// classes that START in [j*CS_STEP, (j+1)*CS_STEP); they end where the first class of the next stripe starts.  A range
-// longer than one tile (a class with thousands of members) is left alone; those pairs are collected afterwards and go
-// through the ordinary radix sort.
+// ---- state of the refinement -------------------------------------------------------------------------------------
+//   SA[slot] = x                          suffixes in the order found so far; a class = a contiguous range of slots
+//   int alphabet:  rank[x]                slot of the head of x's class (one 4-byte gather gives the second key part:
+//                                         jumps are uniform there, the suffix h positions on is x + h)
+//   dictionary:    rj[x] = {rank, jump}   jump = end of the prefix [x, jump) the rank orders x by; never past the first
+//                                         byte after the word's EndOfWord, so "the covered prefix contains the
+//                                         terminator" (the class is a group of identical suffixes, final) is
+//                                         D[jump - 1] == EndOfWord; one 8-byte gather gives rank and jump of the target
+//   active list, in slot order:  aslot[a], arnk[a] = rank of its class (= slot of the class head), ajmp[a] (dictionary)
+// One round = k_round (sort inside every class by the rank of the suffix one covered prefix on, new heads, new ranks,
+// SA; the pairs cross HBM once) + k_round_apply (ranks that changed are scattered to rank[] / rj[] only now -- a round
+// must read the ranks of ONE state --, the list of classes that still have to be refined is compacted per stripe).
+constexpr uint32_t RUN_MIN = DK_CHARS;
 constexpr uint32_t CS_STEP = RS_TILE / 2;
-template <typename K> __global__ __launch_bounds__(BLOCK) void k_class_tile_sort(const K *keys, const uint32_t *vals, const uint32_t *nj, K *okeys, uint32_t *ovals, uint32_t *onj,
-                                                                                 uint64_t na, int lowbits, uint32_t max_range, uint8_t *done, unsigned long long *nsorted)
+constexpr uint8_t RF_KEEP = 1, RF_CHANGED = 2, RF_DONE = 4;
+
+__global__ __launch_bounds__(BLOCK) void k_not_done(const uint8_t *done, uint64_t n, uint32_t *flag)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) flag[i] = done[i] ? 0u : 1u;
+}
+// first class start at or after position b of the active list (arnk ascends along the list: the end of a class is found
+// by bisection, however many members it has)
+__device__ __forceinline__ uint64_t class_start_at_or_after(const uint32_t *arnk, uint64_t na, uint64_t b)
+{
+    if (b == 0 || b >= na) return b < na ? b : na;
+    const uint32_t g = arnk[b - 1];
+    if (arnk[b] != g) return b;
+    uint64_t lo = b, hi = na;                              // first position in [b, na) with arnk > g
+    while (lo < hi) { const uint64_t mid = lo + ((hi - lo) >> 1); if (arnk[mid] <= g) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+// Workgroup j owns the classes that START in [j*CS_STEP, (j+1)*CS_STEP) of the active list; they end where the first
+// class of the next stripe starts (at most one tile of pairs; a longer range -- a class with thousands of members -- is
+// left alone: its flags stay 0 and the pairs go through the global radix sort, k_round_keys / k_round_finish).
+template <bool DICT> __global__ __launch_bounds__(BLOCK) void k_round(const uint32_t *aslot, const uint32_t *arnk, const uint32_t *ajmp, uint64_t na, uint64_t N,
+                                                                      uint32_t *SA, const uint32_t *rank, const uint2 *rj, uint32_t h, const uint8_t *D, const uint32_t *M /*run round*/,
+                                                                      int lowbits, uint32_t max_range, uint32_t *newr, uint32_t *tnj, uint32_t *newj, uint8_t *flags, uint32_t *stripe_keep,
+                                                                      unsigned long long *ndone)
 {
     constexpr int ITEMS = RS_ITEMS, TILE = RS_TILE;
     __shared__ uint32_t wh[BLOCK / WAVE][RS_RADIX];
-    __shared__ K skeys[TILE];
-    __shared__ uint16_t sidx[TILE];                     // the payload inside LDS is the pair's index in the range; x and the new jump
-    __shared__ uint32_t red[4];                          // are fetched from the (cache-resident) input range when the range is written out
-    __shared__ uint32_t bound[2];
+    __shared__ uint64_t skeys[TILE];
+    __shared__ uint16_t sidx[TILE];                      // payload of the LDS sort: index of the pair in the range
+    __shared__ uint16_t shp[TILE + 1];                   // position (in the sorted range) of the head of every pair's new class
+    __shared__ unsigned long long red[4];
+    __shared__ uint64_t bound[2];
     const uint64_t w0 = (uint64_t)blockIdx.x * CS_STEP;
-    if (threadIdx.x < 2) bound[threadIdx.x] = 0xFFFFFFFFu;
+    if (threadIdx.x < 2) bound[threadIdx.x] = class_start_at_or_after(arnk, na, w0 + (uint64_t)threadIdx.x * CS_STEP);
     __syncthreads();
-    for (int which = 0; which < 2; ++which) {          // first class start at or after w0 (which = 0), w0 + CS_STEP (which = 1)
-        const uint64_t b = w0 + (uint64_t)which * CS_STEP;
-        for (uint32_t t = threadIdx.x; t < (uint32_t)TILE; t += BLOCK) {
-            const uint64_t a = b + t;
-            if (a > na) break;
-            const bool st = a == na || a == 0 || (keys[a] >> lowbits) != (keys[a - 1] >> lowbits);
-            if (st) { atomicMin(&bound[which], t); break; }
-        }
-    }
-    __syncthreads();
-    if (bound[0] >= CS_STEP) return;                      // no class starts in this stripe
-    const uint64_t s = w0 + bound[0];
-    if (s >= na) return;
-    if (bound[1] == 0xFFFFFFFFu) return;                  // the last class of the stripe runs on for more than a tile
-    const uint64_t e = w0 + CS_STEP + bound[1];
-    if (e - s > (uint64_t)max_range) return;
+    const uint64_t s = bound[0], e = bound[1];
+    if (s >= w0 + CS_STEP || s >= na) return;             // no class starts in this stripe
+    if (e - s > (uint64_t)max_range) return;              // a class with more members than a tile holds
     const uint32_t n = (uint32_t)(e - s);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;
-    const uint32_t nit = (n + BLOCK - 1) / BLOCK;                 // pairs per thread this range needs (ranges are ~half a tile)
+    const uint32_t nit = (n + BLOCK - 1) / BLOCK;
     const uint32_t base = (uint32_t)wave * (nit * WAVE) + lane;   // wave w owns the contiguous pairs [w * nit * 64, (w + 1) * nit * 64)
-    for (uint32_t j = threadIdx.x; j < n; j += BLOCK) { skeys[j] = keys[s + j]; sidx[j] = (uint16_t)j; }
+    const uint32_t hmin = arnk[s];
+    // ---- keys: (rank of the class, rank of the suffix one covered prefix further on)
+    for (uint32_t j = threadIdx.x; j < n; j += BLOCK) {
+        const uint32_t x = SA[aslot[s + j]];
+        uint32_t low;
+        if (!DICT) { const uint64_t y = (uint64_t)x + h; low = y < N ? rank[y] : 0u; }
+        else {
+            uint32_t nx; bool run = false;
+            if (M) {   // run round: c^d a... is ordered among the suffixes that start with c by t = d if a < c else 2^32-1-d, jump = x + d
+                const uint32_t ip = (uint32_t)(N - 1 - x);
+                const uint32_t d = ip - M[ip] + 1u;
+                if (d >= RUN_MIN && D[x] > EndOfWord) {
+                    const uint64_t en = (uint64_t)x + d;
+                    const uint8_t nxt = en < N ? D[en] : (uint8_t)0;
+                    low = nxt < D[x] ? d : 0xFFFFFFFFu - d; nx = (uint32_t)(en < N ? en : N); run = true;
+                }
+            }
+            if (!run) {
+                const uint32_t y = ajmp[s + j];
+                const uint2 Q = y < N ? rj[y] : make_uint2(0u, (uint32_t)N);
+                low = Q.x; nx = Q.y;
+            }
+            tnj[s + j] = nx;
+        }
+        skeys[j] = ((uint64_t)(arnk[s + j] - hmin) << lowbits) | low; sidx[j] = (uint16_t)j;
+    }
     __syncthreads();
-    const K lomask = lowbits >= 64 ? ~(K)0 : (((K)1 << lowbits) - 1);
-    const K hmin = skeys[0] >> lowbits, hspan = (skeys[n - 1] >> lowbits) - hmin;     // high parts are already in order
+    // ---- LSD radix sort of the range inside LDS: the low part, then the span of the (already ordered) class part
+    const uint64_t lomask = lowbits >= 64 ? ~0ULL : ((1ULL << lowbits) - 1);
+    const uint64_t hspan = skeys[n - 1] >> lowbits;
     const int nlo = (lowbits + 7) / 8;
     int nhi = 0; while (nhi < 8 && (hspan >> (8 * nhi))) ++nhi;
     for (int p = 0; p < nlo + nhi; ++p) {
-        K k[ITEMS]; uint16_t v[ITEMS]; unsigned dg[ITEMS];
+        uint64_t k[ITEMS]; uint16_t v[ITEMS]; unsigned dg[ITEMS];
 #pragma unroll
         for (int w = 0; w < BLOCK / WAVE; ++w) wh[w][threadIdx.x] = 0;
         __syncthreads();
@@ -223,8 +183,8 @@ template <typename K> __global__ __launch_bounds__(BLOCK) void k_class_tile_sort
             if ((uint32_t)it < nit) {                                  // uniform; no break: the loop must unroll (register arrays)
             const uint32_t i = base + (uint32_t)it * WAVE;
             const bool valid = i < n;
-            k[it] = valid ? skeys[i] : (K)0; v[it] = valid ? sidx[i] : (uint16_t)0;
-            const unsigned d = p < nlo ? (unsigned)((k[it] & lomask) >> (8 * p)) & (RS_RADIX - 1) : (unsigned)(((k[it] >> lowbits) - hmin) >> (8 * (p - nlo))) & (RS_RADIX - 1);
+            k[it] = valid ? skeys[i] : 0ULL; v[it] = valid ? sidx[i] : (uint16_t)0;
+            const unsigned d = p < nlo ? (unsigned)((k[it] & lomask) >> (8 * p)) & (RS_RADIX - 1) : (unsigned)((k[it] >> lowbits) >> (8 * (p - nlo))) & (RS_RADIX - 1);
             unsigned long long peers = __ballot(valid);
 #pragma unroll
             for (int bb = 0; bb < 8; ++bb) {
@@ -245,7 +205,7 @@ template <typename K> __global__ __launch_bounds__(BLOCK) void k_class_tile_sort
 #pragma unroll
             for (int w = 0; w < BLOCK / WAVE; ++w) { cw[w] = wh[w][d]; total += cw[w]; }
             uint32_t tt;
-            uint32_t run = block_excl_sum(total, red, &tt);
+            uint32_t run = block_excl_sum(total, reinterpret_cast<uint32_t *>(red), &tt);
 #pragma unroll
             for (int w = 0; w < BLOCK / WAVE; ++w) { wh[w][d] = run; run += cw[w]; }
         }
@@ -257,144 +217,258 @@ template <typename K> __global__ __launch_bounds__(BLOCK) void k_class_tile_sort
         }
         __syncthreads();
     }
-    for (uint32_t j = threadIdx.x; j < n; j += BLOCK) {
-        const uint32_t src = sidx[j];
-        okeys[s + j] = skeys[j]; ovals[s + j] = vals[s + src]; onj[s + j] = nj[s + src]; done[s + j] = 1;
+    // ---- new classes: pair j heads a class iff its key differs from its predecessor's; head position of every pair by a
+    //      max-scan (a thread scans a contiguous chunk, the chunk maxima go through the block scan)
+    const uint32_t c0 = threadIdx.x * nit, c1 = (c0 + nit < n) ? c0 + nit : n;
+    uint32_t runmax = 0;
+    for (uint32_t j = c0; j < c1; ++j) {
+        const bool hd = j == 0 || skeys[j] != skeys[j - 1];
+        runmax = hd ? j : runmax;
+        shp[j] = (uint16_t)runmax;                       // exact only behind the first head of the chunk; fixed below
     }
-    if (threadIdx.x == 0) atomicAdd(nsorted, (unsigned long long)n);
-}
-__global__ __launch_bounds__(BLOCK) void k_not_done(const uint8_t *done, uint64_t n, uint32_t *flag)
-{
-    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i < n) flag[i] = done[i] ? 0u : 1u;
-}
-template <typename K> __global__ __launch_bounds__(BLOCK) void k_gather_pairs(const K *keys, const uint32_t *vals, const uint32_t *idx, uint64_t n, K *ok, uint32_t *ov)
-{
-    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i < n) { ok[i] = keys[idx[i]]; ov[i] = vals[idx[i]]; }
-}
-template <typename K> __global__ __launch_bounds__(BLOCK) void k_scatter_pairs(const K *keys, const uint32_t *vals, const uint32_t *idx, uint64_t n, K *ok, uint32_t *ov)
-{
-    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i < n) { ok[idx[i]] = keys[i]; ov[idx[i]] = vals[i]; }
-}
-__global__ __launch_bounds__(BLOCK) void k_gather_u32(const uint32_t *in, const uint32_t *idx, uint64_t n, uint32_t *out)
-{
-    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i < n) out[i] = in[idx[i]];
-}
-__global__ __launch_bounds__(BLOCK) void k_gather_jump(const uint32_t *vals, const uint32_t *idx, uint64_t n, const uint2 *rj, uint32_t *onj)
-{
-    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i < n) onj[idx[i]] = rj[vals[i]].y;
-}
-// Sorts the na pairs of a round by (high part, low part); result in *sk / *sv.  nj[a] is the new jump of pair a: on the
-// LDS route it travels with the pair (*snj = its sorted copy, the caller writes rank and jump together); when the plain
-// radix sort is taken the jumps are applied to rj here, before the pair order is lost (*snj = nullptr).
-inline int class_segment_sort(pfp_ctx *c, uint64_t *k0, uint32_t *v0, const uint32_t *nj, uint64_t *k1, uint32_t *v1, uint32_t *onj, uint64_t na, int lowbits, int rbits,
-                              uint2 *rj, uint64_t **sk, uint32_t **sv, uint32_t **snj)
-{
-    BitRange rr = {0, lowbits + rbits};
-    const unsigned ga = nblocks(na, BLOCK);
-    *snj = nullptr;
-    static const long long min_na = getenv("PFP_CLASS_SORT_MIN") ? atoll(getenv("PFP_CLASS_SORT_MIN")) : 8ll * RS_TILE;   // < 0: never (tests: 1 = always)
-    if (min_na < 0 || na < (uint64_t)min_na) {
-        PFP_LAUNCH(c, K_SS_MAKE_KEYS, na * 12, k_ss_apply_jump, ga, (const uint32_t *)v0, nj, na, rj);
-        return radix_sort_pairs<uint64_t>(c, k0, v0, k1, v1, na, &rr, 1, sk, sv);
+    uint32_t tot;
+    const uint32_t inc = block_incl_max(runmax, reinterpret_cast<uint32_t *>(red), &tot);
+    uint32_t prev = __shfl_up(inc, 1);
+    __shared__ uint32_t wmax[BLOCK / WAVE];
+    if (lane == 63) wmax[wave] = inc;
+    __syncthreads();
+    if (lane == 0) prev = wave ? wmax[wave - 1] : 0u;     // maximum over the threads in front (0 for thread 0: pair 0 is a head)
+    for (uint32_t j = c0; j < c1; ++j) { const uint32_t v = shp[j]; if (v >= prev && v != 0) break; shp[j] = (uint16_t)(v > prev ? v : prev); }
+    if (threadIdx.x == 0) shp[n] = (uint16_t)n;           // sentinel: "the pair behind the last one heads a class"
+    __syncthreads();
+    // ---- output: all gathers of the old SA first (the range's slots are overwritten below)
+    uint32_t xs[ITEMS]; unsigned long long keepn = 0;     // kept pairs per position stripe (the range touches at most three), 20 bits each
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        const uint32_t j = threadIdx.x + (uint32_t)it * BLOCK;
+        xs[it] = j < n ? SA[aslot[s + sidx[j]]] : 0u;
     }
-    static const uint32_t max_range = getenv("PFP_CLASS_SORT_MAXRANGE") ? (uint32_t)atoi(getenv("PFP_CLASS_SORT_MAXRANGE")) : (uint32_t)RS_TILE;   // tests: smaller, to reach the large-class route
-    const size_t mk = c->arena.mark_hi();
-    uint8_t *done; unsigned long long *d_ns;
-    PFP_ALLOC_HI(c, done, uint8_t, na); PFP_ALLOC_HI(c, d_ns, unsigned long long, 1);
-    PFP_HIP(c, hipMemsetAsync(done, 0, na, c->stream));
-    PFP_HIP(c, hipMemsetAsync(d_ns, 0, 8, c->stream));
-    PFP_LAUNCH(c, K_RADIX_SCATTER, na * 64, (k_class_tile_sort<uint64_t>), nblocks(na, CS_STEP), (const uint64_t *)k0, (const uint32_t *)v0, nj, k1, v1, onj, na, lowbits, max_range, done, d_ns);
-    unsigned long long ns = 0;
-    PFP_HIP(c, hipMemcpyAsync(&ns, d_ns, 8, hipMemcpyDeviceToHost, c->stream));
-    PFP_HIP(c, hipStreamSynchronize(c->stream));
-    const uint64_t nl = na - ns;
-    static const bool verbose = getenv("PFP_VERBOSE") != nullptr;
-    if (verbose) fprintf(stderr, "[pfbwt_hip]   class sort: %llu pairs, %llu in classes too large for one tile%s\n", (unsigned long long)na, (unsigned long long)nl, nl > na / 2 ? " -> plain radix sort" : "");
-    if (nl > na / 2) {            // mostly large classes: one plain sort of everything (k0 / v0 / nj are still intact)
-        c->arena.release_hi(mk);
-        PFP_LAUNCH(c, K_SS_MAKE_KEYS, na * 12, k_ss_apply_jump, ga, (const uint32_t *)v0, nj, na, rj);
-        return radix_sort_pairs<uint64_t>(c, k0, v0, k1, v1, na, &rr, 1, sk, sv);
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        const uint32_t j = threadIdx.x + (uint32_t)it * BLOCK;
+        if (j < n) {
+            const uint32_t hp = shp[j], slot = aslot[s + j];
+            const uint32_t nr = aslot[s + hp];
+            const bool single = hp == j && shp[j + 1] == j + 1;
+            bool keep = !single;
+            uint8_t fl = RF_DONE;
+            if (DICT) {
+                const uint32_t nj = tnj[s + sidx[j]];
+                newj[s + j] = nj;
+                const bool fin = nj >= N || D[nj - 1] == EndOfWord;      // the covered prefix now holds the word's terminator: a group of identical suffixes
+                keep = keep && !fin;
+                fl |= RF_CHANGED;                                         // the jump changes every round
+            } else if (nr != arnk[s + j]) fl |= RF_CHANGED;
+            if (keep) { fl |= RF_KEEP; keepn += 1ULL << (20 * (uint32_t)((s + j) / CS_STEP - blockIdx.x)); }
+            SA[slot] = xs[it]; newr[s + j] = nr; flags[s + j] = fl;
+        }
     }
-    if (nl) {                      // the pairs of the large classes: collect, sort, put back (their positions are whole classes in order)
-        uint32_t *flag, *pos, *idx, *d_cnt, *lnj; uint64_t *lk0, *lk1; uint32_t *lv0, *lv1;
-        PFP_ALLOC_HI(c, flag, uint32_t, na); PFP_ALLOC_HI(c, pos, uint32_t, na); PFP_ALLOC_HI(c, idx, uint32_t, nl); PFP_ALLOC_HI(c, d_cnt, uint32_t, 1);
-        PFP_ALLOC_HI(c, lk0, uint64_t, nl); PFP_ALLOC_HI(c, lk1, uint64_t, nl); PFP_ALLOC_HI(c, lv0, uint32_t, nl); PFP_ALLOC_HI(c, lv1, uint32_t, nl); PFP_ALLOC_HI(c, lnj, uint32_t, nl);
-        PFP_LAUNCH(c, K_COMPACT, na * 5, k_not_done, ga, (const uint8_t *)done, na, flag);
-        PFP_TRY(device_compact(c, nullptr, flag, na, idx, pos, d_cnt));
-        PFP_LAUNCH(c, K_COMPACT, nl * 28, (k_gather_pairs<uint64_t>), nblocks(nl, BLOCK), (const uint64_t *)k0, (const uint32_t *)v0, (const uint32_t *)idx, nl, lk0, lv0);
-        PFP_LAUNCH(c, K_COMPACT, nl * 12, k_gather_u32, nblocks(nl, BLOCK), nj, (const uint32_t *)idx, nl, lnj);
-        PFP_LAUNCH(c, K_SS_MAKE_KEYS, nl * 12, k_ss_apply_jump, nblocks(nl, BLOCK), (const uint32_t *)lv0, (const uint32_t *)lnj, nl, rj);   // their jumps go to rj now, the sort loses the pairing
-        uint64_t *lsk; uint32_t *lsv;
-        PFP_TRY(radix_sort_pairs<uint64_t>(c, lk0, lv0, lk1, lv1, nl, &rr, 1, &lsk, &lsv));
-        PFP_LAUNCH(c, K_COMPACT, nl * 28, (k_scatter_pairs<uint64_t>), nblocks(nl, BLOCK), (const uint64_t *)lsk, (const uint32_t *)lsv, (const uint32_t *)idx, nl, k1, v1);
-        PFP_LAUNCH(c, K_COMPACT, nl * 16, k_gather_jump, nblocks(nl, BLOCK), (const uint32_t *)lsv, (const uint32_t *)idx, nl, (const uint2 *)rj, onj);
+    unsigned long long kt;
+    (void)block_excl_sum(keepn, red, &kt);
+    if (threadIdx.x == 0) {
+        for (int t = 0; t < 3; ++t) { const uint32_t cnt = (uint32_t)(kt >> (20 * t)) & 0xFFFFFu; if (cnt) atomicAdd(&stripe_keep[blockIdx.x + t], cnt); }
+        atomicAdd(ndone, (unsigned long long)n);
     }
-    c->arena.release_hi(mk);
-    *sk = k1; *sv = v1; *snj = onj;
-    return PFP_OK;
 }
 
-// Sorts the N suffixes described by (keys,vals) [already filled: keys = h0-character prefixes, vals = x].
-// Outputs SA (slot -> x) and rank (x -> slot of its class head).  ws/wordid select dictionary semantics
-// (see k_ss_flag_active); D != nullptr additionally enables the run round (byte texts).
-// keys/vals and their twins k1/v1 (N entries each) are scratch owned by the caller.
-inline int suffix_sort_doubling(pfp_ctx *c, uint64_t N, uint64_t *k0, uint32_t *v0, uint64_t *k1, uint32_t *v1,
-                                const BitRange *init_ranges, int n_init_ranges, uint32_t h0,
-                                const uint32_t *ws, const uint32_t *wordid, const uint8_t *D, uint32_t *SA, uint2 *rj, int *rounds_out)
+// pairs of the ranges k_round left alone: keys for the global radix sort (idx = their positions in the active list)
+template <bool DICT> __global__ __launch_bounds__(BLOCK) void k_round_keys(const uint32_t *idx, uint64_t nl, const uint32_t *aslot, const uint32_t *arnk, const uint32_t *ajmp, uint64_t N,
+                                                                           const uint32_t *SA, const uint32_t *rank, const uint2 *rj, uint32_t h, const uint8_t *D, const uint32_t *M, int lowbits,
+                                                                           uint64_t *keys, uint32_t *vals, uint32_t *tnj)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= nl) return;
+    const uint32_t a = idx[i];
+    const uint32_t x = SA[aslot[a]];
+    uint32_t low, nx = 0;
+    if (!DICT) { const uint64_t y = (uint64_t)x + h; low = y < N ? rank[y] : 0u; }
+    else {
+        bool run = false;
+        if (M) {
+            const uint32_t ip = (uint32_t)(N - 1 - x);
+            const uint32_t d = ip - M[ip] + 1u;
+            if (d >= RUN_MIN && D[x] > EndOfWord) {
+                const uint64_t en = (uint64_t)x + d;
+                const uint8_t nxt = en < N ? D[en] : (uint8_t)0;
+                low = nxt < D[x] ? d : 0xFFFFFFFFu - d; nx = (uint32_t)(en < N ? en : N); run = true;
+            }
+        }
+        if (!run) { const uint32_t y = ajmp[a]; const uint2 Q = y < N ? rj[y] : make_uint2(0u, (uint32_t)N); low = Q.x; nx = Q.y; }
+        tnj[a] = nx;
+    }
+    keys[i] = ((uint64_t)arnk[a] << lowbits) | low; vals[i] = x;
+}
+// sorted[i] -> which entry of the unsorted subset it was is not known after a radix sort of (key, x) pairs; the new jump
+// of x is therefore parked in rj[x].y between the two (no k_round of this round reads rj any more)
+__global__ __launch_bounds__(BLOCK) void k_round_park_jumps(const uint32_t *idx, uint64_t nl, const uint32_t *aslot, const uint32_t *SA, const uint32_t *tnj, uint2 *rj)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= nl) return;
+    const uint32_t a = idx[i];
+    reinterpret_cast<uint32_t *>(rj)[2 * (uint64_t)SA[aslot[a]] + 1] = tnj[a];
+}
+__global__ __launch_bounds__(BLOCK) void k_round_subset_heads(const uint64_t *keys, uint64_t nl, uint32_t *headidx)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < nl) headidx[i] = (i == 0 || keys[i] != keys[i - 1]) ? (uint32_t)i : 0u;
+}
+// the sorted subset goes back to its positions (whole classes, in order): same outputs as k_round
+template <bool DICT> __global__ __launch_bounds__(BLOCK) void k_round_finish(const uint64_t *keys, const uint32_t *vals, const uint32_t *headidx /*max-scanned*/, const uint32_t *idx, uint64_t nl, uint64_t N,
+                                                                             const uint32_t *aslot, const uint32_t *arnk, uint32_t *SA, const uint2 *rj, const uint8_t *D,
+                                                                             uint32_t *newr, uint32_t *newj, uint8_t *flags, uint32_t *stripe_keep)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= nl) return;
+    const uint32_t a = idx[i], hi = headidx[i], x = vals[i];
+    const bool single = hi == (uint32_t)i && (i + 1 == nl || headidx[i + 1] == (uint32_t)(i + 1));
+    const uint32_t nr = aslot[idx[hi]];
+    bool keep = !single;
+    uint8_t fl = RF_DONE;
+    if (DICT) {
+        const uint32_t nj = rj[x].y;
+        newj[a] = nj;
+        keep = keep && !(nj >= N || D[nj - 1] == EndOfWord);
+        fl |= RF_CHANGED;
+    } else if (nr != arnk[a]) fl |= RF_CHANGED;
+    if (keep) fl |= RF_KEEP;
+    SA[aslot[a]] = x; newr[a] = nr; flags[a] = fl;
+    if (keep) atomicAdd(&stripe_keep[a / CS_STEP], 1u);
+}
+
+// second half of a round: ranks (and jumps) that changed go to rank[] / rj[] now, the pairs of classes that still have
+// to be refined move to the next active list -- stripe by stripe, at the offsets the scan of stripe_keep gave
+template <bool DICT> __global__ __launch_bounds__(BLOCK) void k_round_apply(const uint32_t *aslot, uint64_t na, const uint32_t *SA, const uint32_t *newr, const uint32_t *newj,
+                                                                            const uint8_t *flags, const uint32_t *stripe_base, uint32_t *rank, uint2 *rj,
+                                                                            uint32_t *oslot, uint32_t *ornk, uint32_t *ojmp)
+{
+    __shared__ uint32_t red[4];
+    const uint64_t s = (uint64_t)blockIdx.x * CS_STEP;
+    const uint64_t e = s + CS_STEP < na ? s + CS_STEP : na;
+    uint32_t outbase = stripe_base[blockIdx.x];
+    for (uint64_t a0 = s; a0 < e; a0 += BLOCK) {            // uniform trip count
+        const uint64_t a = a0 + threadIdx.x;
+        uint8_t fl = 0; uint32_t slot = 0, nr = 0, nj = 0;
+        if (a < e) {
+            fl = flags[a]; slot = aslot[a]; nr = newr[a];
+            if (DICT) nj = newj[a];
+            if (fl & RF_CHANGED) {
+                const uint32_t x = SA[slot];
+                if (DICT) rj[x] = make_uint2(nr, nj); else rank[x] = nr;
+            }
+        }
+        uint32_t tot;
+        const uint32_t ex = block_excl_sum((fl & RF_KEEP) ? 1u : 0u, red, &tot);
+        if (fl & RF_KEEP) { const uint32_t o = outbase + ex; oslot[o] = slot; ornk[o] = nr; if (DICT) ojmp[o] = nj; }
+        outbase += tot;
+    }
+}
+
+// ---- first state after the initial sort of all N suffixes ---------------------------------------------------------
+// keys / vals: sorted initial keys and their suffixes; rk[a] = head slot of a's class (max-scanned).  Writes rank[] /
+// rj[].x and keep[a] = the class of a has to be refined.  Dictionary: the initial jump sits in bits 56..60 of the key
+// (k_dict_init_keys) and the covered prefix holds the terminator exactly when the jump offset is below DK_CHARS or the
+// 16th character is the terminator -- no gathers.
+template <bool DICT> __global__ __launch_bounds__(BLOCK) void k_init_state(const uint64_t *keys, const uint32_t *vals, const uint32_t *head, const uint32_t *rk, uint64_t N, uint32_t *rank, uint2 *rj, uint32_t *keep)
+{
+    const uint64_t a = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (a >= N) return;
+    const uint32_t x = vals[a];
+    if (DICT) rj[x] = make_uint2(rk[a], x + (uint32_t)(keys[a] >> 56)); else rank[x] = rk[a];
+    const bool single = head[a] && (a + 1 == N || head[a + 1]);
+    bool fin = single;
+    if (DICT && !fin) fin = (keys[a] & ((1ULL << DK_KEY_BITS) - 1)) % 9u <= 1u;   // last base-9 digit: padding behind a terminator, or the terminator itself
+    keep[a] = fin ? 0u : 1u;
+}
+template <bool DICT> __global__ __launch_bounds__(BLOCK) void k_init_active(const uint64_t *keys, const uint32_t *vals, const uint32_t *rk, const uint32_t *keep, const uint32_t *pos, uint64_t N,
+                                                                            uint32_t *aslot, uint32_t *arnk, uint32_t *ajmp)
+{
+    const uint64_t a = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (a >= N || !keep[a]) return;
+    const uint32_t o = pos[a];
+    aslot[o] = (uint32_t)a; arnk[o] = rk[a];
+    if (DICT) ajmp[o] = vals[a] + (uint32_t)(keys[a] >> 56);
+}
+
+// Sorts the N suffixes described by (k0, v0) [keys = first characters, vals = x; dictionary keys carry the initial jump
+// offset in bits 56..60].  Outputs SA (slot -> x) and, per x, the slot of its class head: rank[x] (int alphabet,
+// DICT = false: symbols are compared one by one, the covered prefix after the initial sort is h0 symbols) or rj[x].x
+// (dictionary, DICT = true: suffixes end at their EndOfWord, byte-identical suffixes stay one class; D enables the run
+// round).  k0/v0 and their twins k1/v1 (N entries each) are scratch owned by the caller.
+template <bool DICT> inline int suffix_sort_doubling(pfp_ctx *c, uint64_t N, uint64_t *k0, uint32_t *v0, uint64_t *k1, uint32_t *v1,
+                                                    const BitRange *init_ranges, int n_init_ranges, uint32_t h0, const uint8_t *D, uint32_t *SA, uint32_t *rank, uint2 *rj, int *rounds_out)
 {
     const size_t mk = c->arena.mark_hi();
-    uint32_t *head, *aux, *slots, *slots2, *d_cnt, *nj, *onj = nullptr, *M = nullptr;
-    PFP_ALLOC_HI(c, head, uint32_t, N);
-    PFP_ALLOC_HI(c, aux, uint32_t, N);
-    PFP_ALLOC_HI(c, slots, uint32_t, N);
-    PFP_ALLOC_HI(c, slots2, uint32_t, N);
-    PFP_ALLOC_HI(c, d_cnt, uint32_t, 1);
+    uint32_t *head, *aux, *keep, *pos, *d_cnt;
+    PFP_ALLOC_HI(c, head, uint32_t, N); PFP_ALLOC_HI(c, aux, uint32_t, N); PFP_ALLOC_HI(c, keep, uint32_t, N); PFP_ALLOC_HI(c, pos, uint32_t, N);
+    PFP_ALLOC_HI(c, d_cnt, uint32_t, 4);
     uint64_t *sk; uint32_t *sv;
     PFP_TRY(radix_sort_pairs<uint64_t>(c, k0, v0, k1, v1, N, init_ranges, n_init_ranges, &sk, &sv));
     const unsigned gN = nblocks(N, BLOCK);
-    PFP_LAUNCH(c, K_SS_HEADS, N * 24, k_ss_heads, gN, (const uint64_t *)sk, (const uint32_t *)sv, (const uint32_t *)nullptr, N, SA, head, aux);
+    uint64_t keymask = 0; for (int r = 0; r < n_init_ranges; ++r) for (int b = init_ranges[r].lo; b < init_ranges[r].hi; ++b) keymask |= 1ULL << b;
+    PFP_LAUNCH(c, K_SS_HEADS, N * 24, k_ss_heads, gN, (const uint64_t *)sk, (const uint32_t *)sv, N, keymask, SA, head, aux);
     PFP_TRY((device_scan<uint32_t, 1>(c, aux, aux, N, nullptr)));
-    PFP_LAUNCH(c, K_SS_WRITE_RANK, N * 16, k_ss_init_rj, gN, (const uint32_t *)sv, (const uint32_t *)aux, N, h0, rj);
-    // first active list
-    uint32_t *keep = aux; // aux is free again after write_rank
-    PFP_LAUNCH(c, K_SS_FLAG_ACTIVE, N * 16, k_ss_flag_active, gN, (const uint32_t *)sv, (const uint32_t *)head, N, (const uint2 *)rj, (const uint32_t *)nullptr, ws ? (const uint64_t *)sk : (const uint64_t *)nullptr, ws, wordid, keep);
-    PFP_TRY(device_compact(c, nullptr, keep, N, slots, slots2, d_cnt));
+    PFP_LAUNCH(c, K_SS_WRITE_RANK, N * 24, (k_init_state<DICT>), gN, (const uint64_t *)sk, (const uint32_t *)sv, (const uint32_t *)head, (const uint32_t *)aux, N, rank, rj, keep);
+    PFP_TRY((device_scan<uint32_t, 0>(c, keep, pos, N, d_cnt)));
     uint32_t na = 0; PFP_TRY(d2h_u32(c, d_cnt, &na));
     int rounds = 1;
     const int rbits = bits_for(N);
+    static const bool verbose = getenv("PFP_VERBOSE") != nullptr;
     if (na > 0) {
-        PFP_ALLOC_HI(c, nj, uint32_t, na); PFP_ALLOC_HI(c, onj, uint32_t, na);
-        if (D) {   // run lengths for the run round
+        // active lists (two sets, swapped every round) and the per-round outputs; every later list is shorter than the first
+        uint32_t *aslot[2], *arnk[2], *ajmp[2] = {nullptr, nullptr}, *newr, *tnj = nullptr, *newj = nullptr, *M = nullptr, *stripe, *lidx; uint8_t *flags; unsigned long long *d_done;
+        for (int t = 0; t < 2; ++t) { PFP_ALLOC_HI(c, aslot[t], uint32_t, na); PFP_ALLOC_HI(c, arnk[t], uint32_t, na); if (DICT) PFP_ALLOC_HI(c, ajmp[t], uint32_t, na); }
+        PFP_ALLOC_HI(c, newr, uint32_t, na); PFP_ALLOC_HI(c, flags, uint8_t, na); PFP_ALLOC_HI(c, d_done, unsigned long long, 1);
+        if (DICT) { PFP_ALLOC_HI(c, tnj, uint32_t, na); PFP_ALLOC_HI(c, newj, uint32_t, na); }
+        const uint64_t max_stripes = nblocks(na, CS_STEP) + 1;
+        PFP_ALLOC_HI(c, stripe, uint32_t, max_stripes + 4);
+        PFP_ALLOC_HI(c, lidx, uint32_t, na);
+        PFP_LAUNCH(c, K_COMPACT, N * 24, (k_init_active<DICT>), gN, (const uint64_t *)sk, (const uint32_t *)sv, (const uint32_t *)aux, (const uint32_t *)keep, (const uint32_t *)pos, N, aslot[0], arnk[0], ajmp[0]);
+        if (DICT && D) {   // run lengths for the run round
             PFP_ALLOC_HI(c, M, uint32_t, N);
             PFP_LAUNCH(c, K_SS_MAKE_KEYS, N * 5, k_ss_runend_marks, gN, D, N, M);
             PFP_TRY((device_scan<uint32_t, 1>(c, M, M, N, nullptr)));
         }
-    }
-    static const bool verbose = getenv("PFP_VERBOSE") != nullptr;
-    while (na > 0) {
-        if (verbose) fprintf(stderr, "[pfbwt_hip] suffix sort N=%llu round %d: %u active\n", (unsigned long long)N, rounds, na);
-        if (rounds > 64) return PFP_E_CORRUPT; // cannot happen on well-formed input
-        const unsigned ga = nblocks(na, BLOCK);
-        const bool run_round = (M != nullptr && rounds == 1);
-        // build keys for the active list into k0/v0 (previous contents are dead: SA/rank/jump hold the state)
-        PFP_LAUNCH(c, K_SS_MAKE_KEYS, (uint64_t)na * 36, k_ss_make_keys, ga, (const uint32_t *)slots, (const uint32_t *)SA, (const uint2 *)rj, (uint64_t)na, N,
-                   run_round ? D : (const uint8_t *)nullptr, run_round ? (const uint32_t *)M : (const uint32_t *)nullptr, run_round ? 32 : rbits, k0, v0, nj);
-        uint32_t *snj = nullptr;
-        PFP_TRY(class_segment_sort(c, k0, v0, nj, k1, v1, onj, na, run_round ? 32 : rbits, rbits, rj, &sk, &sv, &snj));
-        PFP_LAUNCH(c, K_SS_HEADS, (uint64_t)na * 28, k_ss_heads, ga, (const uint64_t *)sk, (const uint32_t *)sv, (const uint32_t *)slots, (uint64_t)na, SA, head, aux);
-        PFP_TRY((device_scan<uint32_t, 1>(c, aux, aux, na, nullptr)));
-        if (snj) PFP_LAUNCH(c, K_SS_WRITE_RANK, (uint64_t)na * 20, k_ss_write_rank_jump, ga, (const uint32_t *)sv, (const uint32_t *)aux, (const uint32_t *)snj, (uint64_t)na, rj);
-        else PFP_LAUNCH(c, K_SS_WRITE_RANK, (uint64_t)na * 12, k_ss_write_rank, ga, (const uint32_t *)sv, (const uint32_t *)aux, (uint64_t)na, rj);
-        ++rounds;
-        PFP_LAUNCH(c, K_SS_FLAG_ACTIVE, (uint64_t)na * 16, k_ss_flag_active, ga, (const uint32_t *)sv, (const uint32_t *)head, (uint64_t)na, (const uint2 *)rj, (const uint32_t *)snj, (const uint64_t *)nullptr, ws, wordid, keep);
-        PFP_TRY(device_compact(c, slots, keep, na, slots2, head /*pos scratch*/, d_cnt));
-        uint32_t *t = slots; slots = slots2; slots2 = t;
-        PFP_TRY(d2h_u32(c, d_cnt, &na));
+        static const uint32_t max_range = getenv("PFP_CLASS_SORT_MAXRANGE") ? (uint32_t)atoi(getenv("PFP_CLASS_SORT_MAXRANGE")) : (uint32_t)RS_TILE;   // tests: smaller, to reach the large-class route
+        int cur = 0; uint64_t h = h0;
+        // k0 / v0 / k1 / v1 are free from here on: scratch of the large-class route
+        while (na > 0) {
+            if (verbose) fprintf(stderr, "[pfbwt_hip] suffix sort N=%llu round %d: %u active\n", (unsigned long long)N, rounds, na);
+            if (rounds > 64) return PFP_E_CORRUPT; // cannot happen on well-formed input
+            const bool run_round = (M != nullptr && rounds == 1);
+            const int lowbits = run_round ? 32 : rbits;
+            const unsigned gs = nblocks(na, CS_STEP);
+            PFP_HIP(c, hipMemsetAsync(flags, 0, na, c->stream));
+            PFP_HIP(c, hipMemsetAsync(stripe, 0, ((size_t)gs + 3) * 4, c->stream));
+            PFP_HIP(c, hipMemsetAsync(d_done, 0, 8, c->stream));
+            PFP_LAUNCH(c, K_CLASS_SORT, (uint64_t)na * (DICT ? 64 : 48), (k_round<DICT>), gs, (const uint32_t *)aslot[cur], (const uint32_t *)arnk[cur], (const uint32_t *)ajmp[cur], (uint64_t)na, N, SA,
+                       (const uint32_t *)rank, (const uint2 *)rj, (uint32_t)(h < N ? h : N), D, run_round ? (const uint32_t *)M : (const uint32_t *)nullptr, lowbits, max_range, newr, tnj, newj, flags, stripe, d_done);
+            unsigned long long nd = 0;
+            PFP_HIP(c, hipMemcpyAsync(&nd, d_done, 8, hipMemcpyDeviceToHost, c->stream));
+            PFP_HIP(c, hipStreamSynchronize(c->stream));
+            const uint64_t nl = na - nd;
+            if (nl) {   // classes too large for a tile: collect their pairs, sort them globally, put them back
+                if (verbose) fprintf(stderr, "[pfbwt_hip]   class sort: %u pairs, %llu in classes too large for one tile\n", na, (unsigned long long)nl);
+                const unsigned ga = nblocks(na, BLOCK), gl = nblocks(nl, BLOCK);
+                PFP_LAUNCH(c, K_COMPACT, (uint64_t)na * 5, k_not_done, ga, (const uint8_t *)flags, (uint64_t)na, keep);
+                PFP_TRY(device_compact(c, nullptr, keep, na, lidx, pos, d_cnt));
+                PFP_LAUNCH(c, K_SS_MAKE_KEYS, nl * 48, (k_round_keys<DICT>), gl, (const uint32_t *)lidx, nl, (const uint32_t *)aslot[cur], (const uint32_t *)arnk[cur], (const uint32_t *)ajmp[cur], N, (const uint32_t *)SA,
+                           (const uint32_t *)rank, (const uint2 *)rj, (uint32_t)(h < N ? h : N), D, run_round ? (const uint32_t *)M : (const uint32_t *)nullptr, lowbits, k0, v0, tnj);
+                if (DICT) PFP_LAUNCH(c, K_SS_MAKE_KEYS, nl * 20, k_round_park_jumps, gl, (const uint32_t *)lidx, nl, (const uint32_t *)aslot[cur], (const uint32_t *)SA, (const uint32_t *)tnj, rj);
+                BitRange rr = {0, lowbits + rbits};
+                uint64_t *lsk; uint32_t *lsv;
+                PFP_TRY(radix_sort_pairs<uint64_t>(c, k0, v0, k1, v1, nl, &rr, 1, &lsk, &lsv));
+                PFP_LAUNCH(c, K_SS_HEADS, nl * 12, k_round_subset_heads, gl, (const uint64_t *)lsk, nl, head);
+                PFP_TRY((device_scan<uint32_t, 1>(c, head, head, nl, nullptr)));
+                PFP_LAUNCH(c, K_SS_WRITE_RANK, nl * 40, (k_round_finish<DICT>), gl, (const uint64_t *)lsk, (const uint32_t *)lsv, (const uint32_t *)head, (const uint32_t *)lidx, nl, N, (const uint32_t *)aslot[cur],
+                           (const uint32_t *)arnk[cur], SA, (const uint2 *)rj, D, newr, newj, flags, stripe);
+            }
+            PFP_TRY((device_scan<uint32_t, 0>(c, stripe, stripe, (uint64_t)gs, d_cnt)));
+            PFP_LAUNCH(c, K_SS_WRITE_RANK, (uint64_t)na * 30, (k_round_apply<DICT>), gs, (const uint32_t *)aslot[cur], (uint64_t)na, (const uint32_t *)SA, (const uint32_t *)newr, (const uint32_t *)newj,
+                       (const uint8_t *)flags, (const uint32_t *)stripe, rank, rj, aslot[cur ^ 1], arnk[cur ^ 1], ajmp[cur ^ 1]);
+            PFP_TRY(d2h_u32(c, d_cnt, &na));
+            cur ^= 1; ++rounds; h *= 2;
+        }
     }
     if (rounds_out) *rounds_out = rounds;
     c->arena.release_hi(mk);
