@@ -108,6 +108,7 @@ struct pfp_ctx {
     //     k + 1 overlaps the DMA of chunk k (pinned sources are copied directly)
     uint8_t *hstage[2] = {nullptr, nullptr}; hipEvent_t hstage_ev[2] = {nullptr, nullptr}; bool hstage_used[2] = {false, false};
     uint64_t hash_seed = 0x9E3779B97F4A7C15ULL;
+    uint32_t *d_trigtab = nullptr;      // w <= 10: one bit per k-mer, "wang_hash(kmer) % p == 0" (128 KiB for w = 10; lives in LDS during the trigger scan)
 };
 
 namespace pfp {
@@ -151,6 +152,17 @@ struct ProfScope {
         pfp::ProfScope ps_((ctx), (id), (double)(bytes));                                         \
         hipLaunchKernelGGL(kernel, dim3((unsigned)(grid)), dim3(pfp::BLOCK), 0, (ctx)->stream, __VA_ARGS__); \
         hipError_t le_ = hipGetLastError();            /* a rejected launch (grid, LDS size) must not pass as stale output */ \
+        if (le_ != hipSuccess) { (ctx)->hip_err = (int)le_; (ctx)->err_ch = (int)le_;                 \
+            fprintf(stderr, "[pfbwt_hip] launch of %s failed: %s (%s:%d)\n", #kernel, hipGetErrorString(le_), __FILE__, __LINE__); \
+            return PFP_E_HIP; }                                                                       \
+    } while (0)
+
+// the same with an explicit workgroup size
+#define PFP_LAUNCH_B(ctx, id, bytes, kernel, grid, block, ...)                                    \
+    do {                                                                                          \
+        pfp::ProfScope ps_((ctx), (id), (double)(bytes));                                         \
+        hipLaunchKernelGGL(kernel, dim3((unsigned)(grid)), dim3((unsigned)(block)), 0, (ctx)->stream, __VA_ARGS__); \
+        hipError_t le_ = hipGetLastError();                                                       \
         if (le_ != hipSuccess) { (ctx)->hip_err = (int)le_; (ctx)->err_ch = (int)le_;                 \
             fprintf(stderr, "[pfbwt_hip] launch of %s failed: %s (%s:%d)\n", #kernel, hipGetErrorString(le_), __FILE__, __LINE__); \
             return PFP_E_HIP; }                                                                       \

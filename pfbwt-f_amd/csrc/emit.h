@@ -16,17 +16,27 @@
 namespace pfp {
 
 // pfparser.hpp:430-451.  SAP = suffix array of ranks+[0] (m+1 entries), P = 1-based ranks, sai = ye.
-__global__ __launch_bounds__(BLOCK) void k_pbwt_rows(const uint32_t *SAP, const uint32_t *P, const uint8_t *last, const tpos_t *sai, uint64_t m,
-                                                     uint8_t *bwlast, tpos_t *bwsai, uint32_t *W, uint32_t *rowid)
+// Row i with s = SAP[i] needs last[s-2], sai[s-1] and P[s-1]: three random reads of three arrays.  They are packed first
+// (streaming) into ONE 16-byte record per phrase, rec[j] = { sai[j], P[j], last[j-1] (last[m-1] for j = 0) }, so that a
+// row costs one random 16-byte gather (r01: 69-132 GB of HBM traffic per launch for 7.8 GB of algorithmic bytes).
+__global__ __launch_bounds__(BLOCK) void k_pbwt_pack(const uint32_t *P, const uint8_t *last, const tpos_t *sai, uint64_t m, uint4 *rec)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (j >= m) return;
+    const uint64_t v = sai ? (uint64_t)sai[j] : 0ULL;
+    rec[j] = make_uint4((uint32_t)v, (uint32_t)(v >> 32), P[j], (uint32_t)last[j ? j - 1 : m - 1]);
+}
+__global__ __launch_bounds__(BLOCK) void k_pbwt_rows(const uint32_t *SAP, const uint4 *rec, uint64_t m, uint8_t *bwlast, tpos_t *bwsai, uint32_t *W, uint32_t *rowid)
 {
     const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i > m) return;
     const uint32_t s = SAP[i];
     rowid[i] = (uint32_t)i;
     if (s == 0) { bwlast[i] = 0; if (bwsai) bwsai[i] = 0; W[i] = 0; return; }
-    bwlast[i] = (s == 1) ? last[m - 1] : last[s - 2];
-    if (bwsai) bwsai[i] = sai[s - 1];
-    W[i] = P[s - 1];
+    const uint4 R = rec[s - 1];
+    bwlast[i] = (uint8_t)R.w;                                   // last[s - 2], last[m - 1] when s == 1 (:443-449)
+    if (bwsai) bwsai[i] = (tpos_t)(((uint64_t)R.y << 32) | R.x);
+    W[i] = R.z;
 }
 
 __global__ __launch_bounds__(BLOCK) void k_u32_add_store(const uint32_t *in, uint64_t n, uint32_t add, uint32_t *out)

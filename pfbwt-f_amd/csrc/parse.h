@@ -56,21 +56,52 @@ __device__ __forceinline__ uint32_t ntoa_code(uint32_t c)
     return (c == 'A' || c == 'N') ? 0u : (c == 'C') ? 1u : (c == 'G') ? 2u : (c == 'T' || c == '-') ? 3u : 5u;
 }
 
+// 8-entry byte table looked up for four bytes at once: byte i of the result = byte (sel.byte[i] & 7) of {hi, lo} (v_perm_b32)
+__device__ __forceinline__ uint32_t lut8x4(uint32_t hi, uint32_t lo, uint32_t sel)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm(hi, lo, sel);
+#else
+    const uint64_t tbl = ((uint64_t)hi << 32) | lo; uint32_t r = 0;
+    for (int i = 0; i < 4; ++i) r |= (uint32_t)((tbl >> (8 * ((sel >> (8 * i)) & 7))) & 0xff) << (8 * i);
+    return r;
+#endif
+}
+// Four bases at once (norm_base + ntoa_code of every byte, 4-way SWAR; ~9 instead of ~35 instructions per base -- the
+// scan was bound by this, not by the hash).  (c >> 1) & 7 is a perfect hash of the valid symbols, either case:
+// A 0, C 1, T 2, G 3, '-' 6, N 7.  Returns the four 2-bit codes (first base in bits 7..6), *bad = invalid bytes (bit b =
+// byte b), *out = normalised bytes.
+__device__ __forceinline__ uint32_t pack4(uint32_t x, bool ntoa, uint32_t *bad, uint32_t *out)
+{
+    const uint32_t h4 = (x >> 1) & 0x07070707u;
+    const uint32_t exp4 = lut8x4(0x4E2D0000u, 0x47544341u, h4);            // the upper-case symbol with that hash (0: none)
+    const uint32_t L = (exp4 & 0x40404040u) >> 1;                            // 0x20 where a letter is expected: lower case is accepted
+    const uint32_t allowed = (x ^ exp4) & ~L;
+    uint32_t nz = (((allowed & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | allowed) & 0x80808080u;   // 0x80 in every byte that is not a valid symbol
+    uint32_t c4 = lut8x4(0x00030000u, 0x02030100u, h4);                    // seq_nt4_ntoa_table: A,N 0  C 1  G 2  T,'-' 3
+    if (ntoa) {   // pfparser.hpp:342-344: everything that is not ACGT (N and '-' too) becomes 'A'; nothing is invalid
+        nz |= (h4 & 0x04040404u) << 5;
+        const uint32_t m = (nz >> 7) * 0xFFu;
+        *out = (exp4 & ~m) | (0x41414141u & m); c4 &= ~m; *bad = 0;
+    } else {
+        const uint32_t m = (nz >> 7) * 0xFFu;
+        const uint32_t t = x & 0x7F7F7F7Fu;
+        const uint32_t lower = (t + 0x1F1F1F1Fu) & ~(t + 0x05050505u) & ~x & 0x80808080u;   // bytes in 'a'..'z'
+        *out = (exp4 & ~m) | ((x ^ (lower >> 2)) & m);                      // invalid bytes: toupper only (pfparser.hpp:337), code 0
+        c4 &= ~m;
+        *bad = (((nz >> 7) * 0x01020408u) >> 24) & 0xFu;
+    }
+    return (c4 * 0x40100401u) >> 24;
+}
 __device__ __forceinline__ uint32_t pack16(const uint4 &q, bool ntoa, uint32_t *bad /*bitmask of invalid bytes*/, uint4 *normed)
 {
-    uint32_t wds[4] = {q.x, q.y, q.z, q.w}, out[4], pk = 0, badm = 0;
+    const uint32_t wds[4] = {q.x, q.y, q.z, q.w};
+    uint32_t out[4], pk = 0, badm = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        uint32_t o = 0;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            uint32_t c = norm_base((wds[i] >> (8 * b)) & 0xff, ntoa);
-            uint32_t code = ntoa_code(c);
-            if (code > 3) { badm |= 1u << (i * 4 + b); code = 0; }
-            pk = (pk << 2) | code;
-            o |= c << (8 * b);
-        }
-        out[i] = o;
+        uint32_t b4;
+        pk = (pk << 8) | pack4(wds[i], ntoa, &b4, &out[i]);
+        badm |= b4 << (4 * i);
     }
     *bad = badm;
     if (normed) *normed = make_uint4(out[0], out[1], out[2], out[3]);
@@ -146,6 +177,90 @@ __global__ __launch_bounds__(BLOCK) void k_trigger_scan(uint8_t *X, uint64_t n, 
     uint32_t tot;
     (void)block_excl_sum((uint32_t)__popc(trig), red, &tot);
     if (threadIdx.x == 0) blockcnt[blockIdx.x] = tot;   // 64-bit: the scan over workgroups yields phrase indices
+}
+
+// ---- the same scan for w <= 10 (the reference's default and the only value its pipeline driver uses, vcf_to_bwt.py:118-129):
+// the k-mer has at most 20 bits, so "wang_hash(kmer) % p == 0" (hash.hpp:12-21 + pfparser.hpp:347) is precomputed for all
+// 4^w k-mers into a bit table of <= 128 KiB that sits in LDS for the whole scan; a base then costs one LDS read instead of
+// ~60 64-bit integer operations (the hash made the scan VALU-bound: 74 ms of 32 Gbase).  One workgroup of 1024 threads per
+// CU (the table takes 128 of the 160 KiB of LDS), each walks `tiles_per_wg` tiles of 16 Kbase.  The normalised bytes are
+// written back only where they differ from the input (upper-case ACGT input: no stores at all).
+constexpr int TS_THREADS = 1024;
+constexpr int TS_MAX_W = 10;
+constexpr uint32_t TS_TAB_WORDS = 1u << (2 * TS_MAX_W - 5);
+__global__ __launch_bounds__(BLOCK) void k_trigger_table(int w, DivTest p, uint32_t *tab)
+{
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;           // one 32-bit word of the table = 32 k-mers
+    const uint32_t words = (1u << (2 * w)) >= 32u ? (1u << (2 * w)) / 32u : 1u;
+    if (i >= words) return;
+    uint32_t m = 0;
+    for (uint32_t b = 0; b < 32; ++b) { const uint64_t km = (uint64_t)i * 32 + b; if (km < (1ULL << (2 * w)) && divisible(wang_hash(km), p)) m |= 1u << b; }
+    tab[i] = m;
+}
+__global__ __launch_bounds__(TS_THREADS) void k_trigger_scan_tab(uint8_t *X, uint64_t n, int w, const uint32_t *tab, uint32_t tabwords, uint32_t kmask, int ntoa, uint32_t tiles_per_wg,
+                                                                   uint64_t nthreads_total, uint16_t *mask16, uint64_t *blockcnt /*zeroed*/, unsigned long long *err_pos)
+{
+    __shared__ uint32_t stab[TS_TAB_WORDS];
+    __shared__ uint32_t pk[2][TS_THREADS + 2];                     // packed bases of the tile, [0..1] = the 32 bases in front; two tiles alternate
+    for (uint32_t i = threadIdx.x; i < tabwords; i += TS_THREADS) stab[i] = tab[i];
+    const int lane = threadIdx.x & 63;
+    const uint64_t tile0 = (uint64_t)blockIdx.x * tiles_per_wg;
+    // software pipeline: the 16 bytes of tile k + 1 are requested before tile k is processed (one workgroup per CU runs
+    // its waves in step -- nothing else would hide the load latency)
+    uint4 qn = make_uint4(0, 0, 0, 0);
+    if ((tile0 * TS_THREADS + threadIdx.x) * 16 < n) qn = *reinterpret_cast<const uint4 *>(X + (tile0 * TS_THREADS + threadIdx.x) * 16);
+    for (uint32_t tl = 0; tl < tiles_per_wg; ++tl) {
+        const uint64_t first = (tile0 + tl) * TS_THREADS;          // in units of 16 bases
+        if (first >= nthreads_total) break;                        // uniform
+        const uint64_t t = first + threadIdx.x;
+        const uint64_t base = t * 16;
+        const uint4 q = qn;
+        if (tl + 1 < tiles_per_wg && base + (uint64_t)TS_THREADS * 16 < n) qn = *reinterpret_cast<const uint4 *>(X + base + (uint64_t)TS_THREADS * 16); else qn = make_uint4(0, 0, 0, 0);
+        uint4 nq; uint32_t bad = 0;
+        const uint32_t mine = pack16(q, ntoa != 0, &bad, &nq);
+        if (base < n) {
+            const uint32_t live = (n - base >= 16) ? 0xffffu : ((1u << (unsigned)(n - base)) - 1u);
+            if (live != 0xffffu) { // keep bytes beyond n untouched
+                uint32_t a[4] = {q.x, q.y, q.z, q.w}, b[4] = {nq.x, nq.y, nq.z, nq.w};
+                for (int i = 0; i < 16; ++i) if (!((live >> i) & 1)) { b[i >> 2] = (b[i >> 2] & ~(0xffu << (8 * (i & 3)))) | (a[i >> 2] & (0xffu << (8 * (i & 3)))); }
+                nq = make_uint4(b[0], b[1], b[2], b[3]);
+            }
+            if (nq.x != q.x || nq.y != q.y || nq.z != q.z || nq.w != q.w) *reinterpret_cast<uint4 *>(X + base) = nq;
+            bad &= live;
+            if (bad) atomicMin(err_pos, (unsigned long long)(base + (uint64_t)(__ffs((int)bad) - 1)));
+        }
+        uint32_t *cur = pk[tl & 1];
+        const uint32_t *oth = pk[(tl & 1) ^ 1];
+        cur[threadIdx.x + 2] = mine;
+        if (threadIdx.x < 2) { // halo: the 32 bases in front of the tile -- the tail of the previous tile of this workgroup, or from memory
+            uint32_t hv = 0;
+            if (tl) hv = oth[TS_THREADS + threadIdx.x];
+            else if (first + threadIdx.x >= 2) {
+                uint32_t hb;
+                uint4 hq = *reinterpret_cast<const uint4 *>(X + (first + threadIdx.x - 2) * 16);
+                hv = pack16(hq, ntoa != 0, &hb, nullptr);
+            }
+            cur[threadIdx.x] = hv;
+        }
+        __syncthreads();       // the one barrier per tile (tile k + 2 reuses this buffer only after every wave has passed the barrier of tile k + 1)
+        uint32_t kmer = cur[threadIdx.x + 1];                      // the 16 bases in front: enough for w <= 10
+        uint32_t trig = 0;
+#pragma unroll
+        for (int b = 0; b < 16; ++b) {
+            kmer = (kmer << 2) | ((mine >> (30 - 2 * b)) & 3u);   // hash.hpp:32
+            const uint32_t km = kmer & kmask;
+            trig |= ((stab[km >> 5] >> (km & 31u)) & 1u) << b;
+        }
+        // pfparser.hpp:347: pos_ > w  <=>  pos >= w; nothing at or behind n
+        if (base < (uint64_t)w) trig &= ~((1u << (unsigned)((uint64_t)w - base > 16 ? 16 : (uint64_t)w - base)) - 1u);
+        if (base >= n) trig = 0; else if (n - base < 16) trig &= (1u << (unsigned)(n - base)) - 1u;
+        if (t < nthreads_total) mask16[t] = (uint16_t)trig;
+        // trigger count of every group of 256 threads (the unit k_phrase_ends works in): one atomic per wave
+        uint32_t cnt = (uint32_t)__popc(trig);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
+        if (lane == 0 && cnt && t < nthreads_total) atomicAdd(reinterpret_cast<unsigned long long *>(&blockcnt[t / BLOCK]), (unsigned long long)cnt);
+    }
 }
 
 // ye[j] = (trigger position e_j) + 1 for every trigger, in text order

@@ -110,6 +110,7 @@ void pfp_destroy(pfp_ctx *c)
     prof_collect(c);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->tb) (void)hipFree(c->tb);
+    if (c->d_trigtab) (void)hipFree(c->d_trigtab);
     for (int k = 0; k < 2; ++k) { if (c->hstage[k]) (void)hipHostFree(c->hstage[k]); if (c->hstage_ev[k]) (void)hipEventDestroy(c->hstage_ev[k]); }
     if (c->arena.base) (void)hipFree(c->arena.base);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -461,6 +462,20 @@ static int parse_finalize_impl(pfp_ctx *c, pfp_parse_sizes *out)
     PFP_HIP(c, hipMemsetAsync(d_err, 0xff, 8, c->stream));
     PFP_HIP(c, hipMemsetAsync(d_u32, 0, 32, c->stream));
     const uint64_t kmask = (w == 32) ? 0ULL : ((1ULL << (2 * w)) - 1ULL);   // hash.hpp:26 (w == 32: observed x86 value)
+    static const bool no_trigtab = getenv("PFP_NO_TRIGGER_TABLE") != nullptr;      // tests / measurements: the hash evaluated per base
+    if (w <= TS_MAX_W && !no_trigtab) {
+        const uint32_t tabwords = (1u << (2 * w)) >= 32u ? (1u << (2 * w)) / 32u : 1u;
+        if (!c->d_trigtab) {      // w and p are fixed for the life of a context
+            PFP_HIP(c, hipMalloc((void **)&c->d_trigtab, (size_t)TS_TAB_WORDS * 4));
+            PFP_LAUNCH(c, K_MISC, tabwords * 4, k_trigger_table, nblocks(tabwords, BLOCK), w, make_divtest(c->p), c->d_trigtab);
+        }
+        const uint64_t nthreads_total = (uint64_t)gts * BLOCK;
+        const uint64_t tiles = (nthreads_total + TS_THREADS - 1) / TS_THREADS;
+        uint32_t tpw = (uint32_t)(tiles / 1024); if (tpw < 1) tpw = 1; if (tpw > 64) tpw = 64;      // enough workgroups to fill 256 CUs, the table load amortised
+        PFP_HIP(c, hipMemsetAsync(blockcnt, 0, ((size_t)gts + 1) * 8, c->stream));
+        PFP_LAUNCH_B(c, K_TRIGGER_SCAN, n + n / 8, k_trigger_scan_tab, (tiles + tpw - 1) / tpw, TS_THREADS, X, n, w, (const uint32_t *)c->d_trigtab, tabwords, (uint32_t)kmask,
+                     (int)((c->flags & PFP_FLAG_NON_ACGT_TO_A) != 0), tpw, nthreads_total, mask16, blockcnt, d_err);
+    } else
     PFP_LAUNCH(c, K_TRIGGER_SCAN, n * 2 + n / 8, k_trigger_scan, gts, X, n, w, make_divtest(c->p), kmask, (int)((c->flags & PFP_FLAG_NON_ACGT_TO_A) != 0), mask16, blockcnt, d_err);
     PFP_TRY((device_scan<uint64_t, 0>(c, blockcnt, blockcnt, gts, blockcnt + gts)));
     uint64_t ntrig = 0; unsigned long long herr = 0;
@@ -733,8 +748,11 @@ static int parse_bwt_impl(pfp_ctx *c)
     PFP_ALLOC_HI(c, W2, uint32_t, N); PFP_ALLOC_HI(c, rowid2, uint32_t, N);
     int rounds = 0;
     PFP_TRY(sort_int_suffixes(c, c->d_parse, N, c->dwords, SAP, rk, &rounds));   // sacak_int, :425
-    PFP_LAUNCH(c, K_PBWT_ROWS, N * 24, k_pbwt_rows, nblocks(N, BLOCK), (const uint32_t *)SAP, (const uint32_t *)c->d_parse, (const uint8_t *)c->d_last,
-               (const tpos_t *)c->d_ye, m, c->d_bwlast, c->d_bwsai, W, rowid);
+    {
+        uint4 *rec; PFP_ALLOC_HI(c, rec, uint4, m);
+        PFP_LAUNCH(c, K_PBWT_ROWS, m * 29, k_pbwt_pack, nblocks(m, BLOCK), (const uint32_t *)c->d_parse, (const uint8_t *)c->d_last, sai ? (const tpos_t *)c->d_ye : (const tpos_t *)nullptr, m, rec);
+        PFP_LAUNCH(c, K_PBWT_ROWS, N * (4 + 16 + 17), k_pbwt_rows, nblocks(N, BLOCK), (const uint32_t *)SAP, (const uint4 *)rec, m, c->d_bwlast, c->d_bwsai, W, rowid);
+    }
     // ilist: rows grouped by word, ascending inside a word (:452-462) = stable sort of row ids by word
     BitRange wr = {0, bits_for(c->dwords)};
     uint32_t *sw, *sr;
