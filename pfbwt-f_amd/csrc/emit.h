@@ -688,14 +688,6 @@ __global__ __launch_bounds__(BLOCK) void k_run_count(const uint8_t *bwt, uint64_
     (void)block_excl_sum(cntr, red, &tot);
     if (threadIdx.x == 0 && tot) atomicAdd(runs, (unsigned long long)tot);
 }
-// SA value of an output row from its parse-BWT row (samples-only mode: the bwsai gather and the
-// subtraction of the suffix length, pfbwt.hpp:87-89, are done for the 2r sampled rows only).  All members of a group of
-// equal suffixes have the same suffix length, so any slot whose row range covers the output row gives it.
-template <typename SAT, typename EBT> __device__ __forceinline__ SAT sa_of_row(const EmitArgs &a, uint32_t q, uint64_t o)
-{
-    if (o == 0) return (SAT)a.n;                                     // src/pfbwt-f.cpp:301
-    return (SAT)((SAT)a.bwsai[q] - (SAT)a.s_sl[slot_of_row<EBT>(a, o)]);
-}
 // Run starts of a window, 16 rows per thread: bit k of the result <=> row j0 + k (< rows) differs from the row in front
 // of it (pbwtc starts at 0, src/pfbwt-f.cpp:304).  Reads up to 15 bytes past the window (the BWT buffer is padded).
 constexpr int RUN_PER_THREAD = 16, RUN_TILE = BLOCK * RUN_PER_THREAD;
@@ -711,47 +703,56 @@ __device__ __forceinline__ uint32_t run_mask16(const uint8_t *bwt, uint64_t j0, 
     const uint64_t left = rows - j0;
     return left >= 16 ? m : (m & ((1u << left) - 1u));
 }
-__global__ __launch_bounds__(BLOCK) void k_run_tile_count(const uint8_t *bwt, uint64_t rows, int has_prev, uint32_t *tilecnt)
+// run starts per tile; rmask (nullable) keeps every thread's 16-bit mask so that the sampling pass below does not read the
+// BWT bytes again
+__global__ __launch_bounds__(BLOCK) void k_run_tile_count(const uint8_t *bwt, uint64_t rows, int has_prev, uint32_t *tilecnt, uint16_t *rmask)
 {
     __shared__ uint32_t red[4];
-    const uint64_t j0 = ((uint64_t)blockIdx.x * BLOCK + threadIdx.x) * RUN_PER_THREAD;
+    const uint64_t g = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t m = run_mask16(bwt, g * RUN_PER_THREAD, rows, has_prev);
+    if (rmask) rmask[g] = (uint16_t)m;
     uint32_t tot;
-    (void)block_excl_sum((uint32_t)__popc(run_mask16(bwt, j0, rows, has_prev)), red, &tot);
+    (void)block_excl_sum((uint32_t)__popc(m), red, &tot);
     if (threadIdx.x == 0) tilecnt[blockIdx.x] = tot;
 }
-// .ssa / .esa pairs, src/pfbwt-f.cpp:306-315 and :325-328, for a window of rows: row index = row_base + j, run index =
-// run_base + tilebase[tile] + rank inside the tile; total_rows / total_runs_plus1 - 1 describe the whole output.  The SA value of
-// row j is sa[j] (sa[-1] valid when has_prev) or, in samples-only mode (sa == nullptr), computed from qrow[j].
-template <typename SAT, typename EBT> __global__ __launch_bounds__(BLOCK) void k_samples_tile(EmitArgs a, const uint8_t *bwt, uint64_t rows, int has_prev, const uint32_t *tilebase, const SAT *sa, const uint32_t *qrow,
-                                                                                              uint64_t row_base, uint64_t run_base, uint64_t total_rows, uint64_t total_runs_plus1 /*0: this window does not hold the last row*/, SAT *ssa, SAT *esa)
+// .ssa / .esa, src/pfbwt-f.cpp:306-315 and :325-328, for a window of rows, in two steps.  Step 1: the ROWS of the pairs --
+// row index = row_base + j, run index = run_base + tilebase[tile] + rank inside the tile; the run start at row o > 0 also
+// ends the previous run at row o - 1; total_rows / total_runs_plus1 - 1 describe the whole output (the last row ends the
+// last run; index -1 when no run starts in this slice: esa then points one pair past the slice's first entry).
+template <typename SAT> __global__ __launch_bounds__(BLOCK) void k_sample_rows(const uint16_t *rmask, uint64_t rows, const uint32_t *tilebase, uint64_t row_base, uint64_t run_base, uint64_t total_rows,
+                                                                               uint64_t total_runs_plus1 /*0: this window does not hold the last row*/, SAT *ssa, SAT *esa)
 {
     __shared__ uint32_t red[4];
-    __shared__ uint32_t ebl[EMIT_LDS_SLOTS];     // samples-only mode: EB of the slots under this tile's rows, relative to the first
-    __shared__ uint32_t rng[2];
-    const EBT *EB = reinterpret_cast<const EBT *>(a.EB);
-    bool in_lds = false; uint32_t i0 = 0, ns = 0; uint64_t ebase = 0;
-    if (!sa) {   // the slot of a sampled row gives its suffix length: search the tile's slice of EB in LDS, not all of EB
-        const uint64_t b0 = (uint64_t)blockIdx.x * RUN_TILE;
-        const uint64_t first = row_base + b0 - ((row_base + b0) ? 1 : 0);      // includes the row in front of the tile
-        const uint64_t last = row_base + (b0 + RUN_TILE < rows ? b0 + RUN_TILE : rows) - 1;
-        if (threadIdx.x < 2) rng[threadIdx.x] = slot_of_row<EBT>(a, threadIdx.x == 0 ? first : last);
-        __syncthreads();
-        i0 = rng[0]; ns = rng[1] - i0 + 1u; ebase = (uint64_t)EB[i0];
-        in_lds = ns <= (uint32_t)EMIT_LDS_SLOTS && last + 1 - ebase < 0xFFFFFFFFULL;
-        if (in_lds) for (uint32_t t = threadIdx.x; t < ns; t += BLOCK) ebl[t] = (uint32_t)((uint64_t)EB[i0 + t] - ebase);
-        __syncthreads();
-    }
-    const uint64_t j0 = ((uint64_t)blockIdx.x * BLOCK + threadIdx.x) * RUN_PER_THREAD;
-    uint32_t m = run_mask16(bwt, j0, rows, has_prev), tot;
+    const uint64_t g = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const uint64_t j0 = g * RUN_PER_THREAD;
+    uint32_t m = j0 < rows ? (uint32_t)rmask[g] : 0u, tot;
     const uint32_t ex = block_excl_sum((uint32_t)__popc(m), red, &tot);
     uint64_t k = run_base + tilebase[blockIdx.x] + ex;
-    auto value = [&](uint64_t j) -> SAT {     // j may be -1 (as uint64) for the row in front
-        if (sa) return *(sa + j);
-        const uint64_t o = row_base + j;
-        if (o == 0) return (SAT)a.n;                                     // src/pfbwt-f.cpp:301
-        const uint32_t slot = in_lds ? i0 + upper_bound_t<uint32_t>(ebl, ns, (uint32_t)(o - ebase)) - 1u : slot_of_row<EBT>(a, o);
+    while (m) {
+        const int b = __ffs((int)m) - 1; m &= m - 1;
+        const uint64_t o = row_base + j0 + b;
+        ssa[2 * k] = (SAT)o;
+        if (o) esa[2 * (k - 1)] = (SAT)(o - 1);
+        ++k;
+    }
+    if (total_runs_plus1 && j0 < rows && row_base + rows == total_rows && total_rows - 1 - row_base - j0 < RUN_PER_THREAD)
+        *(esa + 2 * ((long long)total_runs_plus1 - 2)) = (SAT)(total_rows - 1);
+}
+// Step 2: the SA VALUES of the sampled rows, one thread per run start of the window (its row and the row in front of it),
+// so that the dependent gathers of all samples are in flight together (a tile of 4096 rows holds ~20 samples: inside the
+// per-tile kernel of round 1 nine lanes in ten idled through four dependent loads).  sa_win != nullptr: a full SA exists,
+// sa_win[o - w_first]; else the value is computed from the row's parse row q (qrow[o - w_first], or looked up -- run-aware
+// emission): sa = bwsai[q] - suffix length of the slot over the row (pfbwt.hpp:87-89), row 0 := n (src/pfbwt-f.cpp:301).
+template <typename SAT, typename EBT> __global__ __launch_bounds__(BLOCK) void k_sample_values(EmitArgs a, const SAT *sa_win, const uint32_t *qrow, uint64_t w_first, uint64_t rc, uint64_t run_base,
+                                                                                               int has_last, uint64_t last_idx, SAT *ssa, SAT *esa)
+{
+    const EBT *EB = reinterpret_cast<const EBT *>(a.EB);
+    auto value = [&](uint64_t o) -> SAT {
+        if (sa_win) return sa_win[o - w_first];
+        if (o == 0) return (SAT)a.n;
+        const uint32_t slot = slot_of_row<EBT>(a, o);
         uint32_t q;
-        if (!a.special) q = *(qrow + j);
+        if (!a.special) q = qrow[o - w_first];
         else {   // run-aware emission: the parse row of a sampled row is looked up, not stored per row
             const uint4 S = a.sinfo[slot]; const uint32_t fl = S.w >> 24;
             if (slot_is_special(fl)) {
@@ -762,19 +763,13 @@ template <typename SAT, typename EBT> __global__ __launch_bounds__(BLOCK) void k
         }
         return (SAT)((SAT)a.bwsai[q] - (SAT)a.s_sl[slot]);
     };
-    while (m) {
-        const int b = __ffs((int)m) - 1; m &= m - 1;
-        const uint64_t j = j0 + b, o = row_base + j;
-        ssa[2 * k] = (SAT)o; ssa[2 * k + 1] = value(j);
-        if (o) { esa[2 * (k - 1)] = (SAT)(o - 1); esa[2 * (k - 1) + 1] = value(j - 1); }
-        ++k;
-    }
-    if (total_runs_plus1 && j0 < rows && row_base + rows == total_rows && total_rows - 1 - row_base - j0 < RUN_PER_THREAD) {   // the last row of the output ends the last run
-        // (index -1 when no run starts in this slice: esa then points one pair past the slice's first entry, see emit_and_sample)
-        const long long last = (long long)total_runs_plus1 - 2;
-        const uint64_t j = rows - 1;
-        *(esa + 2 * last) = (SAT)(row_base + j); *(esa + 2 * last + 1) = value(j);
-    }
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < rc) {
+        const uint64_t k = run_base + i;
+        const uint64_t o = (uint64_t)ssa[2 * k];
+        ssa[2 * k + 1] = value(o);
+        if (o) esa[2 * (k - 1) + 1] = value(o - 1);
+    } else if (i == rc && has_last) *(esa + 2 * (long long)last_idx + 1) = value(a.nout - 1);
 }
 
 } // namespace pfp

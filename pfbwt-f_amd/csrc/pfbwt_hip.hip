@@ -978,13 +978,14 @@ template <typename SAT, typename EBT> static int emit_and_sample(pfp_ctx *c, Emi
     bool bwt_done = false;
     if (want_rssa && !keep_sa) {
         // Samples only: ONE pass per window -- emit the BWT bytes and the parse rows q needed for sampling into scratch, find
-        // the run starts, compute SA values for the 2r sampled rows only (k_samples_tile), forget the q's.  r is not known in
+        // the run starts, compute SA values for the 2r sampled rows only (k_sample_rows, k_sample_values), forget the q's.  r is not known in
         // advance, so the sample arrays get a capacity from the free workspace; if r exceeds it the exact two-pass
         // route below is taken.
         const size_t lo_mark = c->arena.mark_lo(), hi_mark = c->arena.mark_hi();
         const uint64_t maxtiles = nblocks(maxrows, RUN_TILE);
-        uint32_t *tilecnt, *tilebase, *d_cnt, *qtmp;
+        uint32_t *tilecnt, *tilebase, *d_cnt, *qtmp; uint16_t *rmask;
         PFP_ALLOC_HI(c, tilecnt, uint32_t, maxtiles); PFP_ALLOC_HI(c, tilebase, uint32_t, maxtiles); PFP_ALLOC_HI(c, d_cnt, uint32_t, 1);
+        PFP_ALLOC_HI(c, rmask, uint16_t, maxtiles * BLOCK);
         PFP_ALLOC_HI(c, qtmp, uint32_t, qcap);
         const size_t freeb = c->arena.hi > c->arena.lo + ((size_t)256 << 20) ? c->arena.hi - c->arena.lo - ((size_t)256 << 20) : 0;
         uint64_t cap = freeb / (4 * sizeof(SAT));
@@ -1002,13 +1003,17 @@ template <typename SAT, typename EBT> static int emit_and_sample(pfp_ctx *c, Emi
             uint8_t *bw = bwt_of(wn) + wn.cl;                                // first row of the window
             PFP_TRY(emit_window(wn, bw - wn.cl, (SAT *)nullptr, qtmp, true));
             const uint64_t ntiles = nblocks(rows, RUN_TILE);
-            PFP_LAUNCH(c, K_RUNS, rows, k_run_tile_count, ntiles, (const uint8_t *)bw, rows, (int)wn.cl, tilecnt);
+            PFP_LAUNCH(c, K_RUNS, rows, k_run_tile_count, ntiles, (const uint8_t *)bw, rows, (int)wn.cl, tilecnt, rmask);
             PFP_TRY((device_scan<uint32_t, 0>(c, tilecnt, tilebase, ntiles, d_cnt)));
             uint32_t rc = 0; PFP_TRY(d2h_u32(c, d_cnt, &rc));
             if (!overflow && run_base + rc > cap) overflow = true;
-            if (!overflow)
-                PFP_LAUNCH(c, K_SAMPLES, rows + (uint64_t)rc * (32 + 4 * sizeof(SAT)), (k_samples_tile<SAT, EBT>), ntiles, ea, (const uint8_t *)bw, rows, (int)wn.cl, (const uint32_t *)tilebase, (const SAT *)nullptr,
-                           (const uint32_t *)(qtmp + wn.cl), wn.cs, run_base, total, wn.ce == total ? run_base + rc + 1 : (uint64_t)0, ssa, esa_w);
+            if (!overflow) {
+                const bool last = wn.ce == total;
+                PFP_LAUNCH(c, K_SAMPLES, rows / 8 + (uint64_t)rc * 4 * sizeof(SAT), (k_sample_rows<SAT>), ntiles, (const uint16_t *)rmask, rows, (const uint32_t *)tilebase, wn.cs, run_base, total,
+                           last ? run_base + rc + 1 : (uint64_t)0, ssa, esa_w);
+                PFP_LAUNCH(c, K_SAMPLES, (uint64_t)rc * (2 * 60 + 4 * sizeof(SAT)), (k_sample_values<SAT, EBT>), nblocks((uint64_t)rc + 1, BLOCK), ea, (const SAT *)nullptr, (const uint32_t *)qtmp, wn.cs - wn.cl, (uint64_t)rc, run_base,
+                           (int)last, last ? (uint64_t)(run_base + rc - 1) : (uint64_t)0, ssa, esa_w);
+            }
             run_base += rc;
         }
         c->runs = run_base; c->esa_pairs = run_base - (s0 == 0 ? 1 : 0) + (s1 == total ? 1 : 0);
@@ -1041,8 +1046,9 @@ template <typename SAT, typename EBT> static int emit_and_sample(pfp_ctx *c, Emi
         c->d_ssa = ssa; c->d_esa = esa;
         SAT *esa_w = esa + 2 * lead;
         const uint64_t maxtiles = nblocks(maxrows, RUN_TILE);
-        uint32_t *tilecnt, *tilebase, *d_cnt, *qtmp = nullptr;
+        uint32_t *tilecnt, *tilebase, *d_cnt, *qtmp = nullptr; uint16_t *rmask;
         PFP_ALLOC_HI(c, tilecnt, uint32_t, maxtiles); PFP_ALLOC_HI(c, tilebase, uint32_t, maxtiles); PFP_ALLOC_HI(c, d_cnt, uint32_t, 1);
+        PFP_ALLOC_HI(c, rmask, uint16_t, maxtiles * BLOCK);
         if (!sabuf) PFP_ALLOC_HI(c, qtmp, uint32_t, qcap);
         ea.qspec = qtmp;
         uint64_t run_base = 0;
@@ -1052,11 +1058,14 @@ template <typename SAT, typename EBT> static int emit_and_sample(pfp_ctx *c, Emi
             uint8_t *bw = bwt_of(wn) + wn.cl;                                // first row of the chunk
             if (!sabuf) PFP_TRY(emit_window(wn, bw - wn.cl, (SAT *)nullptr, qtmp, !bwt_done));   // pass 2 of this window: the same rows again, now with their q
             const uint64_t ntiles = nblocks(rows, RUN_TILE);
-            PFP_LAUNCH(c, K_RUNS, rows, k_run_tile_count, ntiles, (const uint8_t *)bw, rows, (int)wn.cl, tilecnt);
+            PFP_LAUNCH(c, K_RUNS, rows, k_run_tile_count, ntiles, (const uint8_t *)bw, rows, (int)wn.cl, tilecnt, rmask);
             PFP_TRY((device_scan<uint32_t, 0>(c, tilecnt, tilebase, ntiles, d_cnt)));
             uint32_t rc = 0; PFP_TRY(d2h_u32(c, d_cnt, &rc));
-            PFP_LAUNCH(c, K_SAMPLES, rows + (uint64_t)rc * (32 + 4 * sizeof(SAT)), (k_samples_tile<SAT, EBT>), ntiles, ea, (const uint8_t *)bw, rows, (int)wn.cl, (const uint32_t *)tilebase,
-                       sabuf ? (const SAT *)(sabuf + (wn.cs - (s0 - lead))) : (const SAT *)nullptr, (const uint32_t *)(sabuf ? nullptr : qtmp + wn.cl), wn.cs, run_base, total, wn.ce == total ? r + 1 : (uint64_t)0, ssa, esa_w);
+            if (run_base + rc > r) return PFP_E_CORRUPT;
+            const bool last = wn.ce == total;
+            PFP_LAUNCH(c, K_SAMPLES, rows / 8 + (uint64_t)rc * 4 * sizeof(SAT), (k_sample_rows<SAT>), ntiles, (const uint16_t *)rmask, rows, (const uint32_t *)tilebase, wn.cs, run_base, total, last ? r + 1 : (uint64_t)0, ssa, esa_w);
+            PFP_LAUNCH(c, K_SAMPLES, (uint64_t)rc * (2 * 60 + 4 * sizeof(SAT)), (k_sample_values<SAT, EBT>), nblocks((uint64_t)rc + 1, BLOCK), ea, sabuf ? (const SAT *)(sabuf + (wn.cs - wn.cl - (s0 - lead))) : (const SAT *)nullptr,
+                       (const uint32_t *)qtmp, wn.cs - wn.cl, (uint64_t)rc, run_base, (int)last, last ? (uint64_t)(r - 1) : (uint64_t)0, ssa, esa_w);
             run_base += rc;
         }
         if (run_base != r) return PFP_E_CORRUPT;
@@ -1095,7 +1104,7 @@ template <typename EBT> static int emit_stage(pfp_ctx *c, EmitArgs ea, int want_
     PFP_HIP(c, hipMemcpyAsync(&tot, d_tot, sizeof(EBT), hipMemcpyDeviceToHost, c->stream));
     PFP_HIP(c, hipStreamSynchronize(c->stream));
     hardrows = hh[0]; ea.big_total = hh[1];
-    {   // slot under every EMIT_TILE-th output row (k_emit, k_fill, k_samples_tile, k_slice_bounds start their searches there)
+    {   // slot under every EMIT_TILE-th output row (k_emit, k_fill, k_sample_values, k_slice_bounds start their searches there)
         const uint64_t ntiles = ((uint64_t)tot + EMIT_TILE - 1) / EMIT_TILE;
         uint32_t *tile_slot; PFP_ALLOC_HI(c, tile_slot, uint32_t, ntiles + 1);
         PFP_LAUNCH(c, K_EMIT_COUNT, dsize * 2 * sizeof(EBT) + ntiles * 4, (k_tile_slots<EBT>), nblocks(dsize, BLOCK), (const EBT *)cnt, (const EBT *)EB, dsize, ntiles, tile_slot);
@@ -1350,6 +1359,111 @@ static int sacak_int_impl(const uint32_t *s, void *SA, uint64_t n, uint64_t k, b
     pfp_destroy(c);
     return rounds;
 }
+extern "C++" {
+// int gsacak(unsigned char *s, uint_t *SA, int_t *LCP, int_t *DA, uint_t n), gsa/gsacak.h:86-96 -- the call of
+// include/pfbwt.hpp:211.  s = strings over the dictionary alphabet {'-', A, C, G, N, T} and Dollar (2), each followed by
+// the separator 1, s[n-1] = 0.  Suffixes are compared up to their separator; suffixes that are byte-identical up to it
+// are ordered by position (gsacak.c:877-912) and LCP stops at the separator (:64).
+__global__ __launch_bounds__(BLOCK) void k_gsa_check_alphabet(const uint8_t *D, uint64_t n, uint32_t *bad)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t c = D[i];
+    const bool ok = c <= 2 || c == '-' || c == 'A' || c == 'C' || c == 'G' || c == 'N' || c == 'T';
+    if (!ok || (c == 0 && i + 1 != n) || (i + 1 == n && c != 0)) atomicAdd(bad, 1u);
+}
+// LCP[i] of SA[i-1], SA[i]: bytes are compared eight at a time; inside runs of one byte (a 10 Mbp run of N is one phrase whose
+// suffixes are neighbours in SA) the shorter of the two runs is skipped at once (M: run lengths, see k_ss_runend_marks)
+template <typename LT> __global__ __launch_bounds__(BLOCK) void k_gsa_lcp(const uint8_t *D, const uint32_t *SA, const uint32_t *M, uint64_t n, LT *lcp)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    if (i == 0) { lcp[0] = 0; return; }
+    const uint64_t x = SA[i - 1], y = SA[i];
+    uint64_t h = 0;
+    for (;;) {
+        const uint64_t px = x + h, py = y + h;
+        if (px >= n || py >= n) break;
+        const uint8_t cx = D[px];
+        if (cx != D[py] || cx <= EndOfWord) break;
+        const uint32_t ix = (uint32_t)(n - 1 - px), iy = (uint32_t)(n - 1 - py);
+        const uint64_t rx = ix - M[ix] + 1u, ry = iy - M[iy] + 1u;          // lengths of the runs of cx that start at px / py
+        if (rx >= 16 && ry >= 16) { h += rx < ry ? rx : ry; continue; }
+        const uint64_t a = ld8(D + px), b = ld8(D + py);                     // (the device buffer is padded)
+        // first byte that differs or is a separator / terminator: bytes are < 0x80, so (v - 0x02..02) has its high bit set exactly for v <= 1
+        const uint64_t stop = (a ^ b) | (((a - 0x0202020202020202ULL) & ~a & 0x8080808080808080ULL));
+        if (stop) { h += (uint64_t)(__ffsll((long long)stop) - 1) >> 3; break; }
+        h += 8;
+    }
+    lcp[i] = (LT)h;
+}
+template <typename LT> __global__ __launch_bounds__(BLOCK) void k_gsa_da(const uint32_t *SA, const uint32_t *wordid, uint64_t n, LT *da)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) da[i] = (LT)wordid[SA[i]];
+}
+static int gsacak_impl(const uint8_t *s, void *SA, void *LCP, void *DA, uint64_t n, bool u64)
+{
+    if (!s || !SA || n < 2) return -1;
+    if (n + 64 >= 0xFFFFFFFFULL) return -1;
+    int st = 0;
+    pfp_ctx *c = pfp_create(10, 100, u64 ? PFP_FLAG_U64 : 0u, 0, (uint64_t)(72 * n + (64ULL << 20)), &st);
+    if (!c) return -1;
+    int rounds = -1;
+    auto body = [&]() -> int {
+        PFP_TRY(ensure_arena(c, n));
+        c->arena.reset();
+        c->dsize = n;
+        PFP_ALLOC_LO(c, c->d_dict, uint8_t, n + 16);
+        PFP_HIP(c, hipMemsetAsync(c->d_dict + n, 0, 16, c->stream));
+        PFP_TRY(h2d_copy(c, c->d_dict, s, n));
+        uint32_t *d_bad; PFP_ALLOC_HI(c, d_bad, uint32_t, 1);
+        PFP_HIP(c, hipMemsetAsync(d_bad, 0, 4, c->stream));
+        PFP_LAUNCH(c, K_MISC, n, k_gsa_check_alphabet, nblocks(n, BLOCK), (const uint8_t *)c->d_dict, n, d_bad);
+        uint32_t bad = 0; PFP_TRY(d2h_u32(c, d_bad, &bad));
+        if (bad) return PFP_E_ARG;                                   // a byte outside the dictionary alphabet, or no unique terminator
+        // sort_dict_suffixes with a counted round number
+        uint64_t *k0, *k1; uint32_t *v0, *v1;
+        PFP_ALLOC_LO(c, c->d_gsa, uint32_t, n); PFP_ALLOC_LO(c, c->d_grank, uint2, n);
+        const size_t mk = c->arena.mark_hi();
+        PFP_ALLOC_HI(c, k0, uint64_t, n); PFP_ALLOC_HI(c, k1, uint64_t, n); PFP_ALLOC_HI(c, v0, uint32_t, n); PFP_ALLOC_HI(c, v1, uint32_t, n);
+        PFP_LAUNCH(c, K_SS_INIT_KEYS, n * 13, k_dict_init_keys, nblocks(n, DK_TILE), (const uint8_t *)c->d_dict, n, k0, v0);
+        BitRange full = {0, DK_KEY_BITS};
+        PFP_TRY(suffix_sort_doubling<true>(c, n, k0, v0, k1, v1, &full, 1, DK_CHARS, c->d_dict, c->d_gsa, (uint32_t *)nullptr, c->d_grank, &rounds));
+        c->arena.release_hi(mk);
+        PFP_HIP(c, hipStreamSynchronize(c->stream));
+        if (!u64) PFP_HIP(c, hipMemcpy(SA, c->d_gsa, n * 4, hipMemcpyDeviceToHost));
+        else PFP_TRY(get_u32_as(c, c->d_gsa, n, SA, true));
+        if (LCP) {
+            uint32_t *M; PFP_ALLOC_HI(c, M, uint32_t, n);
+            PFP_LAUNCH(c, K_MISC, n * 5, k_ss_runend_marks, nblocks(n, BLOCK), (const uint8_t *)c->d_dict, n, M);
+            PFP_TRY((device_scan<uint32_t, 1>(c, M, M, n, nullptr)));
+            if (u64) { int64_t *d; PFP_ALLOC_HI(c, d, int64_t, n); PFP_LAUNCH(c, K_MISC, n * 40, (k_gsa_lcp<int64_t>), nblocks(n, BLOCK), (const uint8_t *)c->d_dict, (const uint32_t *)c->d_gsa, (const uint32_t *)M, n, d);
+                       PFP_HIP(c, hipStreamSynchronize(c->stream)); PFP_HIP(c, hipMemcpy(LCP, d, n * 8, hipMemcpyDeviceToHost)); }
+            else { int32_t *d; PFP_ALLOC_HI(c, d, int32_t, n); PFP_LAUNCH(c, K_MISC, n * 36, (k_gsa_lcp<int32_t>), nblocks(n, BLOCK), (const uint8_t *)c->d_dict, (const uint32_t *)c->d_gsa, (const uint32_t *)M, n, d);
+                   PFP_HIP(c, hipStreamSynchronize(c->stream)); PFP_HIP(c, hipMemcpy(LCP, d, n * 4, hipMemcpyDeviceToHost)); }
+            c->arena.release_hi(mk);
+        }
+        if (DA) {   // document of every suffix = number of separators in front of it
+            uint32_t *flag, *wid; PFP_ALLOC_HI(c, flag, uint32_t, n); PFP_ALLOC_HI(c, wid, uint32_t, n);
+            PFP_LAUNCH(c, K_MISC, n * 5, k_eow_flags, nblocks(n, BLOCK), (const uint8_t *)c->d_dict, n, flag);
+            PFP_TRY((device_scan<uint32_t, 0>(c, flag, wid, n, nullptr)));
+            if (u64) { int64_t *d; PFP_ALLOC_HI(c, d, int64_t, n); PFP_LAUNCH(c, K_MISC, n * 16, (k_gsa_da<int64_t>), nblocks(n, BLOCK), (const uint32_t *)c->d_gsa, (const uint32_t *)wid, n, d);
+                       PFP_HIP(c, hipStreamSynchronize(c->stream)); PFP_HIP(c, hipMemcpy(DA, d, n * 8, hipMemcpyDeviceToHost)); }
+            else { int32_t *d; PFP_ALLOC_HI(c, d, int32_t, n); PFP_LAUNCH(c, K_MISC, n * 12, (k_gsa_da<int32_t>), nblocks(n, BLOCK), (const uint32_t *)c->d_gsa, (const uint32_t *)wid, n, d);
+                   PFP_HIP(c, hipStreamSynchronize(c->stream)); PFP_HIP(c, hipMemcpy(DA, d, n * 4, hipMemcpyDeviceToHost)); }
+            c->arena.release_hi(mk);
+        }
+        return PFP_OK;
+    };
+    const int rc = body();
+    pfp_destroy(c);
+    return rc == PFP_OK ? rounds : -1;
+}
+} // extern "C++"
+int pfp_gsacak_u32(const uint8_t *s, uint32_t *SA, int32_t *LCP, int32_t *DA, uint32_t n) { return gsacak_impl(s, SA, LCP, DA, n, false); }
+int pfp_gsacak_u64(const uint8_t *s, uint64_t *SA, int64_t *LCP, int64_t *DA, uint64_t n) { return gsacak_impl(s, SA, LCP, DA, n, true); }
+
 int pfp_sacak_int_u32(const uint32_t *s, uint32_t *SA, uint32_t n, uint32_t k) { return sacak_int_impl(s, SA, n, k, false); }
 int pfp_sacak_int_u64(const uint32_t *s, uint64_t *SA, uint64_t n, uint64_t k) { return sacak_int_impl(s, SA, n, k, true); }
 

@@ -79,6 +79,8 @@ def load_library(path=None):
     L.pfp_merge_shards.argtypes = [vp, i32, C.POINTER(ShardView), C.POINTER(ParseSizes)]
     L.pfp_sacak_int_u32.argtypes = [vp, vp, C.c_uint32, C.c_uint32]
     L.pfp_sacak_int_u64.argtypes = [vp, vp, u64, u64]
+    L.pfp_gsacak_u32.argtypes = [vp, vp, vp, vp, C.c_uint32]
+    L.pfp_gsacak_u64.argtypes = [vp, vp, vp, vp, u64]
     L.pfp_profile_enable.argtypes = [vp, i32]
     L.pfp_profile_reset.argtypes = [vp]
     L.pfp_profile_select.argtypes = [vp, C.c_char_p]
@@ -271,3 +273,15 @@ def sacak_int(s, k, u64=False, lib=None):
     if r < 0:
         raise PfpError(r, "sacak_int failed")
     return SA, r
+
+
+def gsacak(s, lcp=False, da=False, u64=False, lib=None):
+    """Drop-in for gsacak (gsa/gsacak.h:86-96) on a dictionary image: returns (SA, LCP or None, DA or None, rounds)."""
+    L = load_library(lib)
+    s = np.ascontiguousarray(s, np.uint8)
+    ut, it = (np.uint64, np.int64) if u64 else (np.uint32, np.int32)
+    SA = np.empty(s.size, ut); LCP = np.empty(s.size, it) if lcp else None; DA = np.empty(s.size, it) if da else None
+    r = (L.pfp_gsacak_u64 if u64 else L.pfp_gsacak_u32)(_ptr(s), _ptr(SA), _ptr(LCP), _ptr(DA), s.size)
+    if r < 0:
+        raise PfpError(r, "gsacak failed")
+    return SA, LCP, DA, r

@@ -226,3 +226,46 @@ def test_emu_failed_stage_leaves_context_usable(emu_factory):
     sz = ctx.finalize(); ctx.parse_bwt(); ctx.bwt_build(sa=True, rssa=True)
     assert sz.n == ref["n"] and np.array_equal(ctx.bwt_get()["sa"], ref["sa"])
     ctx.close()
+
+
+def _gsacak_check(lib, names, nruns_case=True):
+    """pfp_gsacak_u32/u64 (gsa/gsacak.h:86-96 drop-in): SA, LCP (stops at the separator) and DA of a dictionary image ==
+    the reference's gsacak() (oracle/_ref/libgsacak64.so when it is there) and == the oracle's restatement of it"""
+    import ctypes as C
+    import pfbwt_hip
+    from pfp_testlib import ROOT, oracle
+    so = os.path.join(ROOT, "oracle", "_ref", "libgsacak64.so")
+    G = C.CDLL(so) if os.path.exists(so) else None
+    if G is not None:
+        G.gsacak.argtypes = [C.c_void_p] * 4 + [C.c_uint64]
+    O = oracle(); O.orc_gsa_lcp.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
+    dicts = []
+    for name in names:
+        man, recs = golden_case(name)
+        dicts.append(oracle_run([s for _, s in recs], w=man["w"], p=man["p"], U=8)["dict"].copy())
+    if nruns_case:     # a long run of N inside a phrase (the run-skipping branch of the LCP kernel) and a phrase that recurs
+        rng = np.random.default_rng(4)
+        rnd = lambda k: bytes(rng.choice(list(b"ACGT"), k).astype(np.uint8))
+        a = rnd(700) + b"N" * 5000 + rnd(300)
+        dicts.append(oracle_run([a, rnd(100) + a[200:], a], w=6, p=13, U=8)["dict"].copy())
+    for d in dicts:
+        n = d.size; dwords = int((d == 1).sum())
+        a = np.zeros(n, np.uint64); b = np.zeros(n, np.uint64)
+        assert O.orc_gsa_lcp(d.ctypes.data_as(C.c_void_p), n, dwords, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p)) == 0
+        for u64 in (True, False):
+            sa, lcp, da, r = pfbwt_hip.gsacak(d, lcp=True, da=True, u64=u64, lib=lib)
+            assert r >= 1 and np.array_equal(sa.astype(np.uint64), a) and np.array_equal(lcp.astype(np.uint64), b)
+            assert np.array_equal(da.astype(np.int64), np.cumsum(np.concatenate(([0], d[:-1] == 1)))[sa.astype(np.int64)])
+            if G is not None and u64:
+                SA = np.zeros(n, np.uint64); LCP = np.zeros(n, np.int64); DA = np.zeros(n, np.int64)
+                G.gsacak(d.ctypes.data_as(C.c_void_p), SA.ctypes.data_as(C.c_void_p), LCP.ctypes.data_as(C.c_void_p), DA.ctypes.data_as(C.c_void_p), n)
+                assert np.array_equal(sa, SA) and np.array_equal(lcp, LCP) and np.array_equal(da, DA)
+        sa2, l2, d2, _ = pfbwt_hip.gsacak(d, lib=lib)                      # SA only
+        assert l2 is None and d2 is None and np.array_equal(sa2.astype(np.uint64), a)
+    bad = dicts[0].copy(); bad[5] = ord("R")
+    with pytest.raises(pfbwt_hip.PfpError):
+        pfbwt_hip.gsacak(bad, lib=lib)                                    # a byte outside the dictionary alphabet: -1
+
+
+def test_emu_gsacak_dropin(emu_factory):
+    _gsacak_check(EMU_SO, ["edge", "w4p7"])

@@ -116,6 +116,13 @@ def test_sacak_int_dropin(gpu_ctx_factory):
         assert np.array_equal(SA.astype(np.uint64), want) and rounds >= 1
 
 
+def test_gsacak_dropin(gpu_ctx_factory):
+    """pfp_gsacak_u32/u64 on the MI355X: SA, LCP and DA of dictionary images == the oracle's restatement of gsacak (which the
+    CPU suite pins to the reference's own gsacak build), incl. a dictionary with a long run of N"""
+    from test_emu_pipeline import _gsacak_check
+    _gsacak_check(None, ["edge", "w4p7", "mult_chroms_fa", "panel8"])
+
+
 def test_full_size_properties(gpu_ctx_factory):
     """S-50M-like panel at a size the oracle is too slow for in a unit test: check properties that do
     not need it -- SA is a permutation of 0..n, T[SA[i]-1] == BWT[i], run samples consistent."""

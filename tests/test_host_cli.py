@@ -22,6 +22,10 @@ def sha_f(p):
 
 
 def bins(kind):
+    if kind == "asan":
+        subprocess.run(["make", "-C", os.path.join(ROOT, "pfbwt-f_amd"), "asan"], check=True, stdout=subprocess.DEVNULL)
+        d = os.path.join(ROOT, "tests", "emu", "build")
+        return {"pfbwt-f": os.path.join(d, "pfbwt-f-asan"), "pfbwt-f64": os.path.join(d, "pfbwt-f64-asan"), "merge_pfp": os.path.join(d, "merge_pfp-asan")}
     if kind == "emu":
         subprocess.run(["make", "-C", os.path.join(ROOT, "pfbwt-f_amd"), "emu-host"], check=True, stdout=subprocess.DEVNULL)
         d = os.path.join(ROOT, "tests", "emu", "build")
@@ -116,6 +120,20 @@ def check_stages_and_merge(B, tmp):
 def test_cli_emu(tmp_path):
     B = bins("emu")
     check_cli(B, str(tmp_path), [("edge", "pfbwt-f64", 8), ("mult_chroms_fa", "pfbwt-f", 4)])
+    check_stages_and_merge(B, str(tmp_path))
+
+
+def test_cli_asan_ubsan(tmp_path, monkeypatch):
+    """the host mirror + command lines built with -fsanitize=address,undefined (`make asan`), engine = tests/emu: any
+    sanitizer report makes the binary exit non-zero, which fails the run() helper.  Leak checking is on; the emulator's
+    cached fiber stacks are the one suppressed allocation site."""
+    sup = tmp_path / "lsan.supp"
+    sup.write_text("leak:emu::run_block\n")
+    monkeypatch.setenv("ASAN_OPTIONS", "detect_leaks=1:abort_on_error=0:exitcode=66")
+    monkeypatch.setenv("LSAN_OPTIONS", "suppressions=%s:print_suppressions=0" % sup)
+    monkeypatch.setenv("UBSAN_OPTIONS", "halt_on_error=1:print_stacktrace=1")
+    B = bins("asan")
+    check_cli(B, str(tmp_path), [("edge", "pfbwt-f64", 8), ("w4p7", "pfbwt-f", 4)])
     check_stages_and_merge(B, str(tmp_path))
 
 
