@@ -145,6 +145,18 @@ int pfp_bwt_get(pfp_ctx *ctx, uint8_t *bwt, void *sa, void *ssa, void *esa);
 /* device pointers of the same results (valid until the next pfp_* call that rebuilds them) */
 int pfp_bwt_device_ptrs(pfp_ctx *ctx, const void **d_bwt, const void **d_sa, const void **d_ssa, const void **d_esa);
 
+/* ---- marker-array post-pass --------------------------------------------------- */
+/* write_marker_array, include/marker_array.hpp:138-174 (the tool src/mps_to_ma.cpp): mps = the marker-positions stream
+ * written by MarkerPositionsWriter (:60-136; records: first text position, last text position, packed markers
+ * (include/marker.hpp:9-52), 0xFFFFFFFFFFFFFFFF; intervals ascending and disjoint).  Every suffix-array value is looked up
+ * (rle_window_arr::at, include/rle_window_array.hpp:118-131) and consecutive rows with equal, non-empty marker lists become
+ * one record: first row, last row, the markers, 0xFFFFFFFFFFFFFFFF.  sa_host == NULL: fused with the build -- the suffix
+ * array pfp_bwt_build(want_sa = 1) left on the device is used (the reference pipes it through `tee`, vcf_to_bwt.py:259-285);
+ * otherwise sa_host holds nrows U-wide values in BWT order (row 0 = n, src/pfbwt-f.cpp:301) and the context is reset.
+ * *out_words = 64-bit words of the .ma stream, fetched with pfp_marker_array_get. */
+int pfp_marker_array(pfp_ctx *ctx, const uint64_t *mps, uint64_t mps_words, const void *sa_host, uint64_t nrows, uint64_t *out_words);
+int pfp_marker_array_get(pfp_ctx *ctx, uint64_t *dst);
+
 /* ---- drop-ins for the suffix-sorting C ABI, gsa/gsacak.h:76-103 ------------------------------- */
 /* int sacak_int(int_text *s, uint_t *SA, uint_t n, uint_t k): s[n-1]==0, symbols < k.  Returns the
  * number of refinement rounds (>= 1; the reference returns its recursion depth) or -1 on error. */

@@ -95,6 +95,7 @@ struct pfp_ctx {
     uint64_t nout = 0, runs = 0, esa_pairs = 0, easy = 0, hard = 0, slice_begin = 0, slice_rows = 0;
     uint8_t *d_bwt = nullptr; void *d_sa = nullptr; void *d_ssa = nullptr; void *d_esa = nullptr;
     bool have_sa = false, have_rssa = false;
+    uint64_t *d_ma = nullptr; uint64_t ma_words = 0;      // marker array (pfp_marker_array)
     size_t lo_after_parse = 0, lo_after_pbwt = 0;
     // --- instrumentation
     bool prof_on = false; uint64_t prof_mask = ~0ULL;

@@ -273,28 +273,6 @@ __global__ __launch_bounds__(BLOCK) void k_phrase_ends(const uint16_t *mask16, c
     while (m) { int b = __ffs((int)m) - 1; m &= m - 1; ye[o++] = (tpos_t)(t * 16 + b + 1); }
 }
 
-// ---- phrase fingerprints: polynomial hash modulo the Mersenne prime 2^61-1 ---------------------
-constexpr uint64_t P61 = (1ULL << 61) - 1;
-__host__ __device__ __forceinline__ uint64_t mulmod61(uint64_t a, uint64_t b)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    const uint64_t hi = __umul64hi(a, b);
-#else
-    const uint64_t hi = (uint64_t)(((unsigned __int128)a * b) >> 64);
-#endif
-    const uint64_t lo = a * b;
-    uint64_t r = (lo & P61) + ((lo >> 61) | (hi << 3));
-    r = (r & P61) + (r >> 61);
-    return r >= P61 ? r - P61 : r;
-}
-__host__ __device__ __forceinline__ uint64_t addmod61(uint64_t a, uint64_t b) { uint64_t r = a + b; return r >= P61 ? r - P61 : r; }
-__host__ __device__ __forceinline__ uint64_t powmod61(uint64_t b, uint64_t e)
-{
-    uint64_t r = 1;
-    while (e) { if (e & 1) r = mulmod61(r, b); b = mulmod61(b, b); e >>= 1; }
-    return r;
-}
-
 // Where the byte strings to be de-duplicated live: string j = Y[ys_j .. ye[j]].  Text mode (ys == nullptr):
 // consecutive phrases overlap by w bytes, ys_j = ye[j-1] - w + 1, ys_0 = 0.  Word mode (ys != nullptr): explicit
 // starts (dictionary words of several shards laid out in one buffer, see pfp_merge_shards).
@@ -313,154 +291,260 @@ __device__ __forceinline__ uint64_t ld8(const uint8_t *p) { uint64_t v; __builti
 
 constexpr uint32_t LONG_PHRASE = 2048; // phrases longer than this go to the workgroup-per-phrase kernels
 
-// one thread per phrase
-// The digits of the polynomial are the 8-byte little-endian words of the phrase (the last one masked to the bytes that
-// remain), not its bytes: one modular multiplication per 8 bases.  fingerprint = (sum_j word_j * B^(k-1-j)) * B + len.
-__device__ __forceinline__ uint64_t red61(uint64_t v) { const uint64_t r = (v & P61) + (v >> 61); return r >= P61 ? r - P61 : r; }
-__device__ __forceinline__ uint64_t hash_words(const uint8_t *s, uint32_t len, uint64_t B)
+// ---- exact de-duplication: a hash table of representatives ----------------------------------------------------------
+// The reference keeps the phrases in a std::map<std::string, Freq> (pfparser.hpp:69-70, 595-597).  Here every phrase is
+// looked up in an open-addressing table whose entries are {32 bits of the phrase's hash | index of a representative
+// phrase}: an entry matches when the filter bits agree AND the bytes of the two phrases are equal (compared 8 at a time),
+// so the result is exact whatever the hash does.  The phrases are visited in text order (their own bytes stream through
+// once), the representatives they are compared with are the ~dictionary-sized hot set.  Entries never change once
+// written, so the plain (possibly stale, per-XCD L2) read in front of the compare-and-swap is safe: a stale EMPTY is
+// corrected by the value the CAS returns.  Round 1 sorted (fingerprint, phrase) pairs and compared neighbours instead:
+// 8 radix passes over all phrases and two random phrase reads per phrase.
+constexpr uint64_t HT_EMPTY = ~0ULL;
+constexpr uint32_t HT_MAX_PROBES = 1u << 16;
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t z) { z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL; return z ^ (z >> 31); }
+// content hash of s[0..len): a multiply-xorshift chain over the 8-byte little-endian words, the last one masked
+__device__ __forceinline__ uint64_t str_hash(const uint8_t *s, uint32_t len, uint64_t seed)
 {
-    uint64_t h = 0;
+    uint64_t h = seed ^ ((uint64_t)len * 0x9E3779B97F4A7C15ULL);
     uint32_t i = 0;
-    for (; i + 8 <= len; i += 8) h = addmod61(mulmod61(h, B), red61(ld8(s + i)));
-    if (i < len) h = addmod61(mulmod61(h, B), red61(ld8(s + i) & ((1ULL << (8 * (len - i))) - 1ULL)));
-    return h;
+    for (; i + 8 <= len; i += 8) { h = (h ^ ld8(s + i)) * 0xD6E8FEB86659FD93ULL; h ^= h >> 32; }
+    if (i < len) { h = (h ^ (ld8(s + i) & ((1ULL << (8 * (len - i))) - 1ULL))) * 0xD6E8FEB86659FD93ULL; h ^= h >> 32; }
+    return mix64(h);
 }
-__global__ __launch_bounds__(BLOCK) void k_phrase_hash(const uint8_t *Y, Spans sp, uint64_t m, uint64_t B,
-                                                       uint64_t *keys, uint32_t *vals, uint32_t *longlist, uint32_t *nlong)
+__device__ __forceinline__ bool str_equal(const uint8_t *a, const uint8_t *b, uint32_t len)
 {
+    uint32_t i = 0;
+    for (; i + 8 <= len; i += 8) if (ld8(a + i) != ld8(b + i)) return false;
+    if (i < len) return ((ld8(a + i) ^ ld8(b + i)) & ((1ULL << (8 * (len - i))) - 1ULL)) == 0;
+    return true;
+}
+struct DedupTable {
+    unsigned long long *tab; uint32_t *cnt; uint64_t mask;        // entries, occurrences per entry, table size - 1
+    unsigned long long *rinfo;                                    // per entry: start << 16 | length of its representative once its creator has stored it (0: read the spans)
+    uint32_t *slotof;                                             // per phrase: its entry
+    uint32_t *dslot; uint64_t *dhash; uint32_t *nd; uint32_t limit;   // the entries in use (appended by whoever created them) and their hashes
+    uint32_t *overflow;                                           // != 0: more distinct phrases than `limit` (or a probe sequence too long): retry with a larger table
+};
+// phrase j (hash h, bytes Y[ys..ys+len)) enters the table or finds its representative there
+__device__ __forceinline__ void dedup_find_or_insert(const uint8_t *Y, const Spans &sp, const DedupTable &t, uint32_t j, tpos_t ys, uint32_t len, uint64_t h)
+{
+    const uint64_t filt = h >> 32;
+    uint64_t slot = h & t.mask;
+    for (uint32_t probe = 0; probe < HT_MAX_PROBES; ++probe, slot = (slot + 1) & t.mask) {
+        unsigned long long cur = t.tab[slot];
+        if ((probe & 7u) == 7u && *t.overflow) return;          // the table is being abandoned (it may be full: no EMPTY entry would end the walk)
+        if (cur == HT_EMPTY) {
+            if (*t.overflow) return;
+            cur = atomicCAS(&t.tab[slot], (unsigned long long)HT_EMPTY, (unsigned long long)((filt << 32) | j));
+            if (cur == HT_EMPTY) {                               // this phrase is the representative of a new entry
+                const uint32_t k = atomicAdd(t.nd, 1u);
+                if (k >= t.limit) { *t.overflow = 1; return; }
+                t.dslot[k] = (uint32_t)slot; t.dhash[k] = h;
+                t.slotof[j] = (uint32_t)slot; atomicAdd(&t.cnt[slot], 1u);
+                return;
+            }
+        }
+        if ((cur >> 32) == filt) {
+            tpos_t rs; uint32_t rlen; phrase_span(sp, (uint32_t)cur, &rs, &rlen);
+            if (rlen == len && str_equal(Y + ys, Y + rs, len)) { t.slotof[j] = (uint32_t)slot; atomicAdd(&t.cnt[slot], 1u); return; }
+        }
+    }
+    *t.overflow = 2;
+}
+// One thread per phrase; phrases longer than LONG_PHRASE are only listed (a workgroup each, below).  The 256 phrases of a
+// workgroup are neighbours in the text (~26 KB at p = 100): their bytes are brought into LDS by coalesced 16-byte loads
+// and hashed / compared from there, so that every phrase crosses HBM once; what remains random is the read of the
+// representative (a dictionary-sized hot set).  A window that does not fit (long phrases, scattered words) falls back to
+// reading the phrase from memory.
+constexpr uint32_t DD_TILE_BYTES = 32768 - 64;
+__device__ __forceinline__ uint64_t lds_ld8(const uint32_t *t32, uint32_t off)
+{   // 8 bytes at an arbitrary byte offset of an LDS array of 32-bit words
+    const uint32_t i = off >> 2, sh = (off & 3u) * 8u;
+    const uint32_t w0 = t32[i], w1 = t32[i + 1];
+    if (!sh) return ((uint64_t)w1 << 32) | w0;
+    const uint32_t w2 = t32[i + 2];
+    return ((uint64_t)((w1 >> sh) | (w2 << (32 - sh))) << 32) | ((w0 >> sh) | (w1 << (32 - sh)));
+}
+__global__ __launch_bounds__(BLOCK) void k_dedup_insert(const uint8_t *Y, Spans sp, uint64_t m, uint64_t seed, DedupTable t, uint32_t *longlist, uint32_t *nlong)
+{
+    __shared__ uint32_t tile[DD_TILE_BYTES / 4 + 20];
+    __shared__ unsigned long long wlo[BLOCK / WAVE], whi[BLOCK / WAVE];
     const uint64_t j = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (j >= m) return;
-    tpos_t ys; uint32_t len; phrase_span(sp, j, &ys, &len);
-    vals[j] = (uint32_t)j;
-    if (len > LONG_PHRASE) { longlist[atomicAdd(nlong, 1u)] = (uint32_t)j; keys[j] = 0; return; }
-    keys[j] = addmod61(mulmod61(hash_words(Y + ys, len, B), B), len % P61);
+    const bool live = j < m;
+    tpos_t ys = 0; uint32_t len = 0;
+    if (live) phrase_span(sp, j, &ys, &len);
+    const bool lng = live && len > LONG_PHRASE;
+    if (lng) longlist[atomicAdd(nlong, 1u)] = (uint32_t)j;
+    // window of the workgroup's (short) phrases
+    unsigned long long lo = (live && !lng) ? (unsigned long long)ys : ~0ULL, hi = (live && !lng) ? (unsigned long long)ys + len : 0ULL;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const unsigned long long a = __shfl_xor(lo, d), b = __shfl_xor(hi, d); lo = a < lo ? a : lo; hi = b > hi ? b : hi; }
+    if ((threadIdx.x & 63) == 0) { wlo[threadIdx.x >> 6] = lo; whi[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    lo = wlo[0]; hi = whi[0];
+#pragma unroll
+    for (int v = 1; v < BLOCK / WAVE; ++v) { lo = wlo[v] < lo ? wlo[v] : lo; hi = whi[v] > hi ? whi[v] : hi; }
+    if (hi == 0) return;                                     // nothing but long phrases (or nothing at all)
+    const uint64_t base = lo & ~15ULL;                       // Y + base is 16-byte aligned when Y is: not assumed -- the loads below are byte-exact
+    const bool tiled = hi - base <= DD_TILE_BYTES;
+    if (tiled) {
+        const uint32_t nb = (uint32_t)(hi - base);
+        // the text buffer is padded in front of Y[0] and behind its end, so whole 16-byte pieces may be read
+        for (uint32_t o = threadIdx.x * 16u; o < nb + 8u; o += BLOCK * 16u) {
+            uint4 v; __builtin_memcpy(&v, Y + base + o, 16);
+            tile[o / 4] = v.x; tile[o / 4 + 1] = v.y; tile[o / 4 + 2] = v.z; tile[o / 4 + 3] = v.w;
+        }
+    }
+    __syncthreads();
+    if (!live || lng) return;
+    if (!tiled) { dedup_find_or_insert(Y, sp, t, (uint32_t)j, ys, len, str_hash(Y + ys, len, seed)); return; }
+    const uint32_t off = (uint32_t)(ys - base);
+    uint64_t h = seed ^ ((uint64_t)len * 0x9E3779B97F4A7C15ULL);
+    {
+        uint32_t i = 0;
+        for (; i + 8 <= len; i += 8) { h = (h ^ lds_ld8(tile, off + i)) * 0xD6E8FEB86659FD93ULL; h ^= h >> 32; }
+        if (i < len) { h = (h ^ (lds_ld8(tile, off + i) & ((1ULL << (8 * (len - i))) - 1ULL))) * 0xD6E8FEB86659FD93ULL; h ^= h >> 32; }
+        h = mix64(h);
+    }
+    const uint64_t filt = h >> 32;
+    uint64_t slot = h & t.mask;
+    for (uint32_t probe = 0; probe < HT_MAX_PROBES; ++probe, slot = (slot + 1) & t.mask) {
+        unsigned long long cur = t.tab[slot];
+        unsigned long long ri = t.rinfo[slot];                    // requested together with the entry: the representative's bytes are one dependent load away, not three
+        if ((probe & 7u) == 7u && *t.overflow) return;          // the table is being abandoned (it may be full: no EMPTY entry would end the walk)
+        if (cur == HT_EMPTY) {
+            if (*t.overflow) return;
+            cur = atomicCAS(&t.tab[slot], (unsigned long long)HT_EMPTY, (unsigned long long)((filt << 32) | (uint32_t)j));
+            if (cur == HT_EMPTY) {
+                const uint32_t k = atomicAdd(t.nd, 1u);
+                if (k >= t.limit) { *t.overflow = 1; return; }
+                t.rinfo[slot] = ((unsigned long long)ys << 16) | len;
+                t.dslot[k] = (uint32_t)slot; t.dhash[k] = h;
+                t.slotof[j] = (uint32_t)slot; atomicAdd(&t.cnt[slot], 1u);
+                return;
+            }
+            ri = 0;
+        }
+        if ((cur >> 32) == filt) {
+            tpos_t rs; uint32_t rlen;
+            if (ri) { rs = (tpos_t)(ri >> 16); rlen = (uint32_t)(ri & 0xFFFFu); }
+            else phrase_span(sp, (uint32_t)cur, &rs, &rlen);
+            if (rlen == len) {
+                // no early exit: an entry whose filter bits agree is the same phrase all but never, and independent loads overlap
+                const uint8_t *r = Y + rs;
+                uint64_t diff = 0;
+                uint32_t i = 0;
+                for (; i + 32 <= len; i += 32) {
+                    const uint64_t a0 = ld8(r + i), a1 = ld8(r + i + 8), a2 = ld8(r + i + 16), a3 = ld8(r + i + 24);
+                    diff |= (a0 ^ lds_ld8(tile, off + i)) | (a1 ^ lds_ld8(tile, off + i + 8)) | (a2 ^ lds_ld8(tile, off + i + 16)) | (a3 ^ lds_ld8(tile, off + i + 24));
+                }
+                for (; i + 8 <= len; i += 8) diff |= ld8(r + i) ^ lds_ld8(tile, off + i);
+                if (i < len) diff |= (lds_ld8(tile, off + i) ^ ld8(r + i)) & ((1ULL << (8 * (len - i))) - 1ULL);
+                if (!diff) { t.slotof[j] = (uint32_t)slot; atomicAdd(&t.cnt[slot], 1u); return; }
+            }
+        }
+    }
+    *t.overflow = 2;
 }
-
-// ---- long phrases (e.g. a 10 Mbp run of N is ONE phrase: wang_hash(0) % 100 != 0) ----
-// A host-built chunk table spreads every long phrase over workgroups of LONG_CHUNK bytes.
-constexpr uint32_t LONG_CHUNK = 16384;   // a multiple of 8: chunks hold whole fingerprint words
-struct LongChunk { tpos_t a_off, b_off; uint32_t item; uint32_t len; }; // item index, two Y offsets of the chunk, chunk length
-
-// spans of listed phrases: out[2k] = ys, out[2k+1] = len
-__global__ __launch_bounds__(BLOCK) void k_list_spans(Spans sp, const uint32_t *list, uint32_t cnt, tpos_t *out)
-{
-    const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
-    if (k >= cnt) return;
-    tpos_t ys; uint32_t len; phrase_span(sp, list[k], &ys, &len);
-    out[2 * k] = ys; out[2 * k + 1] = len;
-}
-// same for the two phrases of each listed sorted position i: (vals[i-1], vals[i]); out[3k..] = ys_a, ys_b, len
-__global__ __launch_bounds__(BLOCK) void k_pair_spans(Spans sp, const uint32_t *vals, const uint32_t *list, uint32_t cnt, tpos_t *out)
-{
-    const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
-    if (k >= cnt) return;
-    const uint32_t i = list[k];
-    tpos_t sa_, sb; uint32_t la, lb;
-    phrase_span(sp, vals[i - 1], &sa_, &la);
-    phrase_span(sp, vals[i], &sb, &lb);
-    out[3 * k] = sa_; out[3 * k + 1] = sb; out[3 * k + 2] = la;
-}
-// one workgroup per chunk: polynomial hash of Y[a_off .. a_off+len)
-__global__ __launch_bounds__(BLOCK) void k_phrase_hash_long(const uint8_t *Y, const LongChunk *chunks, uint64_t B, uint64_t *partial)
+// ---- long phrases (e.g. a 10 Mbp run of N is ONE phrase: wang_hash(0) % 100 != 0): one workgroup
+// per phrase hashes and compares it cooperatively; thread 0 walks the probe sequence
+__global__ __launch_bounds__(BLOCK) void k_dedup_insert_long(const uint8_t *Y, Spans sp, const uint32_t *longlist, uint64_t seed, DedupTable t)
 {
     __shared__ uint64_t part[BLOCK];
-    const LongChunk ch = chunks[blockIdx.x];
-    const uint32_t sub = (((ch.len + BLOCK - 1) / BLOCK) + 7u) & ~7u;   // bytes per thread: whole words
-    const uint32_t a = threadIdx.x * sub, b = (a + sub < ch.len) ? a + sub : ch.len;
-    part[threadIdx.x] = a < ch.len ? hash_words(Y + ch.a_off + a, b - a, B) : 0;
+    __shared__ unsigned long long s_cur, s_h;
+    __shared__ int s_state;                                  // 0: next probe, 1: done, 2: compare with the entry's representative
+    __shared__ uint32_t s_diff;
+    const uint32_t j = longlist[blockIdx.x];
+    tpos_t ys; uint32_t len; phrase_span(sp, j, &ys, &len);
+    {   // thread t chains the 8-byte words t, t + 256, t + 512, ... (coalesced reads), thread 0 folds the 256 partial hashes
+        uint64_t hp = seed + threadIdx.x;
+        for (uint64_t k = 8ULL * threadIdx.x; k < len; k += 8ULL * BLOCK) {
+            uint64_t v = ld8(Y + ys + k);
+            if (len - k < 8) v &= (1ULL << (8 * (len - k))) - 1ULL;
+            hp = (hp ^ v) * 0xD6E8FEB86659FD93ULL; hp ^= hp >> 32;
+        }
+        part[threadIdx.x] = hp;
+    }
+    if (threadIdx.x == 0) s_diff = 0;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const uint64_t Bc = powmod61(B, sub / 8);
-        uint64_t acc = 0;
-        for (uint32_t t = 0; t < BLOCK; ++t) {
-            const uint32_t ta = t * sub; if (ta >= ch.len) break;
-            const uint32_t tl = (ta + sub < ch.len ? ta + sub : ch.len) - ta;
-            acc = addmod61(mulmod61(acc, tl == sub ? Bc : powmod61(B, (tl + 7) / 8)), part[t]);
+    if (threadIdx.x == 0) { uint64_t hh = seed ^ len; for (int k = 0; k < BLOCK; ++k) hh = mix64(hh ^ part[k]); s_h = hh; }
+    __syncthreads();
+    const uint64_t h = s_h;
+    const uint64_t filt = h >> 32;
+    uint64_t slot = h & t.mask;
+    for (uint32_t probe = 0; probe < HT_MAX_PROBES; ++probe) {
+        if (threadIdx.x == 0) {
+            int st = 0;
+            unsigned long long cur = t.tab[slot];
+            if (cur == HT_EMPTY) {
+                if (*t.overflow) st = 1;
+                else {
+                    cur = atomicCAS(&t.tab[slot], (unsigned long long)HT_EMPTY, (unsigned long long)((filt << 32) | j));
+                    if (cur == HT_EMPTY) {
+                        const uint32_t k = atomicAdd(t.nd, 1u);
+                        if (k >= t.limit) *t.overflow = 1;
+                        else { t.dslot[k] = (uint32_t)slot; t.dhash[k] = h; t.slotof[j] = (uint32_t)slot; atomicAdd(&t.cnt[slot], 1u); }
+                        st = 1;
+                    }
+                }
+            }
+            if (!st && (cur >> 32) == filt) st = 2;
+            s_cur = cur; s_state = st;
         }
-        partial[blockIdx.x] = acc;
-    }
-}
-// one thread per long phrase folds its chunks (consecutive in the table, first chunk index in first[])
-__global__ __launch_bounds__(BLOCK) void k_phrase_hash_fold(const LongChunk *chunks, const uint32_t *first, const uint32_t *longlist, uint32_t nlong,
-                                                            const tpos_t *spans, const uint64_t *partial, uint64_t B, uint64_t Bchunk, uint64_t *keys)
-{
-    const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
-    if (k >= nlong) return;
-    uint64_t acc = 0;
-    for (uint32_t c = first[k]; c < first[k + 1]; ++c) acc = addmod61(mulmod61(acc, chunks[c].len == LONG_CHUNK ? Bchunk : powmod61(B, (chunks[c].len + 7) / 8)), partial[c]);
-    keys[longlist[k]] = addmod61(mulmod61(acc, B), (uint64_t)spans[2 * k + 1] % P61);
-}
-// one workgroup per chunk of a long pair: byte compare
-__global__ __launch_bounds__(BLOCK) void k_dedup_long(const uint8_t *Y, const LongChunk *chunks, uint32_t *collide)
-{
-    const LongChunk ch = chunks[blockIdx.x];
-    uint32_t diff = 0;
-    for (uint32_t k = threadIdx.x; k < ch.len; k += BLOCK) diff |= (uint32_t)(Y[ch.a_off + k] ^ Y[ch.b_off + k]);
-    if (diff) atomicAdd(collide, 1u);
-}
-
-// After sorting (key, j): head[i] = 1 where a new distinct phrase starts.  Equal fingerprints are
-// verified byte-for-byte against the predecessor; a mismatch (fingerprint collision) raises *collide.
-// DEDUP_LANES lanes share one pair: each reads 8 bytes of both phrases per step, so that a pair of ~100-byte phrases is
-// two coalesced 64-byte reads per phrase instead of a dozen dependent 8-byte reads by one lane.
-constexpr int DEDUP_LANES = 8;
-__global__ __launch_bounds__(BLOCK) void k_dedup_heads(const uint8_t *Y, Spans sp, const uint64_t *keys, const uint32_t *vals,
-                                                       uint64_t m, uint32_t *head, uint32_t *longpairs, uint32_t *nlongpairs, uint32_t *collide)
-{
-    const uint64_t i = ((uint64_t)blockIdx.x * BLOCK + threadIdx.x) / DEDUP_LANES;
-    const uint32_t l = threadIdx.x % DEDUP_LANES;
-    bool cmp = false;
-    tpos_t sa_ = 0, sb = 0; uint32_t la = 0, lb = 0;
-    if (i < m) {
-        if (i == 0 || keys[i] != keys[i - 1]) { if (l == 0) head[i] = 1; }
-        else {
-            phrase_span(sp, vals[i - 1], &sa_, &la);
-            phrase_span(sp, vals[i], &sb, &lb);
-            if (la != lb) { if (l == 0) { head[i] = 1; atomicAdd(collide, 1u); } }
-            else if (la > LONG_PHRASE) { if (l == 0) { head[i] = 0; longpairs[atomicAdd(nlongpairs, 1u)] = (uint32_t)i; } }
-            else cmp = true;
+        __syncthreads();
+        const int st = s_state;
+        if (st == 1) return;
+        if (st == 2) {
+            tpos_t rs; uint32_t rlen; phrase_span(sp, (uint32_t)s_cur, &rs, &rlen);
+            if (rlen != len) { if (threadIdx.x == 0) s_diff = 1; }
+            else {
+                uint64_t d = 0;
+                for (uint64_t k = 8ULL * threadIdx.x; k < len; k += 8ULL * BLOCK) {
+                    uint64_t v = ld8(Y + ys + k) ^ ld8(Y + rs + k);
+                    if (len - k < 8) v &= (1ULL << (8 * (len - k))) - 1ULL;
+                    d |= v;
+                }
+                if (d) s_diff = 1;
+            }
+            __syncthreads();
+            const bool same = s_diff == 0;
+            __syncthreads();
+            if (same) { if (threadIdx.x == 0) { t.slotof[j] = (uint32_t)slot; atomicAdd(&t.cnt[slot], 1u); } return; }
+            if (threadIdx.x == 0) s_diff = 0;
         }
+        slot = (slot + 1) & t.mask;
+        __syncthreads();
     }
-    uint64_t diff = 0;
-    if (cmp) {
-        const uint8_t *a = Y + sa_, *b = Y + sb;
-        for (uint32_t k = 8 * l; k < la; k += 8 * DEDUP_LANES) {
-            uint64_t v = ld8(a + k) ^ ld8(b + k);
-            if (la - k < 8) v &= (1ULL << (8 * (la - k))) - 1ULL;
-            diff |= v;
-        }
-    }
-    const unsigned long long bm = __ballot(diff != 0);
-    if (cmp && l == 0) {
-        const bool differ = ((bm >> ((threadIdx.x & 63) / DEDUP_LANES * DEDUP_LANES)) & ((1ULL << DEDUP_LANES) - 1ULL)) != 0;
-        head[i] = differ ? 1u : 0u;
-        if (differ) atomicAdd(collide, 1u);
-    }
+    if (threadIdx.x == 0) *t.overflow = 2;
 }
-__global__ __launch_bounds__(BLOCK) void k_dedup_ids(const uint32_t *head, uint32_t *ex, uint64_t m)
+// ids = position of an entry's hash among the sorted hashes of the entries in use (deterministic whatever thread created
+// the entry): rep[id] = its representative phrase, occw[id] = its occurrences; the entry then holds the id
+__global__ __launch_bounds__(BLOCK) void k_dedup_assign(const uint32_t *order, uint64_t nd, DedupTable t, uint32_t *rep, uint32_t *occw)
 {
     const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i < m) ex[i] = ex[i] + head[i] - 1u;
+    if (i >= nd) return;
+    const uint32_t slot = t.dslot[order[i]];
+    rep[i] = (uint32_t)t.tab[slot]; occw[i] = t.cnt[slot];
+    t.tab[slot] = (unsigned long long)i;
 }
-// per sorted slot i: id[i] = (inclusive scan of head) - 1 is already in `ids`.  Scatter the word table.
-__global__ __launch_bounds__(BLOCK) void k_dedup_scatter(const uint32_t *vals, const uint32_t *head, const uint32_t *ids, uint64_t m,
-                                                         uint32_t *pid, uint32_t *rep, uint32_t *headpos)
+__global__ __launch_bounds__(BLOCK) void k_dedup_ids(const unsigned long long *tab, const uint32_t *slotof, uint64_t m, uint32_t *pid)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (j < m) pid[j] = (uint32_t)tab[slotof[j]];
+}
+__global__ __launch_bounds__(BLOCK) void k_iota_u32(uint32_t *v, uint64_t n)
 {
     const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= m) return;
-    const uint32_t id = ids[i];
-    pid[vals[i]] = id;
-    if (head[i]) { rep[id] = vals[i]; headpos[id] = (uint32_t)i; }
+    if (i < n) v[i] = (uint32_t)i;
 }
-// wlen1[id] = phrase length + 1 (EndOfWord); occ'[id] = class size
-__global__ __launch_bounds__(BLOCK) void k_word_lengths(Spans sp, const uint32_t *rep, const uint32_t *headpos, uint64_t dwords, uint64_t m,
-                                                        uint32_t *wlen1, uint32_t *occw)
+// wlen1[id] = phrase length + 1 (EndOfWord)
+__global__ __launch_bounds__(BLOCK) void k_word_lengths(Spans sp, const uint32_t *rep, uint64_t dwords, uint32_t *wlen1)
 {
     const uint64_t id = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (id >= dwords) return;
     tpos_t ys; uint32_t len; phrase_span(sp, rep[id], &ys, &len);
     wlen1[id] = len + 1;
-    occw[id] = (id + 1 < dwords ? headpos[id + 1] : (uint32_t)m) - headpos[id];
 }
 
 __device__ __forceinline__ uint32_t upper_bound_u32(const uint32_t *a, uint32_t n, uint32_t x)

@@ -6,6 +6,8 @@
 #include "parse.h"
 #include "sufsort.h"
 #include "emit.h"
+#include "markers.h"
+#include <map>
 
 using namespace pfp;
 
@@ -60,6 +62,7 @@ static void reset_results(pfp_ctx *c)
     c->stage = 0; c->n = 0; c->m = c->dwords = c->dsize = 0; c->nrows = 0; c->nout = c->runs = c->esa_pairs = 0;
     c->gsa_valid = false; c->d_wrank = nullptr; c->d_bwt = nullptr; c->d_sa = c->d_ssa = c->d_esa = nullptr;
     c->d_bwlast = nullptr; c->d_ilist = nullptr; c->d_bwsai = nullptr;
+    c->d_ma = nullptr; c->ma_words = 0;
     c->arena.reset();
 }
 
@@ -266,110 +269,74 @@ static int sort_dict_suffixes(pfp_ctx *c)
     return PFP_OK;
 }
 
-// ---- long phrases: host-built chunk tables (phrases longer than LONG_PHRASE are rare) ----------------
-static int hash_long_phrases(pfp_ctx *c, const uint8_t *Y, Spans sp, const uint32_t *d_longlist, uint32_t nlong, uint64_t B, uint64_t *keys)
+// De-duplicates the m byte strings described by (Y, sp) -- the std::map of pfparser.hpp:69-70, 595-597 -- exactly, with a
+// hash table of representatives (parse.h).  Outputs: number of distinct strings, d_id[j] = id of string j (ids follow the
+// sorted hashes of the distinct strings), rep[id] = a string with that id, occw[id] = how many strings have it.
+static int dedup_strings(pfp_ctx *c, const uint8_t *Y, Spans sp, uint64_t m, uint64_t total_bytes, uint32_t *d_id, uint64_t *ndistinct, uint32_t **rep_out, uint32_t **occw_out)
 {
-    const size_t mk = c->arena.mark_hi();
-    tpos_t *d_spans; PFP_ALLOC_HI(c, d_spans, tpos_t, 2 * (size_t)nlong);
-    PFP_LAUNCH(c, K_MISC, nlong * 16, k_list_spans, nblocks(nlong, BLOCK), sp, d_longlist, nlong, d_spans);
-    std::vector<tpos_t> spans(2 * (size_t)nlong);
-    PFP_HIP(c, hipMemcpyAsync(spans.data(), d_spans, spans.size() * sizeof(tpos_t), hipMemcpyDeviceToHost, c->stream));
-    PFP_HIP(c, hipStreamSynchronize(c->stream));
-    std::vector<LongChunk> tab; std::vector<uint32_t> first(nlong + 1);
-    for (uint32_t k = 0; k < nlong; ++k) {
-        first[k] = (uint32_t)tab.size();
-        const tpos_t ys = spans[2 * k]; const uint32_t len = (uint32_t)spans[2 * k + 1];
-        for (uint32_t a = 0; a < len; a += LONG_CHUNK) tab.push_back({ys + a, (tpos_t)0, k, (len - a < LONG_CHUNK) ? len - a : LONG_CHUNK});
-    }
-    first[nlong] = (uint32_t)tab.size();
-    LongChunk *d_tab; uint32_t *d_first; uint64_t *d_part;
-    PFP_ALLOC_HI(c, d_tab, LongChunk, tab.size()); PFP_ALLOC_HI(c, d_first, uint32_t, first.size()); PFP_ALLOC_HI(c, d_part, uint64_t, tab.size());
-    PFP_HIP(c, hipMemcpyAsync(d_tab, tab.data(), tab.size() * sizeof(LongChunk), hipMemcpyHostToDevice, c->stream));
-    PFP_HIP(c, hipMemcpyAsync(d_first, first.data(), first.size() * 4, hipMemcpyHostToDevice, c->stream));
-    double bytes = 0; for (auto &t : tab) bytes += t.len;
-    PFP_LAUNCH(c, K_PHRASE_HASH_LONG, bytes, k_phrase_hash_long, (unsigned)tab.size(), Y, (const LongChunk *)d_tab, B, d_part);
-    PFP_LAUNCH(c, K_MISC, tab.size() * 24, k_phrase_hash_fold, nblocks(nlong, BLOCK), (const LongChunk *)d_tab, (const uint32_t *)d_first, d_longlist, nlong,
-               (const tpos_t *)d_spans, (const uint64_t *)d_part, B, powmod61(B, LONG_CHUNK / 8), keys);
-    PFP_HIP(c, hipStreamSynchronize(c->stream));   // tab / first are host vectors
-    c->arena.release_hi(mk);
-    return PFP_OK;
-}
-static int compare_long_pairs(pfp_ctx *c, const uint8_t *Y, Spans sp, const uint32_t *d_vals, const uint32_t *d_pairs, uint32_t np, uint32_t *d_collide)
-{
-    const size_t mk = c->arena.mark_hi();
-    tpos_t *d_spans; PFP_ALLOC_HI(c, d_spans, tpos_t, 3 * (size_t)np);
-    PFP_LAUNCH(c, K_MISC, np * 24, k_pair_spans, nblocks(np, BLOCK), sp, d_vals, d_pairs, np, d_spans);
-    std::vector<tpos_t> spans(3 * (size_t)np);
-    PFP_HIP(c, hipMemcpyAsync(spans.data(), d_spans, spans.size() * sizeof(tpos_t), hipMemcpyDeviceToHost, c->stream));
-    PFP_HIP(c, hipStreamSynchronize(c->stream));
-    std::vector<LongChunk> tab;
-    for (uint32_t k = 0; k < np; ++k) {
-        const tpos_t sa_ = spans[3 * k], sb = spans[3 * k + 1]; const uint32_t len = (uint32_t)spans[3 * k + 2];
-        for (uint32_t a = 0; a < len; a += LONG_CHUNK) tab.push_back({sa_ + a, sb + a, k, (len - a < LONG_CHUNK) ? len - a : LONG_CHUNK});
-    }
-    LongChunk *d_tab; PFP_ALLOC_HI(c, d_tab, LongChunk, tab.size());
-    PFP_HIP(c, hipMemcpyAsync(d_tab, tab.data(), tab.size() * sizeof(LongChunk), hipMemcpyHostToDevice, c->stream));
-    double bytes = 0; for (auto &t : tab) bytes += 2.0 * t.len;
-    PFP_LAUNCH(c, K_DEDUP_LONG, bytes, k_dedup_long, (unsigned)tab.size(), Y, (const LongChunk *)d_tab, d_collide);
-    PFP_HIP(c, hipStreamSynchronize(c->stream));
-    c->arena.release_hi(mk);
-    return PFP_OK;
-}
-
-// De-duplicates the m byte strings described by (Y, sp) -- the std::map of pfparser.hpp:69-70, 595-597:
-// fingerprints, stable sort by fingerprint, byte-for-byte verification of equal fingerprints (a collision
-// restarts with another multiplier).  Outputs: number of distinct strings, d_id[j] = id of string j
-// (ids follow fingerprint order), rep[id] = first string with that id, headpos[id] (scratch for class sizes).
-static int dedup_strings(pfp_ctx *c, const uint8_t *Y, Spans sp, uint64_t m, uint64_t total_bytes, uint32_t *d_id, uint64_t *ndistinct, uint32_t **rep_out, uint32_t **headpos_out)
-{
-    uint64_t *hk0, *hk1; uint32_t *hv0, *hv1, *longlist, *head, *ex, *longpairs, *d_u32;
-    PFP_ALLOC_HI(c, hk0, uint64_t, m); PFP_ALLOC_HI(c, hk1, uint64_t, m);
-    PFP_ALLOC_HI(c, hv0, uint32_t, m); PFP_ALLOC_HI(c, hv1, uint32_t, m);
+    uint32_t *longlist, *d_u32, *slotof;
     const uint64_t maxlong = total_bytes / LONG_PHRASE + 2;
     PFP_ALLOC_HI(c, longlist, uint32_t, maxlong);
-    PFP_ALLOC_HI(c, longpairs, uint32_t, maxlong);
-    PFP_ALLOC_HI(c, head, uint32_t, m);
-    PFP_ALLOC_HI(c, ex, uint32_t, m);
     PFP_ALLOC_HI(c, d_u32, uint32_t, 8);
-    uint64_t *sk = nullptr; uint32_t *sv = nullptr;
+    PFP_ALLOC_HI(c, slotof, uint32_t, m);
     const unsigned gm = nblocks(m, BLOCK);
+    static const int force_small = getenv("PFP_DEDUP_TABLE_LOG2") ? atoi(getenv("PFP_DEDUP_TABLE_LOG2")) : 0;      // tests: a first table that overflows
+    DedupTable t; uint32_t nd = 0;
     for (int attempt = 0;; ++attempt) {
-        if (attempt == 8) return PFP_E_CORRUPT;
-        // multiplier in [2^32, P61): a fresh one per attempt
-        uint64_t B = (c->hash_seed + 0x9E3779B97F4A7C15ULL * (uint64_t)(attempt + 1));
-        B ^= B >> 31; B *= 0xD6E8FEB86659FD93ULL; B ^= B >> 29;
-        B = (B % (P61 - (1ULL << 32))) + (1ULL << 32);
+        if (attempt == 2) return PFP_E_CORRUPT;
+        const size_t mk = c->arena.mark_hi();
+        // first guess: a collection is repetitive (distinct strings << strings); if more than half of that table fills up, the
+        // second table holds twice the number of strings, which cannot overflow
+        uint64_t want = attempt == 0 ? m / 4 : 2 * m;
+        int lg = 20; while ((1ULL << lg) < want) ++lg;        // at least 2^20 entries: a text of up to half a million phrases never retries
+        if (attempt == 0 && force_small) lg = force_small;
+        const uint64_t T = 1ULL << lg;
+        const uint64_t limit = T >= 2 * m ? m + 1 : T / 2;
+        if (limit >= 0xFFFFFFFFULL) return PFP_E_TOO_LARGE;
+        PFP_ALLOC_HI(c, t.tab, unsigned long long, T); PFP_ALLOC_HI(c, t.cnt, uint32_t, T); PFP_ALLOC_HI(c, t.rinfo, unsigned long long, T);
+        PFP_ALLOC_HI(c, t.dslot, uint32_t, limit); PFP_ALLOC_HI(c, t.dhash, uint64_t, limit);
+        t.mask = T - 1; t.slotof = slotof; t.nd = d_u32; t.limit = (uint32_t)limit; t.overflow = d_u32 + 1;
+        PFP_HIP(c, hipMemsetAsync(t.tab, 0xFF, T * 8, c->stream));
+        PFP_HIP(c, hipMemsetAsync(t.cnt, 0, T * 4, c->stream));
+        PFP_HIP(c, hipMemsetAsync(t.rinfo, 0, T * 8, c->stream));
         PFP_HIP(c, hipMemsetAsync(d_u32, 0, 32, c->stream));
-        PFP_LAUNCH(c, K_PHRASE_HASH, total_bytes + m * 12, k_phrase_hash, gm, Y, sp, m, B, hk0, hv0, longlist, d_u32 + 1);
-        uint32_t nlong = 0; PFP_TRY(d2h_u32(c, d_u32 + 1, &nlong));
-        if (nlong) PFP_TRY(hash_long_phrases(c, Y, sp, longlist, nlong, B, hk0));
-        BitRange full = {0, 64};
-        PFP_TRY(radix_sort_pairs<uint64_t>(c, hk0, hv0, hk1, hv1, m, &full, 1, &sk, &sv));
-        PFP_LAUNCH(c, K_DEDUP_HEADS, total_bytes + m * 16, k_dedup_heads, nblocks(m * DEDUP_LANES, BLOCK), Y, sp, (const uint64_t *)sk, (const uint32_t *)sv, m, head, longpairs, d_u32 + 2, d_u32 + 3);
-        uint32_t nlp = 0; PFP_TRY(d2h_u32(c, d_u32 + 2, &nlp));
-        if (nlp) PFP_TRY(compare_long_pairs(c, Y, sp, sv, longpairs, nlp, d_u32 + 3));
-        uint32_t collide = 0; PFP_TRY(d2h_u32(c, d_u32 + 3, &collide));
-        if (!collide) break;
+        PFP_LAUNCH(c, K_PHRASE_HASH, 2 * total_bytes + m * 24, k_dedup_insert, gm, Y, sp, m, c->hash_seed, t, longlist, d_u32 + 2);
+        uint32_t h3[3];
+        PFP_HIP(c, hipMemcpyAsync(h3, d_u32, 12, hipMemcpyDeviceToHost, c->stream));
+        PFP_HIP(c, hipStreamSynchronize(c->stream));
+        if (!h3[1] && h3[2]) {
+            PFP_LAUNCH(c, K_PHRASE_HASH_LONG, 2.0 * total_bytes / 64, k_dedup_insert_long, h3[2], Y, sp, (const uint32_t *)longlist, c->hash_seed, t);
+            PFP_HIP(c, hipMemcpyAsync(h3, d_u32, 12, hipMemcpyDeviceToHost, c->stream));
+            PFP_HIP(c, hipStreamSynchronize(c->stream));
+        }
+        if (!h3[1]) { nd = h3[0]; break; }
+        static const bool verbose = getenv("PFP_VERBOSE") != nullptr;
+        if (verbose) fprintf(stderr, "[pfbwt_hip] phrase table of 2^%d entries overflowed (%u distinct so far, state %u): retry\n", lg, h3[0], h3[1]);
+        c->arena.release_hi(mk);
     }
-    PFP_TRY((device_scan<uint32_t, 0>(c, head, ex, m, d_u32 + 4)));
-    uint32_t dw32 = 0; PFP_TRY(d2h_u32(c, d_u32 + 4, &dw32));
-    uint32_t *rep, *headpos;
-    PFP_ALLOC_HI(c, rep, uint32_t, dw32); PFP_ALLOC_HI(c, headpos, uint32_t, (size_t)dw32 + 1);
-    // ids[i] = ex[i] + head[i] - 1 (0-based id of the distinct string, in fingerprint order)
-    PFP_LAUNCH(c, K_MISC, m * 12, k_dedup_ids, gm, (const uint32_t *)head, ex, m);
-    PFP_LAUNCH(c, K_MISC, m * 20, k_dedup_scatter, gm, (const uint32_t *)sv, (const uint32_t *)head, (const uint32_t *)ex, m, d_id, rep, headpos);
-    *ndistinct = dw32; *rep_out = rep; *headpos_out = headpos;
+    // ids in the order of the hashes of the distinct strings
+    uint64_t *k1, *sk; uint32_t *v0, *v1, *sv, *rep, *occw;
+    PFP_ALLOC_HI(c, rep, uint32_t, (size_t)nd + 1); PFP_ALLOC_HI(c, occw, uint32_t, (size_t)nd + 1);
+    const size_t mk2 = c->arena.mark_hi();
+    PFP_ALLOC_HI(c, k1, uint64_t, nd); PFP_ALLOC_HI(c, v0, uint32_t, nd); PFP_ALLOC_HI(c, v1, uint32_t, nd);
+    PFP_LAUNCH(c, K_MISC, nd * 4, k_iota_u32, nblocks(nd, BLOCK), v0, (uint64_t)nd);
+    BitRange full = {0, 64};
+    PFP_TRY(radix_sort_pairs<uint64_t>(c, t.dhash, v0, k1, v1, nd, &full, 1, &sk, &sv));
+    PFP_LAUNCH(c, K_DEDUP_HEADS, (uint64_t)nd * 40, k_dedup_assign, nblocks(nd, BLOCK), (const uint32_t *)sv, (uint64_t)nd, t, rep, occw);
+    PFP_LAUNCH(c, K_DEDUP_HEADS, m * 16, k_dedup_ids, gm, (const unsigned long long *)t.tab, (const uint32_t *)slotof, m, d_id);
+    c->arena.release_hi(mk2);
+    *ndistinct = nd; *rep_out = rep; *occw_out = occw;
     return PFP_OK;
 }
 
 // The dictionary D' (distinct strings in id order, each + EndOfWord, then EndOfDict), its word starts and the
-// word id of every offset.  occw[id] = number of input strings with that id.
-static int build_dictionary(pfp_ctx *c, const uint8_t *Y, Spans sp, const uint32_t *rep, const uint32_t *headpos, uint64_t dwords, uint64_t m, uint32_t **occw_out)
+// word id of every offset.
+static int build_dictionary(pfp_ctx *c, const uint8_t *Y, Spans sp, const uint32_t *rep, uint64_t dwords)
 {
-    uint32_t *wlen1, *occw; tpos_t *srcstart;
-    PFP_ALLOC_HI(c, wlen1, uint32_t, dwords); PFP_ALLOC_HI(c, occw, uint32_t, dwords); PFP_ALLOC_HI(c, srcstart, tpos_t, dwords);
+    uint32_t *wlen1; tpos_t *srcstart;
+    PFP_ALLOC_HI(c, wlen1, uint32_t, dwords); PFP_ALLOC_HI(c, srcstart, tpos_t, dwords);
     const unsigned gd = nblocks(dwords, BLOCK);
-    PFP_LAUNCH(c, K_MISC, dwords * 16, k_word_lengths, gd, sp, rep, headpos, dwords, m, wlen1, occw);
+    PFP_LAUNCH(c, K_MISC, dwords * 16, k_word_lengths, gd, sp, rep, dwords, wlen1);
     PFP_ALLOC_LO(c, c->d_ws, uint32_t, dwords + 1);
     PFP_TRY((device_scan<uint32_t, 0>(c, wlen1, c->d_ws, dwords, c->d_ws + dwords)));
     uint32_t dsm1 = 0; PFP_TRY(d2h_u32(c, c->d_ws + dwords, &dsm1));
@@ -380,7 +347,6 @@ static int build_dictionary(pfp_ctx *c, const uint8_t *Y, Spans sp, const uint32
     PFP_ALLOC_LO(c, c->d_wordid, uint32_t, dsize);
     PFP_LAUNCH(c, K_MISC, dwords * 12, k_rep_starts, gd, sp, rep, dwords, srcstart);
     PFP_LAUNCH(c, K_DICT_BUILD, dsize * 6, k_dict_build, nblocks(dsize, 16 * BLOCK), Y, (const tpos_t *)srcstart, (const uint32_t *)c->d_ws, (uint32_t)dwords, dsize, c->d_dict, c->d_wordid);
-    *occw_out = occw;
     return PFP_OK;
 }
 
@@ -497,11 +463,11 @@ static int parse_finalize_impl(pfp_ctx *c, pfp_parse_sizes *out)
 
     // 2. distinct phrases, dictionary
     Spans sp; sp.ye = c->d_ye; sp.ys32 = nullptr; sp.ye32 = nullptr; sp.w = w;
-    uint64_t dwords = 0; uint32_t *rep, *headpos, *occw;
+    uint64_t dwords = 0; uint32_t *rep, *occw;
     PFP_ALLOC_LO(c, c->d_pid, uint32_t, m);
     PFP_ALLOC_LO(c, c->d_last, uint8_t, m);
-    PFP_TRY(dedup_strings(c, Y, sp, m, n + (uint64_t)w + 1 + m * (uint64_t)w, c->d_pid, &dwords, &rep, &headpos));
-    PFP_TRY(build_dictionary(c, Y, sp, rep, headpos, dwords, m, &occw));
+    PFP_TRY(dedup_strings(c, Y, sp, m, n + (uint64_t)w + 1 + m * (uint64_t)w, c->d_pid, &dwords, &rep, &occw));
+    PFP_TRY(build_dictionary(c, Y, sp, rep, dwords));
     PFP_LAUNCH(c, K_MISC, m * 6, k_last_chars, nblocks(m, BLOCK), Y, (const tpos_t *)c->d_ye, m, w, c->d_last);
     // 3. dictionary suffix sort, ranks, occ, parse, sorted .dict image
     PFP_TRY(finish_parse(c, occw));
@@ -619,7 +585,7 @@ static int merge_shards_impl(pfp_ctx *c, int nshards, const pfp_shard_view *v, p
     }
     // ---- device: one buffer with all dictionaries + junction words, candidate spans
     uint8_t *U; uint32_t *cys, *cye, *cand_id;
-    PFP_ALLOC_HI(c, U, uint8_t, dtot + junc.size() + 16);
+    PFP_ALLOC_HI(c, U, uint8_t, dtot + junc.size() + 64);
     PFP_ALLOC_HI(c, cys, uint32_t, ctot); PFP_ALLOC_HI(c, cye, uint32_t, ctot); PFP_ALLOC_HI(c, cand_id, uint32_t, ctot);
     std::vector<uint32_t> ubase((size_t)nshards), coff((size_t)nshards);
     { uint64_t ub = 0, co = 0; for (int r = 0; r < nshards; ++r) { ubase[r] = (uint32_t)ub; coff[r] = (uint32_t)co; ub += v[r].dsize; co += v[r].dwords; } }
@@ -634,9 +600,9 @@ static int merge_shards_impl(pfp_ctx *c, int nshards, const pfp_shard_view *v, p
     }
     // ---- global distinct words, dictionary
     Spans sp; sp.ye = nullptr; sp.ys32 = cys; sp.ye32 = cye; sp.w = 0;
-    uint64_t dwords = 0; uint32_t *rep, *headpos, *occ_cand, *occw;
-    PFP_TRY(dedup_strings(c, U, sp, ctot, dtot + junc.size(), cand_id, &dwords, &rep, &headpos));
-    PFP_TRY(build_dictionary(c, U, sp, rep, headpos, dwords, ctot, &occ_cand));
+    uint64_t dwords = 0; uint32_t *rep, *occ_cand, *occw;
+    PFP_TRY(dedup_strings(c, U, sp, ctot, dtot + junc.size(), cand_id, &dwords, &rep, &occ_cand));
+    PFP_TRY(build_dictionary(c, U, sp, rep, dwords));
     // ---- global phrase sequence
     c->n = ntot; c->m = mtot;
     PFP_ALLOC_LO(c, c->d_pid, uint32_t, mtot); PFP_ALLOC_LO(c, c->d_ye, tpos_t, mtot); PFP_ALLOC_LO(c, c->d_last, uint8_t, mtot);
@@ -1252,10 +1218,103 @@ int pfp_bwt_device_ptrs(pfp_ctx *c, const void **d_bwt, const void **d_sa, const
     return PFP_OK;
 }
 
+// ---- marker-array post-pass (include/marker_array.hpp:138-174, src/mps_to_ma.cpp) ----------------------
+extern "C++" {
+template <typename SAT> static int marker_array_impl(pfp_ctx *c, const uint64_t *mps, uint64_t mps_words, const SAT *d_sa, uint64_t nrows, uint64_t *out_words)
+{
+    // host: the records of the .mps stream; every distinct marker list gets one id (the reference compares lists by content)
+    std::vector<uint64_t> istart, iend, lvals; std::vector<uint32_t> ilist, loff(1, 0u);
+    std::map<std::vector<uint64_t>, uint32_t> ids;
+    for (uint64_t i = 0; i < mps_words;) {
+        uint64_t j = i;
+        while (j < mps_words && mps[j] != ~0ULL) ++j;
+        if (j == mps_words || j - i < 2) return PFP_E_CORRUPT;                 // a record without its keys or its delimiter
+        if (!istart.empty() && (mps[i] <= iend.back() || mps[i + 1] < mps[i])) return PFP_E_CORRUPT;   // intervals ascend and do not overlap (rle_window_array.hpp:31-34)
+        std::vector<uint64_t> lst(mps + i + 2, mps + j);
+        auto it = ids.find(lst);
+        uint32_t id;
+        if (it != ids.end()) id = it->second;
+        else { id = (uint32_t)ids.size(); ids.emplace(lst, id); lvals.insert(lvals.end(), lst.begin(), lst.end()); loff.push_back((uint32_t)lvals.size()); }
+        // a record with an empty list answers at() like no record at all
+        if (!lst.empty()) { istart.push_back(mps[i]); iend.push_back(mps[i + 1]); ilist.push_back(id); }
+        i = j + 1;
+    }
+    if (istart.size() >= 0xFFFFFFF0ULL || lvals.size() >= 0xFFFFFFF0ULL) return PFP_E_TOO_LARGE;
+    const uint32_t nint = (uint32_t)istart.size();
+    const size_t mk = c->arena.mark_hi();
+    uint64_t *d_is, *d_ie, *d_lv; uint32_t *d_il, *d_lo, *rowlist, *head, *pos, *d_cnt;
+    PFP_ALLOC_HI(c, d_is, uint64_t, nint); PFP_ALLOC_HI(c, d_ie, uint64_t, nint); PFP_ALLOC_HI(c, d_il, uint32_t, nint);
+    PFP_ALLOC_HI(c, d_lo, uint32_t, loff.size()); PFP_ALLOC_HI(c, d_lv, uint64_t, lvals.size());
+    PFP_ALLOC_HI(c, rowlist, uint32_t, nrows); PFP_ALLOC_HI(c, head, uint32_t, nrows); PFP_ALLOC_HI(c, pos, uint32_t, nrows); PFP_ALLOC_HI(c, d_cnt, uint32_t, 1);
+    if (nint) {
+        PFP_HIP(c, hipMemcpyAsync(d_is, istart.data(), (size_t)nint * 8, hipMemcpyHostToDevice, c->stream));
+        PFP_HIP(c, hipMemcpyAsync(d_ie, iend.data(), (size_t)nint * 8, hipMemcpyHostToDevice, c->stream));
+        PFP_HIP(c, hipMemcpyAsync(d_il, ilist.data(), (size_t)nint * 4, hipMemcpyHostToDevice, c->stream));
+    }
+    PFP_HIP(c, hipMemcpyAsync(d_lo, loff.data(), loff.size() * 4, hipMemcpyHostToDevice, c->stream));
+    if (!lvals.empty()) PFP_HIP(c, hipMemcpyAsync(d_lv, lvals.data(), lvals.size() * 8, hipMemcpyHostToDevice, c->stream));
+    const unsigned gr = nblocks(nrows, BLOCK);
+    PFP_LAUNCH(c, K_MISC, nrows * (sizeof(SAT) + 4 + 40), (k_ma_lookup<SAT>), gr, d_sa, nrows, (const uint64_t *)d_is, (const uint64_t *)d_ie, (const uint32_t *)d_il, nint, rowlist);
+    PFP_LAUNCH(c, K_MISC, nrows * 8, k_ma_heads, gr, (const uint32_t *)rowlist, nrows, head);
+    PFP_TRY((device_scan<uint32_t, 0>(c, head, pos, nrows, d_cnt)));
+    uint32_t nh = 0; PFP_TRY(d2h_u32(c, d_cnt, &nh));          // also waits for the host vectors' uploads
+    uint64_t *hrow; uint32_t *hlist; unsigned long long *len, *off, *d_tot;
+    PFP_ALLOC_HI(c, hrow, uint64_t, nh); PFP_ALLOC_HI(c, hlist, uint32_t, nh); PFP_ALLOC_HI(c, len, unsigned long long, nh); PFP_ALLOC_HI(c, off, unsigned long long, nh); PFP_ALLOC_HI(c, d_tot, unsigned long long, 1);
+    PFP_LAUNCH(c, K_MISC, nrows * 12, k_ma_collect, gr, (const uint32_t *)rowlist, (const uint32_t *)head, (const uint32_t *)pos, nrows, hrow, hlist);
+    PFP_LAUNCH(c, K_MISC, (uint64_t)nh * 16, k_ma_lengths, nblocks(nh, BLOCK), (const uint32_t *)hlist, (const uint32_t *)d_lo, (uint64_t)nh, len);
+    PFP_TRY((device_scan<unsigned long long, 0>(c, len, off, nh, d_tot)));
+    unsigned long long tot = 0;
+    PFP_HIP(c, hipMemcpyAsync(&tot, d_tot, 8, hipMemcpyDeviceToHost, c->stream));
+    PFP_HIP(c, hipStreamSynchronize(c->stream));
+    c->d_ma = nullptr; c->ma_words = tot;
+    if (tot) {
+        uint64_t *d_out = (uint64_t *)c->arena.alloc_lo(tot * 8);               // result: low end, survives the release of the scratch
+        if (!d_out) return PFP_E_NOMEM;
+        PFP_LAUNCH(c, K_MISC, tot * 8, k_ma_write, nblocks(nh, BLOCK), (const uint64_t *)hrow, (const uint32_t *)hlist, (const unsigned long long *)off, (const uint32_t *)d_lo, (const uint64_t *)d_lv, (uint64_t)nh, nrows, d_out);
+        PFP_HIP(c, hipStreamSynchronize(c->stream));
+        c->d_ma = d_out;
+    }
+    c->arena.release_hi(mk);
+    if (out_words) *out_words = tot;
+    return PFP_OK;
+}
+} // extern "C++"
+
+int pfp_marker_array(pfp_ctx *c, const uint64_t *mps, uint64_t mps_words, const void *sa_host, uint64_t nrows, uint64_t *out_words)
+{
+    if (!c || (!mps && mps_words)) return PFP_E_ARG;
+    PFP_HIP(c, hipSetDevice(c->device));
+    const bool u64 = (c->flags & PFP_FLAG_U64) != 0;
+    ArenaGuard g(c);
+    if (!sa_host) {      // fused: the suffix array the last pfp_bwt_build(want_sa = 1) left on the device (whole output, not a slice)
+        if (c->stage < 3 || !c->d_sa || c->slice_rows != c->nout) return PFP_E_STATE;
+        return g.done(u64 ? marker_array_impl<uint64_t>(c, mps, mps_words, (const uint64_t *)c->d_sa, c->nout, out_words)
+                          : marker_array_impl<uint32_t>(c, mps, mps_words, (const uint32_t *)c->d_sa, c->nout, out_words));
+    }
+    if (!nrows) return PFP_E_ARG;      // stand-alone (src/mps_to_ma.cpp): the suffix array comes from a file or pipe
+    reset_results(c);
+    const size_t U = u64 ? 8 : 4;
+    int rc = ensure_arena(c, nrows);
+    if (rc != PFP_OK) return rc;
+    c->arena.reset();
+    void *d_sa = c->arena.alloc_hi(nrows * U);
+    if (!d_sa) return PFP_E_NOMEM;
+    rc = h2d_copy(c, (uint8_t *)d_sa, (const uint8_t *)sa_host, nrows * U);
+    if (rc != PFP_OK) return rc;
+    return u64 ? marker_array_impl<uint64_t>(c, mps, mps_words, (const uint64_t *)d_sa, nrows, out_words) : marker_array_impl<uint32_t>(c, mps, mps_words, (const uint32_t *)d_sa, nrows, out_words);
+}
+int pfp_marker_array_get(pfp_ctx *c, uint64_t *dst)
+{
+    if (!c || (!dst && c->ma_words)) return PFP_E_ARG;
+    if (c->ma_words && !c->d_ma) return PFP_E_STATE;
+    PFP_HIP(c, hipSetDevice(c->device));
+    if (c->ma_words) PFP_HIP(c, hipMemcpy(dst, c->d_ma, c->ma_words * 8, hipMemcpyDeviceToHost));
+    return PFP_OK;
+}
+
 // ---- development aid: position-weighted checksum of a device buffer (sum over bytes of (byte + 1) * mix(global position),
 // two independent mixes, modulo 2^64): the checksums of the pieces of a buffer add up to the checksum of the whole, so
 // outputs that live sliced over several builds / GPUs can be compared with a single-context output without moving them
-__device__ __forceinline__ uint64_t mix64(uint64_t z) { z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL; return z ^ (z >> 31); }
 __global__ __launch_bounds__(BLOCK) void k_checksum(const uint8_t *p, uint64_t bytes, uint64_t offset, unsigned long long *out)
 {
     __shared__ unsigned long long red[4];

@@ -79,6 +79,8 @@ def load_library(path=None):
     L.pfp_merge_shards.argtypes = [vp, i32, C.POINTER(ShardView), C.POINTER(ParseSizes)]
     L.pfp_sacak_int_u32.argtypes = [vp, vp, C.c_uint32, C.c_uint32]
     L.pfp_sacak_int_u64.argtypes = [vp, vp, u64, u64]
+    L.pfp_marker_array.argtypes = [vp, vp, u64, vp, u64, C.POINTER(u64)]
+    L.pfp_marker_array_get.argtypes = [vp, vp]
     L.pfp_gsacak_u32.argtypes = [vp, vp, vp, vp, C.c_uint32]
     L.pfp_gsacak_u64.argtypes = [vp, vp, vp, vp, u64]
     L.pfp_profile_enable.argtypes = [vp, i32]
@@ -232,6 +234,20 @@ class PfpContext:
         p = [C.c_void_p(0) for _ in range(4)]
         self._check(self.L.pfp_bwt_device_ptrs(self.h, *[C.byref(x) for x in p]))
         return [x.value for x in p]
+
+    def marker_array(self, mps, sa=None):
+        """marker-array post-pass (include/marker_array.hpp:138-174): the .ma stream (uint64 words) for the .mps stream `mps`;
+        sa=None: fused with the last bwt_build(sa=True) of this context, else the suffix array given (uint_t values, BWT order)"""
+        mps = np.ascontiguousarray(mps, np.uint64)
+        n = C.c_uint64(0)
+        if sa is None:
+            self._check(self.L.pfp_marker_array(self.h, _ptr(mps), mps.size, None, 0, C.byref(n)))
+        else:
+            sa = np.ascontiguousarray(sa, self.udt)
+            self._check(self.L.pfp_marker_array(self.h, _ptr(mps), mps.size, _ptr(sa), sa.size, C.byref(n)))
+        out = np.empty(n.value, np.uint64)
+        self._check(self.L.pfp_marker_array_get(self.h, _ptr(out) if n.value else None))
+        return out
 
     # ---- instrumentation
     def profile_enable(self, on=True):

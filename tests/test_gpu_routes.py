@@ -57,6 +57,8 @@ ENVS = [
     {"PFP_EMIT_CHUNK_ROWS": "7777", "PFP_SAMPLE_CAP": "40"},
     {"PFP_BIG_GROUP_MEMBERS": "1"},
     {"PFP_BIG_GROUP_MEMBERS": "2", "PFP_FORCE_WIDE_ROWS": "1", "PFP_EMIT_CHUNK_ROWS": "50000"},
+    {"PFP_DEDUP_TABLE_LOG2": "6", "PFP_NO_TRIGGER_TABLE": "1"},      # the phrase table overflows and is rebuilt; the trigger test by hashing every window
+    {"PFP_NO_RUNAWARE": "1", "PFP_EMIT_CHUNK_ROWS": "30000"},       # -r with every row enumerated (the route a full SA takes)
 ]
 
 
