@@ -88,6 +88,13 @@ int pfp_parse_feed_device(pfp_ctx *ctx, const void *d_bases, uint64_t len, int e
 /* `count` records of `len` bytes each, record k at d_bases + k*stride (device memory): the same as `count` calls of
  * pfp_parse_feed_device(.., len, 1), done as one strided copy (a collection of equal-length haplotypes) */
 int pfp_parse_feed_device_batch(pfp_ctx *ctx, const void *d_bases, uint64_t count, uint64_t len, uint64_t stride);
+/* Back to feeding with the text kept: after pfp_parse_finalize the (normalised) text is still on the device, more
+ * records can be appended and pfp_parse_finalize run again -- what PfParser::operator+= (pfparser.hpp:194-263) needs
+ * when the right-hand parse is appended as text (pfp_text_view of its context + pfp_parse_feed_device) instead of being
+ * merged phrase by phrase.  PFP_E_STATE for a context whose state came from pfp_merge_shards or pfp_bwt_load. */
+int pfp_parse_reopen(pfp_ctx *ctx);
+/* device pointer and length of the text fed so far (NULL / 0 when the context holds none) */
+int pfp_text_view(pfp_ctx *ctx, const uint8_t **d_text, uint64_t *n);
 /* PfParser::finalize pfparser.hpp:484-517 (+ process_phrase :595-601 for every phrase): trigger scan,
  * phrase de-duplication, dictionary sort, ranks, occ, last, sai.  Results stay on the device. */
 int pfp_parse_finalize(pfp_ctx *ctx, pfp_parse_sizes *out);

@@ -59,7 +59,7 @@ static int ensure_text(pfp_ctx *c, uint64_t need_n)
 
 static void reset_results(pfp_ctx *c)
 {
-    c->stage = 0; c->n = 0; c->m = c->dwords = c->dsize = 0; c->nrows = 0; c->nout = c->runs = c->esa_pairs = 0;
+    c->stage = 0; c->n = 0; c->tb_n = 0; c->m = c->dwords = c->dsize = 0; c->nrows = 0; c->nout = c->runs = c->esa_pairs = 0;
     c->gsa_valid = false; c->d_wrank = nullptr; c->d_bwt = nullptr; c->d_sa = c->d_ssa = c->d_esa = nullptr;
     c->d_bwlast = nullptr; c->d_ilist = nullptr; c->d_bwsai = nullptr;
     c->d_ma = nullptr; c->ma_words = 0;
@@ -169,10 +169,13 @@ static bool host_pointer_is_pinned(const void *p)
 }
 // host memory -> device: pinned sources directly, pageable ones through the staging ring (kseq's 16 KiB reads of
 // include/kseq.h:228 become 32 MiB DMA transfers; the memcpy into one buffer overlaps the transfer of the other)
-static int h2d_copy(pfp_ctx *c, uint8_t *dst, const uint8_t *src, uint64_t len)
+// *in_flight (nullable) = the caller's buffer may still be read when this returns (pinned source: the caller must wait for
+// the stream); copies through the staging ring are complete as far as the caller's buffer is concerned.
+static int h2d_copy(pfp_ctx *c, uint8_t *dst, const uint8_t *src, uint64_t len, bool *in_flight = nullptr)
 {
+    if (in_flight) *in_flight = false;
     if (!len) return PFP_OK;
-    if (host_pointer_is_pinned(src)) { PFP_HIP(c, hipMemcpyAsync(dst, src, (size_t)len, hipMemcpyHostToDevice, c->stream)); return PFP_OK; }
+    if (host_pointer_is_pinned(src)) { PFP_HIP(c, hipMemcpyAsync(dst, src, (size_t)len, hipMemcpyHostToDevice, c->stream)); if (in_flight) *in_flight = true; else PFP_HIP(c, hipStreamSynchronize(c->stream)); return PFP_OK; }
     if (len <= ((size_t)1 << 16)) { PFP_HIP(c, hipMemcpyAsync(dst, src, (size_t)len, hipMemcpyHostToDevice, c->stream)); PFP_HIP(c, hipStreamSynchronize(c->stream)); return PFP_OK; }
     for (int k = 0; k < 2; ++k) if (!c->hstage[k]) {
         PFP_HIP(c, hipHostMalloc((void **)&c->hstage[k], STAGE_BYTES, hipHostMallocDefault));
@@ -198,14 +201,39 @@ static int feed_common(pfp_ctx *c, const void *src, uint64_t len, int end_of_seq
     // pfparser.hpp:326-331: the 32-bit build stops at 2^32 bases; the 64-bit build here at 2^40 (device positions are 64-bit)
     if (c->n + add + (uint64_t)c->w + 64 >= ((c->flags & PFP_FLAG_U64) ? (1ULL << 40) : 0xFFFFFFFFULL)) return PFP_E_TOO_LARGE;
     PFP_TRY(ensure_text(c, c->n + add + (uint64_t)c->w));
-    if (len && kind == hipMemcpyHostToDevice) PFP_TRY(h2d_copy(c, c->tb + 16 + c->n, (const uint8_t *)src, len));
+    bool in_flight = false;
+    if (len && kind == hipMemcpyHostToDevice) PFP_TRY(h2d_copy(c, c->tb + 16 + c->n, (const uint8_t *)src, len, &in_flight));
     else if (len) PFP_HIP(c, hipMemcpyAsync(c->tb + 16 + c->n, src, (size_t)len, kind, c->stream));
     c->n += len;
     if (end_of_seq) {   // the w 'A's of pfparser.hpp:335-337
         PFP_HIP(c, hipMemsetAsync(c->tb + 16 + c->n, 'A', (size_t)c->w, c->stream));
         c->n += (uint64_t)c->w;
     }
-    if (kind == hipMemcpyHostToDevice) PFP_HIP(c, hipStreamSynchronize(c->stream)); // caller may reuse its buffer
+    // the caller may reuse its buffer on return: a pageable source went through the staging ring (its DMA transfers overlap
+    // the caller's next read / decompression, include/kseq.h:228), only a page-locked source is read in place
+    if (in_flight) PFP_HIP(c, hipStreamSynchronize(c->stream));
+    c->tb_n = c->n;
+    return PFP_OK;
+}
+int pfp_parse_reopen(pfp_ctx *c)
+{
+    if (!c) return PFP_E_ARG;
+    PFP_HIP(c, hipSetDevice(c->device));
+    if (c->stage == 0) return PFP_OK;
+    if (!c->tb || !c->tb_n || c->tb_n != c->n) return PFP_E_STATE;   // a context filled by pfp_merge_shards / pfp_bwt_load holds no text
+    PFP_HIP(c, hipStreamSynchronize(c->stream));
+    const uint64_t n = c->n;
+    reset_results(c);
+    c->n = c->tb_n = n;                                         // the (normalised) text is still in place; more can be appended
+    return PFP_OK;
+}
+int pfp_text_view(pfp_ctx *c, const uint8_t **d_text, uint64_t *n)
+{
+    if (!c || !d_text || !n) return PFP_E_ARG;
+    if (!c->tb || c->tb_n != c->n) { *d_text = nullptr; *n = 0; return PFP_OK; }
+    PFP_HIP(c, hipSetDevice(c->device));
+    PFP_HIP(c, hipStreamSynchronize(c->stream));
+    *d_text = c->tb + 16; *n = c->n;
     return PFP_OK;
 }
 int pfp_parse_feed(pfp_ctx *c, const uint8_t *bases, uint64_t len, int end_of_seq) { return feed_common(c, bases, len, end_of_seq, hipMemcpyHostToDevice); }
@@ -224,7 +252,7 @@ int pfp_parse_feed_device_batch(pfp_ctx *c, const void *d_bases, uint64_t count,
     const uint64_t blocks_per_row = ((len + 15) / 16 + BLOCK - 1) / BLOCK;
     if (count * blocks_per_row >= 0x7FFFFFFFULL) return PFP_E_TOO_LARGE;      // grid limit (2^31 workgroups = 8 Tbase)
     PFP_LAUNCH(c, K_MISC, 2 * count * len, k_feed_batch, count * blocks_per_row, (const uint8_t *)d_bases, count, len, stride, c->w, dst);
-    c->n += add;
+    c->n += add; c->tb_n = c->n;
     return PFP_OK;
 }
 
@@ -246,7 +274,7 @@ int pfp_parse_feed_batch(pfp_ctx *c, const uint8_t *bases, uint64_t count, uint6
     PFP_HIP(c, hipMemcpy2DAsync(dst, (size_t)pitch, bases, (size_t)stride, (size_t)len, (size_t)count, hipMemcpyHostToDevice, c->stream));
     PFP_HIP(c, hipMemset2DAsync(dst + len, (size_t)pitch, 'A', (size_t)c->w, (size_t)count, c->stream));
     PFP_HIP(c, hipStreamSynchronize(c->stream));      // the caller may reuse its buffer
-    c->n += add;
+    c->n += add; c->tb_n = c->n;
     return PFP_OK;
 }
 
@@ -275,6 +303,7 @@ static int sort_dict_suffixes(pfp_ctx *c)
 static int dedup_strings(pfp_ctx *c, const uint8_t *Y, Spans sp, uint64_t m, uint64_t total_bytes, uint32_t *d_id, uint64_t *ndistinct, uint32_t **rep_out, uint32_t **occw_out)
 {
     uint32_t *longlist, *d_u32, *slotof;
+    const size_t mk0 = c->arena.mark_hi();
     const uint64_t maxlong = total_bytes / LONG_PHRASE + 2;
     PFP_ALLOC_HI(c, longlist, uint32_t, maxlong);
     PFP_ALLOC_HI(c, d_u32, uint32_t, 8);
@@ -317,15 +346,21 @@ static int dedup_strings(pfp_ctx *c, const uint8_t *Y, Spans sp, uint64_t m, uin
     // ids in the order of the hashes of the distinct strings
     uint64_t *k1, *sk; uint32_t *v0, *v1, *sv, *rep, *occw;
     PFP_ALLOC_HI(c, rep, uint32_t, (size_t)nd + 1); PFP_ALLOC_HI(c, occw, uint32_t, (size_t)nd + 1);
-    const size_t mk2 = c->arena.mark_hi();
     PFP_ALLOC_HI(c, k1, uint64_t, nd); PFP_ALLOC_HI(c, v0, uint32_t, nd); PFP_ALLOC_HI(c, v1, uint32_t, nd);
     PFP_LAUNCH(c, K_MISC, nd * 4, k_iota_u32, nblocks(nd, BLOCK), v0, (uint64_t)nd);
     BitRange full = {0, 64};
     PFP_TRY(radix_sort_pairs<uint64_t>(c, t.dhash, v0, k1, v1, nd, &full, 1, &sk, &sv));
     PFP_LAUNCH(c, K_DEDUP_HEADS, (uint64_t)nd * 40, k_dedup_assign, nblocks(nd, BLOCK), (const uint32_t *)sv, (uint64_t)nd, t, rep, occw);
     PFP_LAUNCH(c, K_DEDUP_HEADS, m * 16, k_dedup_ids, gm, (const unsigned long long *)t.tab, (const uint32_t *)slotof, m, d_id);
-    c->arena.release_hi(mk2);
-    *ndistinct = nd; *rep_out = rep; *occw_out = occw;
+    // the table (20 bytes per entry) is dead now: give its space back and keep only rep / occw, moved to the top of what it
+    // occupied (they were allocated below it, and are smaller than it: the two regions cannot overlap)
+    c->arena.release_hi(mk0);
+    uint32_t *rep2, *occw2;
+    PFP_ALLOC_HI(c, rep2, uint32_t, (size_t)nd + 1); PFP_ALLOC_HI(c, occw2, uint32_t, (size_t)nd + 1);
+    if ((char *)occw2 < (char *)(rep + nd + 1) + ((size_t)nd + 1) * 4) return PFP_E_CORRUPT;      // cannot happen (see above)
+    PFP_HIP(c, hipMemcpyAsync(rep2, rep, ((size_t)nd + 1) * 4, hipMemcpyDeviceToDevice, c->stream));
+    PFP_HIP(c, hipMemcpyAsync(occw2, occw, ((size_t)nd + 1) * 4, hipMemcpyDeviceToDevice, c->stream));
+    *ndistinct = nd; *rep_out = rep2; *occw_out = occw2;
     return PFP_OK;
 }
 

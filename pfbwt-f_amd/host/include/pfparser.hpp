@@ -3,13 +3,17 @@
 //
 //   reference member                         here
 //   PfParser(PfParserParams) :82-84          pfp_create (w, p, flags)
-//   add_fasta :299-369                       host FASTA reader -> pfp_parse_feed per record
+//   add_fasta :299-369                       host FASTA reader -> pfp_parse_feed per record (the engine stages pageable
+//                                            memory through two pinned buffers; the DMA of one record overlaps the
+//                                            reading / inflating of the next).  The text lives in HBM ONLY: the
+//                                            mirror keeps no copy (a 32 Gbase collection would not fit a host string)
 //   finalize :484-517                        pfp_parse_finalize + pfp_parse_get (dict, occ, ranks, last, sai)
 //   bwt_of_parse :379-467                    pfp_parse_bwt + pfp_parse_bwt_get, then OutFn(bwlast, ilist, bwsai)
 //   operator+= :194-263                      exact by construction: the merged parse IS the parse of the
-//                                            concatenated texts (tests/test_parser.cpp:188-234), so += appends
-//                                            rhs' text and finalize() re-parses on the GPU
-//   load ctor :89-132, init_from_dict_ranks  text rebuilt from (dict, ranks), then parsed
+//                                            concatenated texts (tests/test_parser.cpp:188-234), so += copies rhs' text
+//                                            device to device behind its own (pfp_parse_reopen + pfp_text_view +
+//                                            pfp_parse_feed_device) and finalize() re-parses on the GPU
+//   load ctor :89-132, init_from_dict_ranks  text rebuilt from (dict, ranks) in a transient buffer, fed, parsed
 //   getters :469-544                         host vectors filled by finalize()
 // Not carried over: the std::map FreqMap (get_freqs) -- use get_sorted_phrases()/get_occs().
 #ifndef PFBWTF_PFPARSER_HPP
@@ -67,14 +71,13 @@ template <typename Hasher = WangHash> struct PfParser {
     // append another parse (pfparser.hpp:194-263); call finalize() afterwards
     PfParser &operator+=(const PfParser &rhs)
     {
-        if (!text_.size() && !seq_ends_.size()) { const PfParserParams keep = params_; const bool had = have_params_; *this = rhs; if (had) { params_.store_docs = keep.store_docs; } finalized_ = false; return *this; }
+        if (!n_fed_ && !nseqs_) { const PfParserParams keep = params_; const bool had = have_params_; *this = rhs; if (had) { params_.store_docs = keep.store_docs; } finalized_ = false; return *this; }
         if (rhs.params_.w != params_.w) { fprintf(stderr, "invalid w\n"); exit(1); }
         if (rhs.params_.p != params_.p) { fprintf(stderr, "invalid p\n"); exit(1); }
-        const size_t prev_n = text_.size();
+        const size_t prev_n = n_fed_;
         for (auto s : rhs.doc_starts_) doc_starts_.push_back((UIntType)(s + prev_n));
         for (auto &nm : rhs.doc_names_) doc_names_.push_back(nm);
-        for (auto e : rhs.seq_ends_) seq_ends_.push_back(e + prev_n);
-        text_.append(rhs.text_);
+        append_device_text(rhs);
         nseqs_ += rhs.nseqs_;
         finalized_ = false;
         return *this;
@@ -93,18 +96,19 @@ template <typename Hasher = WangHash> struct PfParser {
 #if !M64
         uint64_t total_l = 0;
 #endif
+        ensure_ctx();
+        if (finalized_) { engine_check(ctx_, pfp_parse_reopen(ctx_), "pfp_parse_reopen"); finalized_ = false; }
         while (rd.next(rec)) {
-            if (params_.store_docs) { doc_starts_.push_back((UIntType)text_.size()); doc_names_.push_back(rec.name); }
+            if (params_.store_docs) { doc_starts_.push_back((UIntType)n_fed_); doc_names_.push_back(rec.name); }
 #if !M64
             if (total_l + rec.seq.size() > 0xFFFFFFFFull) { fprintf(stderr, "size: %lu\n", (unsigned long)(total_l + rec.seq.size())); die("input too long, please use 64-bit version"); }
             total_l += rec.seq.size();
 #endif
-            text_.append(rec.seq);
-            text_.append(params_.w, 'A');          // :335-337; kept on the host so that += and re-finalize work
-            seq_ends_.push_back(text_.size());
+            // straight to the device; end_of_seq = 1 appends the w 'A's of :335-337 there
+            engine_check(ctx_, pfp_parse_feed(ctx_, (const uint8_t *)rec.seq.data(), rec.seq.size(), 1), "pfp_parse_feed");
+            n_fed_ += rec.seq.size() + params_.w;
             nseqs_ += 1;
         }
-        finalized_ = false;
         return get_pos();
     }
 
@@ -115,8 +119,6 @@ template <typename Hasher = WangHash> struct PfParser {
     {
         if (finalized_) return;
         ensure_ctx();
-        // records are fed one by one; the pad 'A's are already part of text_, so end_of_seq = 0
-        engine_check(ctx_, pfp_parse_feed(ctx_, (const uint8_t *)text_.data(), text_.size(), 0), "pfp_parse_feed");
         pfp_parse_sizes sz;
         engine_check(ctx_, pfp_parse_finalize(ctx_, &sz), "pfp_parse_finalize");
         n_ = sz.n; dict_.resize(sz.dsize); occs_.resize(sz.dwords); parse_ranks_.resize(sz.m); last_.resize(sz.m);
@@ -149,7 +151,7 @@ template <typename Hasher = WangHash> struct PfParser {
 
     size_t get_parse_size() const { return parse_ranks_.size(); }
     const std::vector<UIntType> get_occs() const { return occs_; }
-    size_t get_n() const { return finalized_ ? n_ : text_.size(); }            // includes the As at the end of each seq
+    size_t get_n() const { return finalized_ ? n_ : n_fed_; }                  // includes the As at the end of each seq
     const std::vector<UIntType> &get_sai() const { return sai_; }
     const std::vector<char> &get_last() const { return last_; }
     const std::vector<int_text> &get_parse_ranks() const { return parse_ranks_; }
@@ -159,7 +161,7 @@ template <typename Hasher = WangHash> struct PfParser {
     const std::vector<UIntType> &get_doc_starts() const { return doc_starts_; }
     const std::vector<std::string> &get_doc_names() const { return doc_names_; }
     const PfParserParams get_params() const { return params_; }
-    size_t get_pos() const { return text_.size() + (finalized_ ? params_.w : 1); }   // pos_ counts the Dollars (:612)
+    size_t get_pos() const { return n_fed_ + (finalized_ ? params_.w : 1); }   // pos_ counts the Dollars (:612)
     // the engine context that holds this parse on the device (lets PrefixFreeBWT skip the file round trip)
     pfp_ctx *engine() const { return ctx_; }
     bool parse_bwt_done() const { return parse_bwt_done_; }
@@ -175,41 +177,57 @@ template <typename Hasher = WangHash> struct PfParser {
         if (!ctx_) { fprintf(stderr, "pfp_create: %s\n", pfp_strerror(st)); exit(1); }
     }
     void release() { if (ctx_) { pfp_destroy(ctx_); ctx_ = nullptr; } }
+    // the text of `r` (device resident in r's context) behind this parser's own text, device to device
+    void append_device_text(const PfParser &r)
+    {
+        if (!r.n_fed_) return;
+        ensure_ctx();
+        if (finalized_ || n_fed_) engine_check(ctx_, pfp_parse_reopen(ctx_), "pfp_parse_reopen");
+        const uint8_t *dt = nullptr; uint64_t dn = 0;
+        engine_check(r.ctx_, pfp_text_view(r.ctx_, &dt, &dn), "pfp_text_view");
+        if (!dt || dn != r.n_fed_) { fprintf(stderr, "PfParser: the right-hand parse holds no text on the device\n"); exit(1); }
+        engine_check(ctx_, pfp_parse_feed_device(ctx_, dt, dn, 0), "pfp_parse_feed_device");   // its pads are part of its text
+        n_fed_ += dn;
+    }
     void copy_from(const PfParser &r)
     {
-        params_ = r.params_; have_params_ = r.have_params_; text_ = r.text_; seq_ends_ = r.seq_ends_; doc_starts_ = r.doc_starts_; doc_names_ = r.doc_names_; nseqs_ = r.nseqs_;
+        params_ = r.params_; have_params_ = r.have_params_; doc_starts_ = r.doc_starts_; doc_names_ = r.doc_names_; nseqs_ = 0; n_fed_ = 0;
         n_ = r.n_; dict_ = r.dict_; occs_ = r.occs_; parse_ranks_ = r.parse_ranks_; last_ = r.last_; sai_ = r.sai_; keys_ = r.keys_;
-        finalized_ = r.finalized_; parse_bwt_done_ = false; ctx_ = nullptr;
+        finalized_ = false; parse_bwt_done_ = false; ctx_ = nullptr;      // device state is not shared: the copy gets its own text, the next finalize() parses it (cheap on the GPU)
         sorted_phrases_.clear();
         for (auto p : r.sorted_phrases_) sorted_phrases_.push_back(keys_.data() + (p - r.keys_.data()));
-        if (finalized_) { finalized_ = false; }   // device state is not shared: next finalize() re-parses (cheap on the GPU)
+        append_device_text(r);
+        nseqs_ = r.nseqs_;
     }
     void move_from(PfParser &r)
     {
-        params_ = r.params_; have_params_ = r.have_params_; text_ = std::move(r.text_); seq_ends_ = std::move(r.seq_ends_); doc_starts_ = std::move(r.doc_starts_);
+        params_ = r.params_; have_params_ = r.have_params_; n_fed_ = r.n_fed_; doc_starts_ = std::move(r.doc_starts_);
         doc_names_ = std::move(r.doc_names_); nseqs_ = r.nseqs_; n_ = r.n_; dict_ = std::move(r.dict_); occs_ = std::move(r.occs_);
         parse_ranks_ = std::move(r.parse_ranks_); last_ = std::move(r.last_); sai_ = std::move(r.sai_); keys_ = std::move(r.keys_);
-        sorted_phrases_ = std::move(r.sorted_phrases_); finalized_ = r.finalized_; parse_bwt_done_ = r.parse_bwt_done_; ctx_ = r.ctx_; r.ctx_ = nullptr;
+        sorted_phrases_ = std::move(r.sorted_phrases_); finalized_ = r.finalized_; parse_bwt_done_ = r.parse_bwt_done_; ctx_ = r.ctx_; r.ctx_ = nullptr; r.n_fed_ = 0; r.nseqs_ = 0;
     }
     // inverse of the parse: phrase 0 without its Dollar, every later phrase without its first w bytes,
-    // the last one without its w Dollars (init_from_dict_ranks, pfparser.hpp:549-567)
+    // the last one without its w Dollars (init_from_dict_ranks, pfparser.hpp:549-567); fed in pieces, never held whole
     void text_from_dict_ranks(const std::vector<std::string> &phrases, const std::vector<IntType> &ranks)
     {
-        text_.clear();
+        ensure_ctx();
+        std::string buf;
         for (size_t j = 0; j < ranks.size(); ++j) {
             const std::string &ph = phrases[ranks[j] - 1];
             size_t from = j ? params_.w : 1, to = ph.size();
             if (j + 1 == ranks.size()) to -= params_.w;
-            if (to > from) text_.append(ph, from, to - from);
+            if (to > from) buf.append(ph, from, to - from);
+            if (buf.size() >= ((size_t)64 << 20) || j + 1 == ranks.size()) {
+                engine_check(ctx_, pfp_parse_feed(ctx_, (const uint8_t *)buf.data(), buf.size(), 0), "pfp_parse_feed");
+                n_fed_ += buf.size(); buf.clear();
+            }
         }
-        seq_ends_.assign(1, text_.size());
         nseqs_ = 1;
     }
 
     PfParserParams params_;
     bool have_params_ = false;
-    std::string text_;                        // sum over sequences of (bases + w 'A's), raw case
-    std::vector<size_t> seq_ends_;
+    size_t n_fed_ = 0;                        // bytes of text (bases + w 'A's per sequence) fed to the engine; the text itself is in HBM only
     std::vector<UIntType> doc_starts_;
     std::vector<std::string> doc_names_;
     std::vector<ntab_entry> ntab_;
