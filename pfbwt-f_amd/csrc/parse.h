@@ -449,17 +449,18 @@ __global__ __launch_bounds__(BLOCK) void k_dedup_insert(const uint8_t *Y, Spans 
 }
 // ---- long phrases (e.g. a 10 Mbp run of N is ONE phrase: wang_hash(0) % 100 != 0): one workgroup
 // per phrase hashes and compares it cooperatively; thread 0 walks the probe sequence
-__global__ __launch_bounds__(BLOCK) void k_dedup_insert_long(const uint8_t *Y, Spans sp, const uint32_t *longlist, uint64_t seed, DedupTable t)
+constexpr int DL_THREADS = 1024;       // the waves of one whole CU stream the phrase
+__global__ __launch_bounds__(DL_THREADS) void k_dedup_insert_long(const uint8_t *Y, Spans sp, const uint32_t *longlist, uint64_t seed, DedupTable t)
 {
-    __shared__ uint64_t part[BLOCK];
+    __shared__ uint64_t part[DL_THREADS];
     __shared__ unsigned long long s_cur, s_h;
     __shared__ int s_state;                                  // 0: next probe, 1: done, 2: compare with the entry's representative
     __shared__ uint32_t s_diff;
     const uint32_t j = longlist[blockIdx.x];
     tpos_t ys; uint32_t len; phrase_span(sp, j, &ys, &len);
-    {   // thread t chains the 8-byte words t, t + 256, t + 512, ... (coalesced reads), thread 0 folds the 256 partial hashes
+    {   // thread t chains the 8-byte words t, t + 1024, t + 2048, ... (coalesced reads), thread 0 folds the partial hashes
         uint64_t hp = seed + threadIdx.x;
-        for (uint64_t k = 8ULL * threadIdx.x; k < len; k += 8ULL * BLOCK) {
+        for (uint64_t k = 8ULL * threadIdx.x; k < len; k += 8ULL * DL_THREADS) {
             uint64_t v = ld8(Y + ys + k);
             if (len - k < 8) v &= (1ULL << (8 * (len - k))) - 1ULL;
             hp = (hp ^ v) * 0xD6E8FEB86659FD93ULL; hp ^= hp >> 32;
@@ -468,7 +469,7 @@ __global__ __launch_bounds__(BLOCK) void k_dedup_insert_long(const uint8_t *Y, S
     }
     if (threadIdx.x == 0) s_diff = 0;
     __syncthreads();
-    if (threadIdx.x == 0) { uint64_t hh = seed ^ len; for (int k = 0; k < BLOCK; ++k) hh = mix64(hh ^ part[k]); s_h = hh; }
+    if (threadIdx.x == 0) { uint64_t hh = seed ^ len; for (int k = 0; k < DL_THREADS; ++k) hh = mix64(hh ^ part[k]); s_h = hh; }
     __syncthreads();
     const uint64_t h = s_h;
     const uint64_t filt = h >> 32;
@@ -500,7 +501,7 @@ __global__ __launch_bounds__(BLOCK) void k_dedup_insert_long(const uint8_t *Y, S
             if (rlen != len) { if (threadIdx.x == 0) s_diff = 1; }
             else {
                 uint64_t d = 0;
-                for (uint64_t k = 8ULL * threadIdx.x; k < len; k += 8ULL * BLOCK) {
+                for (uint64_t k = 8ULL * threadIdx.x; k < len; k += 8ULL * DL_THREADS) {
                     uint64_t v = ld8(Y + ys + k) ^ ld8(Y + rs + k);
                     if (len - k < 8) v &= (1ULL << (8 * (len - k))) - 1ULL;
                     d |= v;

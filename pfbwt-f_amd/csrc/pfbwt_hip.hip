@@ -334,7 +334,7 @@ static int dedup_strings(pfp_ctx *c, const uint8_t *Y, Spans sp, uint64_t m, uin
         PFP_HIP(c, hipMemcpyAsync(h3, d_u32, 12, hipMemcpyDeviceToHost, c->stream));
         PFP_HIP(c, hipStreamSynchronize(c->stream));
         if (!h3[1] && h3[2]) {
-            PFP_LAUNCH(c, K_PHRASE_HASH_LONG, 2.0 * total_bytes / 64, k_dedup_insert_long, h3[2], Y, sp, (const uint32_t *)longlist, c->hash_seed, t);
+            PFP_LAUNCH_B(c, K_PHRASE_HASH_LONG, 2.0 * total_bytes / 64, k_dedup_insert_long, h3[2], DL_THREADS, Y, sp, (const uint32_t *)longlist, c->hash_seed, t);
             PFP_HIP(c, hipMemcpyAsync(h3, d_u32, 12, hipMemcpyDeviceToHost, c->stream));
             PFP_HIP(c, hipStreamSynchronize(c->stream));
         }
@@ -712,10 +712,10 @@ static int sort_int_suffixes(pfp_ctx *c, const uint32_t *dS, uint64_t N, uint64_
     uint64_t *k0, *k1; uint32_t *v0, *v1;
     PFP_ALLOC_HI(c, k0, uint64_t, N); PFP_ALLOC_HI(c, k1, uint64_t, N);
     PFP_ALLOC_HI(c, v0, uint32_t, N); PFP_ALLOC_HI(c, v1, uint32_t, N);
-    PFP_LAUNCH(c, K_SS_INIT_KEYS, N * 16, k_int_init_keys, nblocks(N, BLOCK), dS, N, k0, v0);
     const int sb = bits_for(maxsym);
-    BitRange rr[2] = {{0, sb}, {32, 32 + sb}};
-    PFP_TRY(suffix_sort_doubling<false>(c, N, k0, v0, k1, v1, rr, 2, 2, (const uint8_t *)nullptr, SA, rank, (uint2 *)nullptr, rounds));
+    PFP_LAUNCH(c, K_SS_INIT_KEYS, N * 16, k_int_init_keys, nblocks(N, BLOCK), dS, N, sb, k0, v0);
+    BitRange rr = {0, 2 * sb};
+    PFP_TRY(suffix_sort_doubling<false>(c, N, k0, v0, k1, v1, &rr, 1, 2, (const uint8_t *)nullptr, SA, rank, (uint2 *)nullptr, rounds));
     c->arena.release_hi(mk);
     return PFP_OK;
 }

@@ -54,11 +54,11 @@ __global__ __launch_bounds__(BLOCK) void k_dict_init_keys(const uint8_t *D, uint
 }
 
 // parse keys: (S[x], S[x+1]) with S = ranks + [0]  (pfparser.hpp:407-410)
-__global__ __launch_bounds__(BLOCK) void k_int_init_keys(const uint32_t *S, uint64_t N, uint64_t *keys, uint32_t *vals)
+__global__ __launch_bounds__(BLOCK) void k_int_init_keys(const uint32_t *S, uint64_t N, int symbits, uint64_t *keys, uint32_t *vals)
 {
     const uint64_t x = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (x >= N) return;
-    keys[x] = ((uint64_t)S[x] << 32) | (x + 1 < N ? S[x + 1] : 0u);
+    keys[x] = ((uint64_t)S[x] << symbits) | (x + 1 < N ? S[x + 1] : 0u);      // packed tightly: 2 * symbits key bits (5 radix passes for 20-bit symbols, not 6)
     vals[x] = (uint32_t)x;
 }
 
@@ -340,7 +340,7 @@ template <bool DICT> __global__ __launch_bounds__(BLOCK) void k_round_finish(con
 // to be refined move to the next active list -- stripe by stripe, at the offsets the scan of stripe_keep gave
 template <bool DICT> __global__ __launch_bounds__(BLOCK) void k_round_apply(const uint32_t *aslot, uint64_t na, const uint32_t *SA, const uint32_t *newr, const uint32_t *newj,
                                                                             const uint8_t *flags, const uint32_t *stripe_base, uint32_t *rank, uint2 *rj,
-                                                                            uint32_t *oslot, uint32_t *ornk, uint32_t *ojmp)
+                                                                            uint32_t *oslot, uint32_t *ornk, uint32_t *ojmp, unsigned long long *stat /*nullable (PFP_VERBOSE): ranks scattered*/)
 {
     __shared__ uint32_t red[4];
     const uint64_t s = (uint64_t)blockIdx.x * CS_STEP;
@@ -355,6 +355,7 @@ template <bool DICT> __global__ __launch_bounds__(BLOCK) void k_round_apply(cons
             if (fl & RF_CHANGED) {
                 const uint32_t x = SA[slot];
                 if (DICT) rj[x] = make_uint2(nr, nj); else rank[x] = nr;
+                if (stat) atomicAdd(stat, 1ULL);
             }
         }
         uint32_t tot;
@@ -441,7 +442,9 @@ template <bool DICT> inline int suffix_sort_doubling(pfp_ctx *c, uint64_t N, uin
             PFP_HIP(c, hipMemsetAsync(flags, 0, na, c->stream));
             PFP_HIP(c, hipMemsetAsync(stripe, 0, ((size_t)gs + 3) * 4, c->stream));
             PFP_HIP(c, hipMemsetAsync(d_done, 0, 8, c->stream));
-            PFP_LAUNCH(c, K_CLASS_SORT, (uint64_t)na * (DICT ? 64 : 48), (k_round<DICT>), gs, (const uint32_t *)aslot[cur], (const uint32_t *)arnk[cur], (const uint32_t *)ajmp[cur], (uint64_t)na, N, SA,
+            // algorithmic bytes per active suffix: list entry 8 (+4 jump), SA[slot] 4 in + 4 out, the gathered
+            // rank 4 (rank + jump 8, + 1 terminator byte), new rank 4 (+ new jump 4 + 4 through scratch), flag 1
+            PFP_LAUNCH(c, K_CLASS_SORT, (uint64_t)na * (DICT ? 46 : 25), (k_round<DICT>), gs, (const uint32_t *)aslot[cur], (const uint32_t *)arnk[cur], (const uint32_t *)ajmp[cur], (uint64_t)na, N, SA,
                        (const uint32_t *)rank, (const uint2 *)rj, (uint32_t)(h < N ? h : N), D, run_round ? (const uint32_t *)M : (const uint32_t *)nullptr, lowbits, max_range, newr, tnj, newj, flags, stripe, d_done);
             unsigned long long nd = 0;
             PFP_HIP(c, hipMemcpyAsync(&nd, d_done, 8, hipMemcpyDeviceToHost, c->stream));
@@ -464,8 +467,14 @@ template <bool DICT> inline int suffix_sort_doubling(pfp_ctx *c, uint64_t N, uin
                            (const uint32_t *)arnk[cur], SA, (const uint2 *)rj, D, newr, newj, flags, stripe);
             }
             PFP_TRY((device_scan<uint32_t, 0>(c, stripe, stripe, (uint64_t)gs, d_cnt)));
-            PFP_LAUNCH(c, K_SS_WRITE_RANK, (uint64_t)na * 30, (k_round_apply<DICT>), gs, (const uint32_t *)aslot[cur], (uint64_t)na, (const uint32_t *)SA, (const uint32_t *)newr, (const uint32_t *)newj,
-                       (const uint8_t *)flags, (const uint32_t *)stripe, rank, rj, aslot[cur ^ 1], arnk[cur ^ 1], ajmp[cur ^ 1]);
+            PFP_LAUNCH(c, K_SS_WRITE_RANK, (uint64_t)na * (DICT ? 37 : 25), (k_round_apply<DICT>), gs, (const uint32_t *)aslot[cur], (uint64_t)na, (const uint32_t *)SA, (const uint32_t *)newr, (const uint32_t *)newj,
+                       (const uint8_t *)flags, (const uint32_t *)stripe, rank, rj, aslot[cur ^ 1], arnk[cur ^ 1], ajmp[cur ^ 1], verbose ? d_done : (unsigned long long *)nullptr);
+            if (verbose) {
+                unsigned long long ch = 0;
+                PFP_HIP(c, hipMemcpyAsync(&ch, d_done, 8, hipMemcpyDeviceToHost, c->stream));
+                PFP_HIP(c, hipStreamSynchronize(c->stream));
+                fprintf(stderr, "[pfbwt_hip]   ranks scattered this round: %llu (the counter started at the %llu pairs the round kernel handled)\n", ch - nd, nd);
+            }
             PFP_TRY(d2h_u32(c, d_cnt, &na));
             cur ^= 1; ++rounds; h *= 2;
         }

@@ -116,7 +116,7 @@ if "PFP_BIG_GROUP_MEMBERS" in os.environ or "PFP_CLASS_SORT_MIN" in os.environ: 
 for ci, (seqs, w, p) in enumerate(cases):
     for U in ((8, 4) if ci == 0 else (8,)):
         ref = oracle_run(seqs, w=w, p=p, U=U)
-        for sa, rssa in (((True, True), (False, True), (True, False), (False, False)) if (U == 8 and ci == 0) else ((True, True), (False, True))):
+        for sa, rssa in (((True, True), (False, True), (True, False), (False, False)) if (U == 8 and ci == 0) else ((False, True),)):
             res = engine_run(F, seqs, w, p, U, sa=sa, rssa=rssa)
             names = ["bwt"] + (["sa"] if sa else []) + (["ssa", "esa"] if rssa else [])
             bad = compare(res, ref, U, names=tuple(names))
@@ -181,7 +181,7 @@ def test_emu_failed_stage_leaves_context_usable(emu_factory):
     workspace, then the cheaper request in the SAME context succeeds and is bit-exact; (2) a rejected text
     (invalid character) followed by pfp_reset and a good text."""
     import pfbwt_hip
-    man, recs = golden_case("mult_chroms_fa")
+    man, recs = golden_case("w4p7")
     seqs = [s for _, s in recs]
     ref = oracle_run(seqs, w=man["w"], p=man["p"], U=8)
 
@@ -207,7 +207,7 @@ def test_emu_failed_stage_leaves_context_usable(emu_factory):
         finally:
             ctx.close()
 
-    lo, hi = 50_000, 64_000_000                    # smallest workspace in which the BWT-only build succeeds (fresh context)
+    lo, hi = 50_000, 16_000_000                    # smallest workspace in which the BWT-only build succeeds (fresh context)
     assert attempt(hi, False) == "bwt ok"
     while hi - lo > 4096:
         mid = (lo + hi) // 2
