@@ -120,8 +120,8 @@ __device__ __forceinline__ uint64_t class_start_at_or_after(const uint32_t *arnk
 // left alone: its flags stay 0 and the pairs go through the global radix sort, k_round_keys / k_round_finish).
 template <bool DICT> __global__ __launch_bounds__(BLOCK) void k_round(const uint32_t *aslot, const uint32_t *arnk, const uint32_t *ajmp, uint64_t na, uint64_t N,
                                                                       uint32_t *SA, const uint32_t *rank, const uint2 *rj, uint32_t h, const uint8_t *D, const uint32_t *M /*run round*/,
-                                                                      int lowbits, uint32_t max_range, uint32_t *newr, uint32_t *tnj, uint32_t *newj, uint8_t *flags, uint32_t *stripe_keep,
-                                                                      unsigned long long *ndone)
+                                                                      int lowbits, uint32_t max_range, uint32_t *newr, uint32_t *xout /*the sorted suffixes, in list order*/, uint32_t *tnj, uint32_t *newj, uint8_t *flags,
+                                                                      uint32_t *stripe_keep, unsigned long long *ndone)
 {
     constexpr int ITEMS = RS_ITEMS, TILE = RS_TILE;
     __shared__ uint32_t wh[BLOCK / WAVE][RS_RADIX];
@@ -142,30 +142,63 @@ template <bool DICT> __global__ __launch_bounds__(BLOCK) void k_round(const uint
     const uint32_t nit = (n + BLOCK - 1) / BLOCK;
     const uint32_t base = (uint32_t)wave * (nit * WAVE) + lane;   // wave w owns the contiguous pairs [w * nit * 64, (w + 1) * nit * 64)
     const uint32_t hmin = arnk[s];
-    // ---- keys: (rank of the class, rank of the suffix one covered prefix further on)
-    for (uint32_t j = threadIdx.x; j < n; j += BLOCK) {
-        const uint32_t x = SA[aslot[s + j]];
-        uint32_t low;
-        if (!DICT) { const uint64_t y = (uint64_t)x + h; low = y < N ? rank[y] : 0u; }
-        else {
-            uint32_t nx; bool run = false;
-            if (M) {   // run round: c^d a... is ordered among the suffixes that start with c by t = d if a < c else 2^32-1-d, jump = x + d
-                const uint32_t ip = (uint32_t)(N - 1 - x);
-                const uint32_t d = ip - M[ip] + 1u;
-                if (d >= RUN_MIN && D[x] > EndOfWord) {
-                    const uint64_t en = (uint64_t)x + d;
-                    const uint8_t nxt = en < N ? D[en] : (uint8_t)0;
-                    low = nxt < D[x] ? d : 0xFFFFFFFFu - d; nx = (uint32_t)(en < N ? en : N); run = true;
-                }
-            }
-            if (!run) {
-                const uint32_t y = ajmp[s + j];
-                const uint2 Q = y < N ? rj[y] : make_uint2(0u, (uint32_t)N);
-                low = Q.x; nx = Q.y;
-            }
-            tnj[s + j] = nx;
+    // ---- keys: (rank of the class, rank of the suffix one covered prefix further on).  Three dependent gathers per pair
+    //      (list entry -> SA[slot] -> rank of the target): all of a thread's pairs go through each stage together, so that a
+    //      tile pays three memory latencies, not three per pair (measured: 15.6 -> see DESIGN.md section 4 per full round)
+    uint32_t xi[ITEMS];                                  // the suffixes of this thread's pairs (by position before the sort)
+    {
+        uint32_t sl[ITEMS], lowv[ITEMS], njv[ITEMS], yj[ITEMS];
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            const uint32_t j = threadIdx.x + (uint32_t)it * BLOCK;
+            sl[it] = j < n ? aslot[s + j] : 0u;
+            yj[it] = (DICT && j < n) ? ajmp[s + j] : 0u;
         }
-        skeys[j] = ((uint64_t)(arnk[s + j] - hmin) << lowbits) | low; sidx[j] = (uint16_t)j;
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) { const uint32_t j = threadIdx.x + (uint32_t)it * BLOCK; xi[it] = j < n ? SA[sl[it]] : 0u; }
+        if (!DICT) {
+#pragma unroll
+            for (int it = 0; it < ITEMS; ++it) {
+                const uint32_t j = threadIdx.x + (uint32_t)it * BLOCK;
+                const uint64_t y = (uint64_t)xi[it] + h;
+                lowv[it] = (j < n && y < N) ? rank[y] : 0u; njv[it] = 0;
+            }
+        } else if (!M) {
+#pragma unroll
+            for (int it = 0; it < ITEMS; ++it) {
+                const uint32_t j = threadIdx.x + (uint32_t)it * BLOCK;
+                const uint2 Q = (j < n && yj[it] < N) ? rj[yj[it]] : make_uint2(0u, (uint32_t)N);
+                lowv[it] = Q.x; njv[it] = Q.y;
+            }
+        } else {
+            // run round: c^d a... is ordered among the suffixes that start with c by t = d if a < c else 2^32-1-d, jump = x + d
+#pragma unroll
+            for (int it = 0; it < ITEMS; ++it) {
+                const uint32_t j = threadIdx.x + (uint32_t)it * BLOCK;
+                uint32_t low = 0, nx = 0;
+                if (j < n) {
+                    const uint32_t x = xi[it];
+                    bool run = false;
+                    const uint32_t ip = (uint32_t)(N - 1 - x);
+                    const uint32_t d = ip - M[ip] + 1u;
+                    if (d >= RUN_MIN && D[x] > EndOfWord) {
+                        const uint64_t en = (uint64_t)x + d;
+                        const uint8_t nxt = en < N ? D[en] : (uint8_t)0;
+                        low = nxt < D[x] ? d : 0xFFFFFFFFu - d; nx = (uint32_t)(en < N ? en : N); run = true;
+                    }
+                    if (!run) { const uint32_t y = yj[it]; const uint2 Q = y < N ? rj[y] : make_uint2(0u, (uint32_t)N); low = Q.x; nx = Q.y; }
+                }
+                lowv[it] = low; njv[it] = nx;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            const uint32_t j = threadIdx.x + (uint32_t)it * BLOCK;
+            if (j < n) {
+                if (DICT) tnj[s + j] = njv[it];
+                skeys[j] = ((uint64_t)(arnk[s + j] - hmin) << lowbits) | lowv[it]; sidx[j] = (uint16_t)j;
+            }
+        }
     }
     __syncthreads();
     // ---- LSD radix sort of the range inside LDS: the low part, then the span of the (already ordered) class part
@@ -236,32 +269,49 @@ template <bool DICT> __global__ __launch_bounds__(BLOCK) void k_round(const uint
     for (uint32_t j = c0; j < c1; ++j) { const uint32_t v = shp[j]; if (v >= prev && v != 0) break; shp[j] = (uint16_t)(v > prev ? v : prev); }
     if (threadIdx.x == 0) shp[n] = (uint16_t)n;           // sentinel: "the pair behind the last one heads a class"
     __syncthreads();
-    // ---- output: all gathers of the old SA first (the range's slots are overwritten below)
-    uint32_t xs[ITEMS]; unsigned long long keepn = 0;     // kept pairs per position stripe (the range touches at most three), 20 bits each
+    // the keys are not needed any more: their LDS holds the suffixes now, indexed by position before the sort, so that the
+    // output below does not gather SA a second time
+    uint32_t *sx = reinterpret_cast<uint32_t *>(skeys);
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) { const uint32_t j = threadIdx.x + (uint32_t)it * BLOCK; if (j < n) sx[j] = xi[it]; }
+    __syncthreads();
+    // ---- output: all gathers first (the old SA of the range's slots is overwritten below; loads of all of a thread's pairs
+    //      are in flight together), then the stores
+    uint32_t xs[ITEMS], slo[ITEMS], nrv[ITEMS], njo[ITEMS], oldr[ITEMS]; uint8_t flg[ITEMS]; unsigned long long keepn = 0;     // kept pairs per position stripe (the range touches at most three), 20 bits each
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
         const uint32_t j = threadIdx.x + (uint32_t)it * BLOCK;
-        xs[it] = j < n ? SA[aslot[s + sidx[j]]] : 0u;
+        const bool ok = j < n;
+        const uint32_t src = ok ? sidx[j] : 0u, hp = ok ? shp[j] : 0u;
+        xs[it] = ok ? sx[src] : 0u;
+        slo[it] = ok ? aslot[s + j] : 0u;
+        nrv[it] = ok ? aslot[s + hp] : 0u;
+        oldr[it] = ok ? arnk[s + j] : 0u;
+        njo[it] = (DICT && ok) ? tnj[s + src] : 0u;
+        const bool single = ok && hp == j && shp[j + 1] == j + 1;
+        flg[it] = ok ? (uint8_t)(RF_DONE | (single ? 0 : RF_KEEP)) : (uint8_t)0;
+    }
+    if (DICT) {
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            if (flg[it]) {
+                const bool fin = njo[it] >= N || D[njo[it] - 1] == EndOfWord;     // the covered prefix now holds the word's terminator: a group of identical suffixes
+                if (fin) flg[it] &= (uint8_t)~RF_KEEP;
+                flg[it] |= RF_CHANGED;                                           // the jump changes every round
+            }
+        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) if (flg[it] && nrv[it] != oldr[it]) flg[it] |= RF_CHANGED;
     }
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
         const uint32_t j = threadIdx.x + (uint32_t)it * BLOCK;
         if (j < n) {
-            const uint32_t hp = shp[j], slot = aslot[s + j];
-            const uint32_t nr = aslot[s + hp];
-            const bool single = hp == j && shp[j + 1] == j + 1;
-            bool keep = !single;
-            uint8_t fl = RF_DONE;
-            if (DICT) {
-                const uint32_t nj = tnj[s + sidx[j]];
-                newj[s + j] = nj;
-                const bool fin = nj >= N || D[nj - 1] == EndOfWord;      // the covered prefix now holds the word's terminator: a group of identical suffixes
-                keep = keep && !fin;
-                fl |= RF_CHANGED;                                         // the jump changes every round
-            } else if (nr != arnk[s + j]) fl |= RF_CHANGED;
-            if (keep) { fl |= RF_KEEP; keepn += 1ULL << (20 * (uint32_t)((s + j) / CS_STEP - blockIdx.x)); }
-            SA[slot] = xs[it]; newr[s + j] = nr; flags[s + j] = fl;
+            if (flg[it] & RF_KEEP) keepn += 1ULL << (20 * (uint32_t)((s + j) / CS_STEP - blockIdx.x));
+            if (DICT) newj[s + j] = njo[it];
+            SA[slo[it]] = xs[it]; newr[s + j] = nrv[it]; flags[s + j] = flg[it]; xout[s + j] = xs[it];
         }
     }
     unsigned long long kt;
@@ -316,7 +366,7 @@ __global__ __launch_bounds__(BLOCK) void k_round_subset_heads(const uint64_t *ke
 // the sorted subset goes back to its positions (whole classes, in order): same outputs as k_round
 template <bool DICT> __global__ __launch_bounds__(BLOCK) void k_round_finish(const uint64_t *keys, const uint32_t *vals, const uint32_t *headidx /*max-scanned*/, const uint32_t *idx, uint64_t nl, uint64_t N,
                                                                              const uint32_t *aslot, const uint32_t *arnk, uint32_t *SA, const uint2 *rj, const uint8_t *D,
-                                                                             uint32_t *newr, uint32_t *newj, uint8_t *flags, uint32_t *stripe_keep)
+                                                                             uint32_t *newr, uint32_t *xout, uint32_t *newj, uint8_t *flags, uint32_t *stripe_keep)
 {
     const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= nl) return;
@@ -332,37 +382,39 @@ template <bool DICT> __global__ __launch_bounds__(BLOCK) void k_round_finish(con
         fl |= RF_CHANGED;
     } else if (nr != arnk[a]) fl |= RF_CHANGED;
     if (keep) fl |= RF_KEEP;
-    SA[aslot[a]] = x; newr[a] = nr; flags[a] = fl;
+    SA[aslot[a]] = x; newr[a] = nr; flags[a] = fl; xout[a] = x;
     if (keep) atomicAdd(&stripe_keep[a / CS_STEP], 1u);
 }
 
 // second half of a round: ranks (and jumps) that changed go to rank[] / rj[] now, the pairs of classes that still have
 // to be refined move to the next active list -- stripe by stripe, at the offsets the scan of stripe_keep gave
-template <bool DICT> __global__ __launch_bounds__(BLOCK) void k_round_apply(const uint32_t *aslot, uint64_t na, const uint32_t *SA, const uint32_t *newr, const uint32_t *newj,
+template <bool DICT> __global__ __launch_bounds__(BLOCK) void k_round_apply(const uint32_t *aslot, uint64_t na, const uint32_t *xsorted, const uint32_t *newr, const uint32_t *newj,
                                                                             const uint8_t *flags, const uint32_t *stripe_base, uint32_t *rank, uint2 *rj,
                                                                             uint32_t *oslot, uint32_t *ornk, uint32_t *ojmp, unsigned long long *stat /*nullable (PFP_VERBOSE): ranks scattered*/)
 {
-    __shared__ uint32_t red[4];
+    constexpr int PER = (CS_STEP + BLOCK - 1) / BLOCK;          // a thread owns PER consecutive pairs of the stripe: one block scan per stripe,
+    __shared__ uint32_t red[4];                                  // the loads of all its pairs in flight together
     const uint64_t s = (uint64_t)blockIdx.x * CS_STEP;
     const uint64_t e = s + CS_STEP < na ? s + CS_STEP : na;
-    uint32_t outbase = stripe_base[blockIdx.x];
-    for (uint64_t a0 = s; a0 < e; a0 += BLOCK) {            // uniform trip count
-        const uint64_t a = a0 + threadIdx.x;
-        uint8_t fl = 0; uint32_t slot = 0, nr = 0, nj = 0;
-        if (a < e) {
-            fl = flags[a]; slot = aslot[a]; nr = newr[a];
-            if (DICT) nj = newj[a];
-            if (fl & RF_CHANGED) {
-                const uint32_t x = SA[slot];
-                if (DICT) rj[x] = make_uint2(nr, nj); else rank[x] = nr;
-                if (stat) atomicAdd(stat, 1ULL);
-            }
-        }
-        uint32_t tot;
-        const uint32_t ex = block_excl_sum((fl & RF_KEEP) ? 1u : 0u, red, &tot);
-        if (fl & RF_KEEP) { const uint32_t o = outbase + ex; oslot[o] = slot; ornk[o] = nr; if (DICT) ojmp[o] = nj; }
-        outbase += tot;
+    const uint64_t a0 = s + (uint64_t)threadIdx.x * PER;
+    uint8_t fl[PER]; uint32_t slot[PER], nr[PER], nj[PER], x[PER], kept = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const uint64_t a = a0 + k;
+        const bool ok = a < e;
+        fl[k] = ok ? flags[a] : (uint8_t)0; slot[k] = ok ? aslot[a] : 0u; nr[k] = ok ? newr[a] : 0u; nj[k] = (DICT && ok) ? newj[a] : 0u;
+        x[k] = ok ? xsorted[a] : 0u;
+        kept += (fl[k] & RF_KEEP) ? 1u : 0u;
     }
+    uint32_t tot;
+    uint32_t o = stripe_base[blockIdx.x] + block_excl_sum(kept, red, &tot);
+    uint32_t nch = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        if (fl[k] & RF_CHANGED) { if (DICT) rj[x[k]] = make_uint2(nr[k], nj[k]); else rank[x[k]] = nr[k]; ++nch; }
+        if (fl[k] & RF_KEEP) { oslot[o] = slot[k]; ornk[o] = nr[k]; if (DICT) ojmp[o] = nj[k]; ++o; }
+    }
+    if (stat && nch) atomicAdd(stat, (unsigned long long)nch);
 }
 
 // ---- first state after the initial sort of all N suffixes ---------------------------------------------------------
@@ -419,7 +471,8 @@ template <bool DICT> inline int suffix_sort_doubling(pfp_ctx *c, uint64_t N, uin
         // active lists (two sets, swapped every round) and the per-round outputs; every later list is shorter than the first
         uint32_t *aslot[2], *arnk[2], *ajmp[2] = {nullptr, nullptr}, *newr, *tnj = nullptr, *newj = nullptr, *M = nullptr, *stripe, *lidx; uint8_t *flags; unsigned long long *d_done;
         for (int t = 0; t < 2; ++t) { PFP_ALLOC_HI(c, aslot[t], uint32_t, na); PFP_ALLOC_HI(c, arnk[t], uint32_t, na); if (DICT) PFP_ALLOC_HI(c, ajmp[t], uint32_t, na); }
-        PFP_ALLOC_HI(c, newr, uint32_t, na); PFP_ALLOC_HI(c, flags, uint8_t, na); PFP_ALLOC_HI(c, d_done, unsigned long long, 1);
+        uint32_t *xout;
+        PFP_ALLOC_HI(c, newr, uint32_t, na); PFP_ALLOC_HI(c, xout, uint32_t, na); PFP_ALLOC_HI(c, flags, uint8_t, na); PFP_ALLOC_HI(c, d_done, unsigned long long, 1);
         if (DICT) { PFP_ALLOC_HI(c, tnj, uint32_t, na); PFP_ALLOC_HI(c, newj, uint32_t, na); }
         const uint64_t max_stripes = nblocks(na, CS_STEP) + 1;
         PFP_ALLOC_HI(c, stripe, uint32_t, max_stripes + 4);
@@ -445,7 +498,7 @@ template <bool DICT> inline int suffix_sort_doubling(pfp_ctx *c, uint64_t N, uin
             // algorithmic bytes per active suffix: list entry 8 (+4 jump), SA[slot] 4 in + 4 out, the gathered
             // rank 4 (rank + jump 8, + 1 terminator byte), new rank 4 (+ new jump 4 + 4 through scratch), flag 1
             PFP_LAUNCH(c, K_CLASS_SORT, (uint64_t)na * (DICT ? 46 : 25), (k_round<DICT>), gs, (const uint32_t *)aslot[cur], (const uint32_t *)arnk[cur], (const uint32_t *)ajmp[cur], (uint64_t)na, N, SA,
-                       (const uint32_t *)rank, (const uint2 *)rj, (uint32_t)(h < N ? h : N), D, run_round ? (const uint32_t *)M : (const uint32_t *)nullptr, lowbits, max_range, newr, tnj, newj, flags, stripe, d_done);
+                       (const uint32_t *)rank, (const uint2 *)rj, (uint32_t)(h < N ? h : N), D, run_round ? (const uint32_t *)M : (const uint32_t *)nullptr, lowbits, max_range, newr, xout, tnj, newj, flags, stripe, d_done);
             unsigned long long nd = 0;
             PFP_HIP(c, hipMemcpyAsync(&nd, d_done, 8, hipMemcpyDeviceToHost, c->stream));
             PFP_HIP(c, hipStreamSynchronize(c->stream));
@@ -464,10 +517,10 @@ template <bool DICT> inline int suffix_sort_doubling(pfp_ctx *c, uint64_t N, uin
                 PFP_LAUNCH(c, K_SS_HEADS, nl * 12, k_round_subset_heads, gl, (const uint64_t *)lsk, nl, head);
                 PFP_TRY((device_scan<uint32_t, 1>(c, head, head, nl, nullptr)));
                 PFP_LAUNCH(c, K_SS_WRITE_RANK, nl * 40, (k_round_finish<DICT>), gl, (const uint64_t *)lsk, (const uint32_t *)lsv, (const uint32_t *)head, (const uint32_t *)lidx, nl, N, (const uint32_t *)aslot[cur],
-                           (const uint32_t *)arnk[cur], SA, (const uint2 *)rj, D, newr, newj, flags, stripe);
+                           (const uint32_t *)arnk[cur], SA, (const uint2 *)rj, D, newr, xout, newj, flags, stripe);
             }
             PFP_TRY((device_scan<uint32_t, 0>(c, stripe, stripe, (uint64_t)gs, d_cnt)));
-            PFP_LAUNCH(c, K_SS_WRITE_RANK, (uint64_t)na * (DICT ? 37 : 25), (k_round_apply<DICT>), gs, (const uint32_t *)aslot[cur], (uint64_t)na, (const uint32_t *)SA, (const uint32_t *)newr, (const uint32_t *)newj,
+            PFP_LAUNCH(c, K_SS_WRITE_RANK, (uint64_t)na * (DICT ? 37 : 25), (k_round_apply<DICT>), gs, (const uint32_t *)aslot[cur], (uint64_t)na, (const uint32_t *)xout, (const uint32_t *)newr, (const uint32_t *)newj,
                        (const uint8_t *)flags, (const uint32_t *)stripe, rank, rj, aslot[cur ^ 1], arnk[cur ^ 1], ajmp[cur ^ 1], verbose ? d_done : (unsigned long long *)nullptr);
             if (verbose) {
                 unsigned long long ch = 0;
