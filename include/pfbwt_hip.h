@@ -109,7 +109,7 @@ int pfp_parse_bwt_get(pfp_ctx *ctx, uint8_t *bwlast, void *ilist, void *bwsai);
 
 /* ---- multi-GPU: sharded parse (semantics of PfParser::operator+=, pfparser.hpp:194-263) ---- */
 /* A shard is a run of whole sequences.  Shard r > 0 is fed the w 'A's that end shard r-1 first (pfp_parse_feed(ctx,
- * "AAAA...", w, 0)) as left context, then its sequences; every shard is parsed with pfp_parse_finalize on its own GPU.
+ * "AAAA...", w, 0) or pfp_parse_feed_left_context) as left context, then its sequences; every shard is parsed with pfp_parse_finalize on its own GPU.
  * pfp_shard_view_get exposes the device arrays of a finished local parse (to be copied into send buffers with
  * pfp_device_copy and exchanged with one RCCL all-gather); pfp_merge_shards takes the N views -- device pointers on
  * the calling context's GPU -- and leaves that context in the state pfp_parse_finalize would have produced on the
@@ -121,7 +121,17 @@ typedef struct pfp_shard_view {
     const uint32_t *d_pid;          /* m: word id of every phrase */
     const uint64_t *d_ye;           /* m: 1-based end position of every phrase in the shard's text (= sai) */
     const uint8_t *d_last;          /* m */
+    uint64_t left_context;          /* bytes of left context in front of the shard's own text: w (pfp_parse_feed_left_context: the
+                                       shard was parsed knowing that w 'A's precede it) or 0 (a stand-alone parse, e.g. one made by
+                                       `pfbwt-f --parse-only` and loaded with pfp_shard_load: the merge then re-tests the first w
+                                       windows of the shard like PfParser::operator+=, pfparser.hpp:226-245) */
 } pfp_shard_view;
+/* the w 'A's that end the previous shard, fed as left context of a shard r > 0 (must be the first feed of the shard) */
+int pfp_parse_feed_left_context(pfp_ctx *ctx);
+/* A parse that was saved to <prefix>.dict / <prefix>.parse (pfbwt_io.hpp:234-249; load_parser :211-222 + init_from_dict_ranks,
+ * pfparser.hpp:549-567) becomes a shard on the device: dict = the .dict image (dsize bytes), parse = m 1-based ranks.
+ * The context then answers pfp_shard_view_get (left_context = 0) -- nothing else; it holds no text. */
+int pfp_shard_load(pfp_ctx *ctx, const uint8_t *dict, uint64_t dsize, const uint32_t *parse, uint64_t m);
 int pfp_shard_view_get(pfp_ctx *ctx, pfp_shard_view *view);
 int pfp_device_copy(pfp_ctx *ctx, void *d_dst, const void *d_src, uint64_t bytes);
 int pfp_merge_shards(pfp_ctx *ctx, int nshards, const pfp_shard_view *views, pfp_parse_sizes *out);

@@ -72,6 +72,7 @@ struct pfp_ctx {
     uint64_t err_pos = 0; int err_ch = 0;
     // --- text staging (device): tb = 16 guard bytes (tb[15] = Dollar) + X + w Dollars + slack
     uint8_t *tb = nullptr; size_t tb_cap = 0; uint64_t n = 0; bool text_in_arena = false;
+    uint64_t left_ctx = 0;       // bytes of left context fed in front of this shard's text (pfp_parse_feed_left_context)
     uint64_t tb_n = 0;           // bytes of tb that hold the text of the current parse (0: none -- merged or loaded state)
     // --- parse results (device, arena low end)
     int stage = 0;             // 0 feeding, 1 parsed, 2 parse-bwt done

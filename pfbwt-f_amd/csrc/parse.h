@@ -15,7 +15,7 @@ namespace pfp {
 typedef uint64_t tpos_t;   // text positions (see Spans below)
 
 // include/hash.hpp:12-21
-__device__ __forceinline__ uint64_t wang_hash(uint64_t key)
+__host__ __device__ __forceinline__ uint64_t wang_hash(uint64_t key)
 {
     key = (~key) + (key << 21);
     key = key ^ (key >> 24);
@@ -124,7 +124,7 @@ inline DivTest make_divtest(uint64_t p)
     t.dinv = x; t.limit = ~0ULL / p;
     return t;
 }
-__device__ __forceinline__ bool divisible(uint64_t h, const DivTest &t)
+__host__ __device__ __forceinline__ bool divisible(uint64_t h, const DivTest &t)
 {
     const uint64_t v = h * t.dinv;
     return (t.k ? ((v >> t.k) | (v << (64 - t.k))) : v) <= t.limit;

@@ -59,10 +59,12 @@ static int ensure_text(pfp_ctx *c, uint64_t need_n)
 
 static void reset_results(pfp_ctx *c)
 {
-    c->stage = 0; c->n = 0; c->tb_n = 0; c->m = c->dwords = c->dsize = 0; c->nrows = 0; c->nout = c->runs = c->esa_pairs = 0;
+    c->stage = 0; c->n = 0; c->tb_n = 0; c->left_ctx = 0; c->m = c->dwords = c->dsize = 0; c->nrows = 0; c->nout = c->runs = c->esa_pairs = 0;
     c->gsa_valid = false; c->d_wrank = nullptr; c->d_bwt = nullptr; c->d_sa = c->d_ssa = c->d_esa = nullptr;
     c->d_bwlast = nullptr; c->d_ilist = nullptr; c->d_bwsai = nullptr;
     c->d_ma = nullptr; c->ma_words = 0;
+    c->d_ye = nullptr; c->d_pid = nullptr; c->d_parse = nullptr; c->d_last = nullptr; c->d_dict = nullptr; c->d_ws = nullptr; c->d_wordid = nullptr;
+    c->d_occ = nullptr; c->d_sdict = nullptr; c->d_gsa = nullptr; c->d_grank = nullptr;
     c->arena.reset();
 }
 
@@ -234,6 +236,16 @@ int pfp_text_view(pfp_ctx *c, const uint8_t **d_text, uint64_t *n)
     PFP_HIP(c, hipSetDevice(c->device));
     PFP_HIP(c, hipStreamSynchronize(c->stream));
     *d_text = c->tb + 16; *n = c->n;
+    return PFP_OK;
+}
+int pfp_parse_feed_left_context(pfp_ctx *c)
+{
+    if (!c) return PFP_E_ARG;
+    if (c->stage != 0) { PFP_HIP(c, hipSetDevice(c->device)); reset_results(c); }
+    if (c->n != 0) return PFP_E_STATE;                            // the context must be the first thing a shard is fed
+    const std::vector<uint8_t> a((size_t)c->w, (uint8_t)'A');
+    PFP_TRY(feed_common(c, a.data(), a.size(), 0, hipMemcpyHostToDevice));
+    c->left_ctx = (uint64_t)c->w;
     return PFP_OK;
 }
 int pfp_parse_feed(pfp_ctx *c, const uint8_t *bases, uint64_t len, int end_of_seq) { return feed_common(c, bases, len, end_of_seq, hipMemcpyHostToDevice); }
@@ -545,12 +557,90 @@ __global__ __launch_bounds__(BLOCK) void k_merge_phrases(const uint32_t *pid, co
     else { gye[g] = ye[j] + shift; glast[g] = last[j]; }
 }
 
+__global__ __launch_bounds__(BLOCK) void k_merge_extra(const uint32_t *cand_id, const tpos_t *xye, const uint32_t *xlast, uint32_t nx, uint32_t goff, uint32_t *gpid, tpos_t *gye, uint8_t *glast, uint32_t *occw)
+{
+    const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
+    if (k >= nx) return;
+    const uint32_t id = cand_id[k];
+    gpid[goff + k] = id; gye[goff + k] = xye[k]; glast[goff + k] = (uint8_t)xlast[k];
+    atomicAdd(&occw[id], 1u);
+}
+
+// ---- a saved parse (.dict + .parse) as a shard: load_parser pfbwt_io.hpp:211-222, init_from_dict_ranks pfparser.hpp:549-567 ----
+__global__ __launch_bounds__(BLOCK) void k_shard_phrases(const uint32_t *parse, const uint32_t *ws, const uint8_t *dict, uint64_t m, uint32_t dwords, int w, uint32_t *pid, unsigned long long *adv, uint8_t *last, uint32_t *bad)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (j >= m) return;
+    const uint32_t r = parse[j];
+    if (r == 0 || r > dwords) { atomicAdd(bad, 1u); pid[j] = 0; adv[j] = 0; last[j] = 0; return; }
+    const uint32_t id = r - 1, s = ws[id], len = ws[id + 1] - s - 1u;            // the dictionary image is in rank order: word id = rank - 1
+    if (len <= (uint32_t)w) { atomicAdd(bad, 1u); pid[j] = 0; adv[j] = 0; last[j] = 0; return; }
+    pid[j] = id;
+    adv[j] = j ? (unsigned long long)(len - (uint32_t)w) : (unsigned long long)len;      // phrase 0 starts at Y[0] (its Dollar); later ones overlap by w
+    last[j] = dict[s + len - (uint32_t)w - 1u];                                          // pfparser.hpp:599
+}
+__global__ __launch_bounds__(BLOCK) void k_shard_ends(const unsigned long long *adv_ex, const unsigned long long *adv, uint64_t m, tpos_t *ye)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (j < m) ye[j] = (tpos_t)(adv_ex[j] + adv[j] - 1ULL);                              // Y coordinate of the phrase's last byte
+}
+int pfp_shard_load(pfp_ctx *c, const uint8_t *dict, uint64_t dsize, const uint32_t *parse, uint64_t m)
+{
+    if (!c || !dict || !parse || dsize < 3 || m < 1) return PFP_E_ARG;
+    if (dsize + 64 >= 0xFFFFFFFFULL || m > 0xFFFFFFFEULL - 64) return PFP_E_TOO_LARGE;
+    if (dict[dsize - 1] != EndOfDict || dict[dsize - 2] != EndOfWord) return PFP_E_CORRUPT;
+    PFP_HIP(c, hipSetDevice(c->device));
+    reset_results(c);
+    auto body = [&]() -> int {
+        // a shard context stays small: merge_pfp may hold thousands of them
+        const size_t saved = c->arena_request;
+        if (!saved) c->arena_request = (size_t)(dsize * 26 + m * 48 + ((size_t)4 << 20));
+        const int ra = ensure_arena(c, 0);
+        c->arena_request = saved;
+        if (ra != PFP_OK) return ra;
+        c->arena.reset();
+        PFP_ALLOC_LO(c, c->d_dict, uint8_t, dsize + 16);
+        PFP_ALLOC_LO(c, c->d_pid, uint32_t, m); PFP_ALLOC_LO(c, c->d_ye, tpos_t, m); PFP_ALLOC_LO(c, c->d_last, uint8_t, m);
+        PFP_HIP(c, hipMemsetAsync(c->d_dict + dsize, 0, 16, c->stream));
+        PFP_TRY(h2d_copy(c, c->d_dict, dict, dsize));
+        const size_t mk = c->arena.mark_hi();
+        uint32_t *flag, *wid, *d_cnt, *d_parse; unsigned long long *adv, *advx, *d_tot;
+        PFP_ALLOC_HI(c, flag, uint32_t, dsize); PFP_ALLOC_HI(c, wid, uint32_t, dsize); PFP_ALLOC_HI(c, d_cnt, uint32_t, 2);
+        PFP_LAUNCH(c, K_MISC, dsize * 5, k_eow_flags, nblocks(dsize, BLOCK), (const uint8_t *)c->d_dict, dsize, flag);
+        PFP_TRY((device_scan<uint32_t, 0>(c, flag, wid, dsize, d_cnt)));
+        uint32_t nw = 0; PFP_TRY(d2h_u32(c, d_cnt, &nw));
+        if (nw < 1) return PFP_E_CORRUPT;
+        PFP_ALLOC_LO(c, c->d_ws, uint32_t, (size_t)nw + 2);
+        PFP_LAUNCH(c, K_MISC, dsize * 5, k_ws_from_flags, nblocks(dsize, BLOCK), (const uint8_t *)c->d_dict, dsize, (const uint32_t *)wid, c->d_ws);
+        PFP_ALLOC_HI(c, d_parse, uint32_t, m); PFP_ALLOC_HI(c, adv, unsigned long long, m); PFP_ALLOC_HI(c, advx, unsigned long long, m); PFP_ALLOC_HI(c, d_tot, unsigned long long, 1);
+        PFP_TRY(h2d_copy(c, (uint8_t *)d_parse, (const uint8_t *)parse, m * 4));
+        PFP_HIP(c, hipMemsetAsync(d_cnt + 1, 0, 4, c->stream));
+        PFP_LAUNCH(c, K_MISC, m * 24, k_shard_phrases, nblocks(m, BLOCK), (const uint32_t *)d_parse, (const uint32_t *)c->d_ws, (const uint8_t *)c->d_dict, m, nw, c->w, c->d_pid, adv, c->d_last, d_cnt + 1);
+        PFP_TRY((device_scan<unsigned long long, 0>(c, adv, advx, m, d_tot)));
+        PFP_LAUNCH(c, K_MISC, m * 24, k_shard_ends, nblocks(m, BLOCK), (const unsigned long long *)advx, (const unsigned long long *)adv, m, c->d_ye);
+        uint32_t bad = 0; unsigned long long tot = 0;
+        PFP_HIP(c, hipMemcpyAsync(&bad, d_cnt + 1, 4, hipMemcpyDeviceToHost, c->stream));
+        PFP_HIP(c, hipMemcpyAsync(&tot, d_tot, 8, hipMemcpyDeviceToHost, c->stream));
+        PFP_HIP(c, hipStreamSynchronize(c->stream));
+        if (bad || tot < (unsigned long long)c->w + 2) return PFP_E_CORRUPT;           // a rank outside the dictionary, or a word of at most w bytes
+        c->arena.release_hi(mk);
+        c->dwords = nw; c->dsize = dsize; c->m = m;
+        c->n = tot - 1 - (uint64_t)c->w;                                               // Y holds Dollar + X + w Dollars
+        c->left_ctx = 0; c->stage = 1;
+        return PFP_OK;
+    };
+    const int rc = body();
+    if (rc != PFP_OK) reset_results(c);
+    return rc;
+}
+
 int pfp_shard_view_get(pfp_ctx *c, pfp_shard_view *v)
 {
     if (!c || !v) return PFP_E_ARG;
     if (c->stage < 1 || !c->d_pid || !c->d_last) return PFP_E_STATE;
     v->n = c->n; v->m = c->m; v->dwords = c->dwords; v->dsize = c->dsize;
     v->d_dict = c->d_dict; v->d_ws = c->d_ws; v->d_pid = c->d_pid; v->d_ye = c->d_ye; v->d_last = c->d_last;
+    v->left_context = c->left_ctx;
     return PFP_OK;
 }
 
@@ -578,8 +668,10 @@ static int merge_shards_impl(pfp_ctx *c, int nshards, const pfp_shard_view *v, p
     const uint32_t w = (uint32_t)c->w;
     uint64_t ntot = 0, mtot = 0, dtot = 0, ctot = 0;
     for (int r = 0; r < nshards; ++r) {
-        if (v[r].m < 2 || v[r].n < (r ? w + 1 : 1) || !v[r].d_dict || !v[r].d_ws || !v[r].d_pid || !v[r].d_ye || !v[r].d_last) return PFP_E_ARG;
-        ntot += v[r].n - (r ? w : 0); mtot += v[r].m - (r ? 1 : 0); dtot += v[r].dsize; ctot += v[r].dwords;
+        const uint64_t lc = v[r].left_context;
+        if ((lc != 0 && lc != w) || (r == 0 && lc != 0)) return PFP_E_ARG;
+        if (v[r].m < 2 || v[r].n < lc + 1 || !v[r].d_dict || !v[r].d_ws || !v[r].d_pid || !v[r].d_ye || !v[r].d_last) return PFP_E_ARG;
+        ntot += v[r].n - lc; mtot += v[r].m - (r ? 1 : 0); dtot += v[r].dsize; ctot += v[r].dwords;
     }
     if (ntot + w + 64 >= ((c->flags & PFP_FLAG_U64) ? (1ULL << 40) : 0xFFFFFFFFULL) || dtot + 64 >= 0xFFFFFFFFULL || mtot > 0xFFFFFFFEULL - 64) return PFP_E_TOO_LARGE;
     reset_results(c);
@@ -611,32 +703,97 @@ static int merge_shards_impl(pfp_ctx *c, int nshards, const pfp_shard_view *v, p
             if (fr[r].wl.size() < (size_t)w) return PFP_E_CORRUPT;
         }
     }
-    std::vector<uint8_t> junc; std::vector<uint32_t> jstart((size_t)nshards + 1, 0);
+    // Junction phrases of every seam r | r+1.  tail = last phrase of shard r without its w Dollars, head = first phrase of
+    // shard r+1 without its Dollar (and without the left context, if it was parsed with one).  A shard that knew its left
+    // context has already cut its head at every trigger; a stand-alone shard could not trigger in its first w windows
+    // (pfparser.hpp:347 "pos_ > w"), so those windows are re-tested here exactly as PfParser::operator+= does (:226-245): the k-mer
+    // of window i < w sees the w 'A's that end shard r as zeros.  Piece 0 = tail + head[0..t_1], piece j = the phrase that
+    // ends at trigger t_{j+1} (it starts w-1 characters before t_j: in the 'A' pad for t_j < w-1), the last piece ends where
+    // the head ends.
+    struct Piece { uint32_t js, je; tpos_t ye; uint8_t last; };               // span in the junction buffer, global end position, last char
+    std::vector<uint8_t> junc; std::vector<std::vector<Piece>> pieces((size_t)nshards);
+    std::vector<tpos_t> shift((size_t)nshards);
+    { uint64_t g = 0; for (int r = 0; r < nshards; ++r) { shift[r] = (tpos_t)(g - v[r].left_context); g += v[r].n - v[r].left_context; } }
+    const DivTest dt = make_divtest(c->p);
+    const uint64_t kmask = (w == 32) ? 0ULL : ((1ULL << (2 * w)) - 1ULL);
+    uint64_t extra = 0;
     for (int r = 0; r + 1 < nshards; ++r) {
-        jstart[r] = (uint32_t)junc.size();
-        junc.insert(junc.end(), fr[r].wl.begin(), fr[r].wl.end() - w);                 // tail of shard r without its w Dollars
-        junc.insert(junc.end(), fr[r + 1].w0.begin() + 1 + w, fr[r + 1].w0.end());     // head of shard r+1 without Dollar + context
-        jstart[r + 1] = (uint32_t)junc.size();
+        const uint32_t lc = (uint32_t)v[r + 1].left_context;
+        if (fr[r + 1].w0.size() < 1 + (size_t)lc + 1) return PFP_E_CORRUPT;
+        const std::vector<uint8_t> tail(fr[r].wl.begin(), fr[r].wl.end() - w);
+        const std::vector<uint8_t> head(fr[r + 1].w0.begin() + 1 + lc, fr[r + 1].w0.end());
+        std::vector<uint32_t> trig;                                            // trigger positions inside the head's first w windows
+        if (lc == 0) {
+            uint64_t kmer = 0;
+            for (uint32_t i = 0; i < w && i < head.size(); ++i) {
+                const uint8_t ch = head[i];
+                const uint64_t code = (ch == 'C') ? 1 : (ch == 'G') ? 2 : (ch == 'T' || ch == '-') ? 3 : 0;      // the text is normalised: A, N -> 0
+                kmer = ((kmer << 2) | code) & kmask;
+                if (i + 1 < head.size() && divisible(wang_hash(kmer), dt)) trig.push_back(i);   // the head's own last character ends its phrase anyway
+            }
+        }
+        const tpos_t G = shift[r + 1] + lc;                                    // global index of the head's first character
+        auto add_piece = [&](const std::vector<uint8_t> &bytes, tpos_t ye) {
+            Piece pc; pc.js = (uint32_t)junc.size(); junc.insert(junc.end(), bytes.begin(), bytes.end()); pc.je = (uint32_t)junc.size() - 1u;
+            pc.ye = ye; pc.last = bytes.size() > (size_t)w ? bytes[bytes.size() - w - 1] : (uint8_t)Dollar;
+            pieces[r].push_back(pc);
+        };
+        uint32_t from = 0;                                                     // first head character of the current piece
+        std::vector<uint8_t> cur(tail);
+        for (size_t k = 0; k <= trig.size(); ++k) {
+            const uint32_t to = k < trig.size() ? trig[k] : (uint32_t)head.size() - 1u;      // last head character of the piece
+            cur.insert(cur.end(), head.begin() + from, head.begin() + to + 1);
+            add_piece(cur, (tpos_t)(G + to + 1));
+            if (k < trig.size()) {   // the next phrase starts w - 1 characters before the trigger: 'A's of the pad, then head characters
+                cur.clear();
+                const uint32_t t = trig[k];
+                if (t + 1 < w) cur.assign((size_t)(w - 1 - t), (uint8_t)'A');
+                const uint32_t hs = t + 1 >= w ? t + 1 - w : 0;
+                cur.insert(cur.end(), head.begin() + hs, head.begin() + t + 1);
+                from = t + 1;
+            }
+        }
+        extra += pieces[r].size() - 1;
     }
+    if (mtot + extra > 0xFFFFFFFEULL - 64) return PFP_E_TOO_LARGE;
+    mtot += extra;
     // ---- device: one buffer with all dictionaries + junction words, candidate spans
     uint8_t *U; uint32_t *cys, *cye, *cand_id;
+    const uint64_t call = ctot + extra;                                        // the shards' words + the extra junction phrases
     PFP_ALLOC_HI(c, U, uint8_t, dtot + junc.size() + 64);
-    PFP_ALLOC_HI(c, cys, uint32_t, ctot); PFP_ALLOC_HI(c, cye, uint32_t, ctot); PFP_ALLOC_HI(c, cand_id, uint32_t, ctot);
+    PFP_ALLOC_HI(c, cys, uint32_t, call); PFP_ALLOC_HI(c, cye, uint32_t, call); PFP_ALLOC_HI(c, cand_id, uint32_t, call);
     std::vector<uint32_t> ubase((size_t)nshards), coff((size_t)nshards);
     { uint64_t ub = 0, co = 0; for (int r = 0; r < nshards; ++r) { ubase[r] = (uint32_t)ub; coff[r] = (uint32_t)co; ub += v[r].dsize; co += v[r].dwords; } }
     for (int r = 0; r < nshards; ++r) PFP_HIP(c, hipMemcpyAsync(U + ubase[r], v[r].d_dict, (size_t)v[r].dsize, hipMemcpyDeviceToDevice, c->stream));
     if (!junc.empty()) PFP_HIP(c, hipMemcpyAsync(U + dtot, junc.data(), junc.size(), hipMemcpyHostToDevice, c->stream));
+    const uint32_t jb = (uint32_t)dtot;
     for (int r = 0; r < nshards; ++r) {
-        const uint32_t jb = (uint32_t)dtot;
-        const uint32_t f0s = r > 0 ? jb + jstart[r - 1] : 0, f0e = r > 0 ? jb + jstart[r] - 1 : 0;
-        const uint32_t fls = r + 1 < nshards ? jb + jstart[r] : 0, fle = r + 1 < nshards ? jb + jstart[r + 1] - 1 : 0;
+        // the first word of a shard r > 0 and the last word of a shard r < N-1 are fragments: both are re-pointed at piece 0 of
+        // their seam (the first word is referenced by no phrase that is kept)
+        const uint32_t f0s = r > 0 ? jb + pieces[r - 1][0].js : 0, f0e = r > 0 ? jb + pieces[r - 1][0].je : 0;
+        const uint32_t fls = r + 1 < nshards ? jb + pieces[r][0].js : 0, fle = r + 1 < nshards ? jb + pieces[r][0].je : 0;
         PFP_LAUNCH(c, K_MISC, v[r].dwords * 12, k_merge_spans, nblocks(v[r].dwords, BLOCK), v[r].d_ws, (uint32_t)v[r].dwords, ubase[r], coff[r],
                    fr[r].id0, f0s, f0e, fr[r].idl, fls, fle, cys, cye);
+    }
+    std::vector<uint32_t> xs, xe, xlast; std::vector<tpos_t> xye; std::vector<uint32_t> xfirst((size_t)nshards + 1, 0);
+    for (int r = 0; r + 1 < nshards; ++r) {
+        xfirst[r] = (uint32_t)xs.size();
+        for (size_t k = 1; k < pieces[r].size(); ++k) { xs.push_back(jb + pieces[r][k].js); xe.push_back(jb + pieces[r][k].je); xye.push_back(pieces[r][k].ye); xlast.push_back(pieces[r][k].last); }
+        xfirst[r + 1] = (uint32_t)xs.size();
+    }
+    tpos_t *d_xye = nullptr; uint32_t *d_xlast = nullptr;
+    if (extra) {
+        PFP_ALLOC_HI(c, d_xye, tpos_t, extra); PFP_ALLOC_HI(c, d_xlast, uint32_t, extra);
+        PFP_HIP(c, hipMemcpyAsync(cys + ctot, xs.data(), extra * 4, hipMemcpyHostToDevice, c->stream));
+        PFP_HIP(c, hipMemcpyAsync(cye + ctot, xe.data(), extra * 4, hipMemcpyHostToDevice, c->stream));
+        PFP_HIP(c, hipMemcpyAsync(d_xye, xye.data(), extra * sizeof(tpos_t), hipMemcpyHostToDevice, c->stream));
+        PFP_HIP(c, hipMemcpyAsync(d_xlast, xlast.data(), extra * 4, hipMemcpyHostToDevice, c->stream));
+        PFP_HIP(c, hipStreamSynchronize(c->stream));                          // the host vectors go out of use below
     }
     // ---- global distinct words, dictionary
     Spans sp; sp.ye = nullptr; sp.ys32 = cys; sp.ye32 = cye; sp.w = 0;
     uint64_t dwords = 0; uint32_t *rep, *occ_cand, *occw;
-    PFP_TRY(dedup_strings(c, U, sp, ctot, dtot + junc.size(), cand_id, &dwords, &rep, &occ_cand));
+    PFP_TRY(dedup_strings(c, U, sp, call, dtot + junc.size(), cand_id, &dwords, &rep, &occ_cand));
     PFP_TRY(build_dictionary(c, U, sp, rep, dwords));
     // ---- global phrase sequence
     c->n = ntot; c->m = mtot;
@@ -644,18 +801,22 @@ static int merge_shards_impl(pfp_ctx *c, int nshards, const pfp_shard_view *v, p
     PFP_ALLOC_HI(c, occw, uint32_t, dwords);
     PFP_HIP(c, hipMemsetAsync(occw, 0, dwords * 4, c->stream));
     {
-        uint64_t goff = 0, gtext = 0;
-        std::vector<tpos_t> shift((size_t)nshards);
-        { uint64_t g = 0; for (int r = 0; r < nshards; ++r) { shift[r] = r ? (tpos_t)(g - w) : (tpos_t)0; g += v[r].n - (r ? w : 0); } }
-        (void)gtext;
+        uint64_t goff = 0;
         for (int r = 0; r < nshards; ++r) {
             const uint32_t j0 = r ? 1u : 0u, cnt = (uint32_t)v[r].m - j0;
             const int hj = r + 1 < nshards;
-            const tpos_t jye = hj ? fr[r + 1].ye0 + shift[r + 1] : (tpos_t)0; const uint32_t jl = hj ? fr[r + 1].last0 : 0u;
+            const tpos_t jye = hj ? pieces[r][0].ye : (tpos_t)0; const uint32_t jl = hj ? pieces[r][0].last : 0u;
             PFP_LAUNCH(c, K_MISC, cnt * 24, k_merge_phrases, nblocks(cnt, BLOCK), v[r].d_pid, v[r].d_ye, v[r].d_last, (uint32_t)v[r].m, j0, (uint32_t)goff, coff[r], shift[r],
                        (const uint32_t *)cand_id, jye, jl, hj, c->d_pid, c->d_ye, c->d_last, occw);
             goff += cnt;
+            if (hj && pieces[r].size() > 1) {   // the extra junction phrases of this seam follow piece 0
+                const uint32_t nx = (uint32_t)pieces[r].size() - 1u;
+                PFP_LAUNCH(c, K_MISC, nx * 24, k_merge_extra, nblocks(nx, BLOCK), (const uint32_t *)cand_id + ctot + xfirst[r], (const tpos_t *)d_xye + xfirst[r], (const uint32_t *)d_xlast + xfirst[r], nx, (uint32_t)goff,
+                           c->d_pid, c->d_ye, c->d_last, occw);
+                goff += nx;
+            }
         }
+        if (goff != mtot) return PFP_E_CORRUPT;
     }
     PFP_TRY(finish_parse(c, occw));
     PFP_HIP(c, hipStreamSynchronize(c->stream));

@@ -121,15 +121,21 @@ template <typename Hasher = WangHash> struct PfParser {
         ensure_ctx();
         pfp_parse_sizes sz;
         engine_check(ctx_, pfp_parse_finalize(ctx_, &sz), "pfp_parse_finalize");
-        n_ = sz.n; dict_.resize(sz.dsize); occs_.resize(sz.dwords); parse_ranks_.resize(sz.m); last_.resize(sz.m);
-        if (params_.get_sai) sai_.resize(sz.m); else sai_.clear();
-        engine_check(ctx_, pfp_parse_get(ctx_, (uint8_t *)dict_.data(), occs_.data(), parse_ranks_.data(), (uint8_t *)last_.data(), params_.get_sai ? sai_.data() : nullptr), "pfp_parse_get");
-        // NUL-terminated keys for get_sorted_phrases(): private copy of the dict image with EndOfWord -> 0
-        keys_ = dict_; sorted_phrases_.clear(); sorted_phrases_.reserve(sz.dwords);
-        size_t start = 0;
-        for (size_t i = 0; i + 1 < keys_.size(); ++i) if (keys_[i] == EndOfWord) { keys_[i] = 0; sorted_phrases_.push_back(keys_.data() + start); start = i + 1; }
-        finalized_ = true; parse_bwt_done_ = false;
+        fetch_results(sz);
     }
+    // Exact merge of parses on the device (PfParser::operator+= over N operands, pfparser.hpp:194-263; what src/merge_pfp.cpp:97-113
+    // folds): the shards' dictionaries are united and de-duplicated, every seam is re-hashed, the result is the parse of the
+    // concatenated texts -- no text is rebuilt or re-parsed.  `views` come from pfp_shard_view_get of contexts that hold a parse
+    // (pfp_parse_finalize) or a loaded one (pfp_shard_load).  The merged parser holds no text: it cannot be appended to.
+    void merge_device_shards(const std::vector<pfp_shard_view> &views)
+    {
+        ensure_ctx();
+        pfp_parse_sizes sz;
+        engine_check(ctx_, pfp_merge_shards(ctx_, (int)views.size(), views.data(), &sz), "pfp_merge_shards");
+        n_fed_ = sz.n; nseqs_ = views.size();
+        fetch_results(sz);
+    }
+    void set_docs(const std::vector<UIntType> &starts, const std::vector<std::string> &names) { doc_starts_ = starts; doc_names_ = names; }
     void sort_dict() { finalize(); }
     void generate_ranks() { finalize(); }
     void regenerate_parse() { finalize(); }
@@ -167,6 +173,17 @@ template <typename Hasher = WangHash> struct PfParser {
     bool parse_bwt_done() const { return parse_bwt_done_; }
 
   private:
+    void fetch_results(const pfp_parse_sizes &sz)
+    {
+        n_ = sz.n; dict_.resize(sz.dsize); occs_.resize(sz.dwords); parse_ranks_.resize(sz.m); last_.resize(sz.m);
+        if (params_.get_sai) sai_.resize(sz.m); else sai_.clear();
+        engine_check(ctx_, pfp_parse_get(ctx_, (uint8_t *)dict_.data(), occs_.data(), parse_ranks_.data(), (uint8_t *)last_.data(), params_.get_sai ? sai_.data() : nullptr), "pfp_parse_get");
+        // NUL-terminated keys for get_sorted_phrases(): private copy of the dict image with EndOfWord -> 0
+        keys_ = dict_; sorted_phrases_.clear(); sorted_phrases_.reserve(sz.dwords);
+        size_t start = 0;
+        for (size_t i = 0; i + 1 < keys_.size(); ++i) if (keys_[i] == EndOfWord) { keys_[i] = 0; sorted_phrases_.push_back(keys_.data() + start); start = i + 1; }
+        finalized_ = true; parse_bwt_done_ = false;
+    }
     void ensure_ctx()
     {
         if (ctx_) return;

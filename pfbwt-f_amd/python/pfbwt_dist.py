@@ -22,7 +22,7 @@ def pack_local_shard(ctx, device):
     buf = torch.empty(max(tot, 256), dtype=torch.uint8, device=device)
     for off, b, ptr in zip(offs, sizes, (v.d_dict, v.d_ws, v.d_pid, v.d_ye, v.d_last)):
         ctx.device_copy(buf.data_ptr() + off, ptr, b)
-    meta = torch.tensor([v.n, v.m, v.dwords, v.dsize, tot], dtype=torch.int64, device=device)
+    meta = torch.tensor([v.n, v.m, v.dwords, v.dsize, tot, v.left_context], dtype=torch.int64, device=device)
     return buf, meta
 
 
@@ -50,8 +50,8 @@ def allgather_shards(ctx, device, group=None):
         torch.cuda.synchronize(device)
     views = []
     for r in range(world):
-        n, m, dw, ds, _ = (int(x) for x in metas[r])
-        v = pfbwt_hip.ShardView(); v.n, v.m, v.dwords, v.dsize = n, m, dw, ds
+        n, m, dw, ds, _, lc = (int(x) for x in metas[r])
+        v = pfbwt_hip.ShardView(); v.n, v.m, v.dwords, v.dsize, v.left_context = n, m, dw, ds, lc
         off, ptrs = 0, []
         for b in v.nbytes():
             ptrs.append(recv[r].data_ptr() + off); off = _align(off + b)

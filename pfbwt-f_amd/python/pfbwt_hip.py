@@ -32,7 +32,8 @@ class BwtSizes(C.Structure):
 
 class ShardView(C.Structure):
     _fields_ = [("n", C.c_uint64), ("m", C.c_uint64), ("dwords", C.c_uint64), ("dsize", C.c_uint64),
-                ("d_dict", C.c_void_p), ("d_ws", C.c_void_p), ("d_pid", C.c_void_p), ("d_ye", C.c_void_p), ("d_last", C.c_void_p)]
+                ("d_dict", C.c_void_p), ("d_ws", C.c_void_p), ("d_pid", C.c_void_p), ("d_ye", C.c_void_p), ("d_last", C.c_void_p),
+                ("left_context", C.c_uint64)]
 
     def nbytes(self):
         """byte sizes of the five device arrays, in field order"""
@@ -75,6 +76,8 @@ def load_library(path=None):
     L.pfp_bwt_get.argtypes = [vp, vp, vp, vp, vp]
     L.pfp_bwt_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.pfp_shard_view_get.argtypes = [vp, C.POINTER(ShardView)]
+    L.pfp_parse_feed_left_context.argtypes = [vp]
+    L.pfp_shard_load.argtypes = [vp, vp, u64, vp, u64]
     L.pfp_device_copy.argtypes = [vp, vp, vp, u64]
     L.pfp_merge_shards.argtypes = [vp, i32, C.POINTER(ShardView), C.POINTER(ParseSizes)]
     L.pfp_sacak_int_u32.argtypes = [vp, vp, C.c_uint32, C.c_uint32]
@@ -171,9 +174,14 @@ class PfpContext:
         """`count` equal-length records that already sit in device memory, `stride` bytes apart"""
         self._check(self.L.pfp_parse_feed_device_batch(self.h, C.c_void_p(int(dev_ptr)), int(count), int(length), int(stride)))
 
-    def feed_left_context(self, w):
-        """shard r > 0: the w 'A's that end the previous shard (pfparser.hpp:335-337)"""
-        self.feed(b"A" * w, end_of_seq=False)
+    def feed_left_context(self, w=None):
+        """shard r > 0: the w 'A's that end the previous shard (pfparser.hpp:335-337); recorded in the shard view"""
+        self._check(self.L.pfp_parse_feed_left_context(self.h))
+
+    def shard_load(self, dict_image, parse):
+        """a parse saved as .dict / .parse becomes a (stand-alone) shard on the device"""
+        d = np.ascontiguousarray(dict_image, np.uint8); p = np.ascontiguousarray(parse, np.uint32)
+        self._check(self.L.pfp_shard_load(self.h, _ptr(d), d.size, _ptr(p), p.size))
 
     def shard_view(self):
         v = ShardView()

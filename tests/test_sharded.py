@@ -20,15 +20,24 @@ def synth(seed, L, H, nruns=(0, 0, 0, 0)):
     return out
 
 
-def sharded_single_process(factory, seqs, shards, w, p, U):
+def sharded_single_process(factory, seqs, shards, w, p, U, mode="context"):
+    """mode: "context" -- shard r > 0 is parsed with the w 'A's of its left neighbour (the multi-GPU convention);
+    "standalone" -- every shard is parsed on its own, the merge re-tests the first w windows (PfParser::operator+=, :226-245);
+    "loaded" -- every shard is parsed on its own by the ORACLE, saved as .dict / .parse images and loaded (merge_pfp from files)"""
     ctxs, views = [], []
     for r, grp in enumerate(shards):
         c = factory(w=w, p=p, u64=(U == 8), sai=True)
-        if r > 0:
-            c.feed_left_context(w)
-        for i in grp:
-            c.feed(seqs[i], True)
-        c.finalize(); ctxs.append(c); views.append(c.shard_view())
+        if mode == "loaded":
+            o = oracle_run([seqs[i] for i in grp], w=w, p=p, U=U)
+            c.shard_load(o["dict"], o["parse"])
+        else:
+            if r > 0 and mode == "context":
+                c.feed_left_context(w)
+            for i in grp:
+                c.feed(seqs[i], True)
+            c.finalize()
+        ctxs.append(c); views.append(c.shard_view())
+        assert views[-1].left_context == (w if (r > 0 and mode == "context") else 0)
     g = factory(w=w, p=p, u64=(U == 8), sai=True)
     sz = g.merge_shards(views)
     res = {"n": sz.n, "m": sz.m, "dwords": sz.dwords, "dsize": sz.dsize}
@@ -51,6 +60,28 @@ def test_sharded_merge_emu(emu_factory):
     for w, p, shards in ((10, 100, [[0], [1], [2], [3]]), (4, 7, [[0, 1], [2, 3]]), (4, 7, [[0], [1, 2, 3]])):
         ref = oracle_run(seqs, w=w, p=p, U=4)
         assert compare(sharded_single_process(emu_factory, seqs, shards, w, p, 4), ref, 4) == []
+
+
+def seam_trigger_seqs():
+    """sequences whose first w windows hold triggers for (w, p) = (4, 3) and (6, 2): a stand-alone parse cannot cut there"""
+    rng = np.random.default_rng(17)
+    return [bytes(rng.choice(list(b"ACGT"), n).astype(np.uint8)) for n in (900, 35, 700, 5, 1200, 64, 300)]
+
+
+@pytest.mark.parametrize("mode", ["standalone", "loaded"])
+def test_merge_of_standalone_shards_emu(emu_factory, mode):
+    """pfp_merge_shards on shards that were parsed WITHOUT knowing their left neighbour (merge_pfp on saved parses,
+    src/merge_pfp.cpp:97-113): the seam is re-hashed like PfParser::operator+= (pfparser.hpp:226-245) -- extra junction phrases
+    where the first w windows of a shard hold triggers; result == the single parse on every array"""
+    seqs = seam_trigger_seqs()
+    extra_seen = False
+    for w, p, shards in ((4, 3, [[0], [1], [2], [3], [4], [5], [6]]), (6, 2, [[0, 1], [2], [3, 4, 5], [6]]), (10, 100, [[0, 1, 2], [3, 4, 5, 6]])):
+        ref = oracle_run(seqs, w=w, p=p, U=8)
+        res = sharded_single_process(emu_factory, seqs, shards, w, p, 8, mode=mode)
+        assert compare(res, ref, 8) == [], (mode, w, p)
+        parts = sum(int(oracle_run([seqs[i] for i in g], w=w, p=p, U=8)["m"]) for g in shards)
+        extra_seen |= int(ref["m"]) > parts - (len(shards) - 1)            # more phrases than "every seam fuses two fragments into one"
+    assert extra_seen, "no seam of the test inputs needed an extra junction phrase"
 
 
 WORKER = r'''
@@ -190,6 +221,20 @@ def test_sharded_merge_gpu(gpu_ctx_factory):
     seqs = synth(10, 60000, 4)
     ref = oracle_run(seqs, w=4, p=7, U=8)
     assert compare(sharded_single_process(gpu_ctx_factory, seqs, [[0], [1, 2], [3]], 4, 7, 8), ref, 8) == []
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["standalone", "loaded"])
+def test_merge_of_standalone_shards_gpu(gpu_ctx_factory, mode):
+    """merge_pfp's case on the card: shards parsed on their own (or loaded from saved .dict/.parse images) -- the seams are
+    re-hashed inside pfp_merge_shards"""
+    seqs = seam_trigger_seqs()
+    for w, p, shards in ((4, 3, [[0], [1], [2], [3], [4], [5], [6]]), (6, 2, [[0, 1], [2], [3, 4, 5], [6]])):
+        ref = oracle_run(seqs, w=w, p=p, U=8)
+        assert compare(sharded_single_process(gpu_ctx_factory, seqs, shards, w, p, 8, mode=mode), ref, 8) == [], (mode, w, p)
+    seqs = synth(9, 300000, 6, (50000, 40000, 200000, 500))
+    ref = oracle_run(seqs, w=10, p=100, U=4)
+    assert compare(sharded_single_process(gpu_ctx_factory, seqs, [[0, 1], [2, 3], [4, 5]], 10, 100, 4, mode=mode), ref, 4) == []
 
 
 NCCL_WORKER = r'''

@@ -54,8 +54,8 @@ for r in range(a.ranks):
     ctx.close()
 views = []
 for r in range(a.ranks):
-    n, m, dw, ds, _ = (int(x) for x in metas[r])
-    v = pfbwt_hip.ShardView(); v.n, v.m, v.dwords, v.dsize = n, m, dw, ds
+    n, m, dw, ds, _, lc = (int(x) for x in metas[r])
+    v = pfbwt_hip.ShardView(); v.n, v.m, v.dwords, v.dsize, v.left_context = n, m, dw, ds, lc
     off, ptrs = 0, []
     for b in v.nbytes():
         ptrs.append(packed[r].data_ptr() + off); off = pfbwt_dist._align(off + b)
