@@ -84,19 +84,33 @@ __global__ __launch_bounds__(BLOCK) void k_ss_runend_marks(const uint8_t *D, uin
 
 // ---- state of the refinement -------------------------------------------------------------------------------------
 //   SA[slot] = x                          suffixes in the order found so far; a class = a contiguous range of slots
-//   int alphabet:  rank[x]                slot of the head of x's class (one 4-byte gather gives the second key part:
-//                                         jumps are uniform there, the suffix h positions on is x + h)
+//   int alphabet:  rank[x]                slot of the head of x's class (jumps are uniform there: the suffix one covered
+//                                         prefix on is x + h)
 //   dictionary:    rj[x] = {rank, jump}   jump = end of the prefix [x, jump) the rank orders x by; never past the first
 //                                         byte after the word's EndOfWord, so "the covered prefix contains the
 //                                         terminator" (the class is a group of identical suffixes, final) is
-//                                         D[jump - 1] == EndOfWord; one 8-byte gather gives rank and jump of the target
+//                                         D[jump - 1] == EndOfWord
 //   active list, in slot order:  aslot[a], arnk[a] = rank of its class (= slot of the class head), ajmp[a] (dictionary)
-// One round = k_round (sort inside every class by the rank of the suffix one covered prefix on, new heads, new ranks,
-// SA; the pairs cross HBM once) + k_round_apply (ranks that changed are scattered to rank[] / rj[] only now -- a round
-// must read the ranks of ONE state --, the list of classes that still have to be refined is compacted per stripe).
+// One round = k_round (sort inside every class by the ranks of the next K covered prefixes, new heads, new ranks, SA;
+// the pairs cross HBM once) + k_round_apply (ranks that changed are scattered to rank[] / rj[] only now -- a round must
+// read the ranks of ONE state --, the list of classes that still have to be refined is compacted per stripe).
+//
+// K = 3 ("quadrupling"): what bounds a round is the random gather of the second key -- one 128-byte line per pair for 4
+// useful bytes (PMC: 165 B of HBM traffic per pair) -- and the scatter of the new ranks; the LDS sort costs ~1.5 ms per
+// 8-bit pass and 325 M pairs (VALU-bound: the eight ballots per item; measured: K = 1 rounds 14.3 ms for 6 passes, K = 3
+// rounds 26.5 ms for 14), so three ranks per round cost less than two rounds of one and halve the scatters.  A pass in
+// TEXT order (coalesced) therefore first builds T[y] = {rank of y, of the suffix one covered prefix behind y, of the one
+// two behind; (dictionary) the jump behind the third}: ONE 16-byte gather per pair then orders the class by three further
+// prefixes, the covered prefix grows 4x per round and the rounds (gathers, scatters, compactions) halve.  When few pairs
+// are left the table is not worth a pass over all N positions: the kernel then follows the chain itself.
 constexpr uint32_t RUN_MIN = DK_CHARS;
-constexpr uint32_t CS_STEP = RS_TILE / 2;
 constexpr uint8_t RF_KEEP = 1, RF_CHANGED = 2, RF_DONE = 4;
+#ifndef PFP_K3_ITEMS
+#define PFP_K3_ITEMS 9
+#endif
+// pairs per thread of the class-sort tile: 15 -> 3840 pairs, 49 KiB of LDS with 8-byte keys (three workgroups per CU);
+// 9 -> 2304 pairs with the 16-byte keys of K = 3 (50 KiB)
+template <int K> struct RoundCfg { static constexpr int ITEMS = K == 1 ? RS_ITEMS : PFP_K3_ITEMS, TILE = BLOCK * ITEMS; static constexpr uint32_t STEP = TILE / 2; };
 
 __global__ __launch_bounds__(BLOCK) void k_not_done(const uint8_t *done, uint64_t n, uint32_t *flag)
 {
@@ -115,26 +129,54 @@ __device__ __forceinline__ uint64_t class_start_at_or_after(const uint32_t *arnk
     return lo;
 }
 
-// Workgroup j owns the classes that START in [j*CS_STEP, (j+1)*CS_STEP) of the active list; they end where the first
-// class of the next stripe starts (at most one tile of pairs; a longer range -- a class with thousands of members -- is
-// left alone: its flags stay 0 and the pairs go through the global radix sort, k_round_keys / k_round_finish).
-template <bool DICT> __global__ __launch_bounds__(BLOCK) void k_round(const uint32_t *aslot, const uint32_t *arnk, const uint32_t *ajmp, uint64_t na, uint64_t N,
-                                                                      uint32_t *SA, const uint32_t *rank, const uint2 *rj, uint32_t h, const uint8_t *D, const uint32_t *M /*run round*/,
-                                                                      int lowbits, uint32_t max_range, uint32_t *newr, uint32_t *xout /*the sorted suffixes, in list order*/, uint32_t *tnj, uint32_t *newj, uint8_t *flags,
-                                                                      uint32_t *stripe_keep, unsigned long long *ndone)
+// the three ranks behind y (and the jump behind the third), straight from the state: the chain stops at the prefix that
+// holds the word's terminator (nothing behind it is compared; both members of a tie stop at the same link)
+template <bool DICT> __device__ __forceinline__ uint4 chain3(const uint32_t *rank, const uint2 *rj, uint64_t N, uint64_t y, uint32_t h, const uint8_t *D)
 {
-    constexpr int ITEMS = RS_ITEMS, TILE = RS_TILE;
+    if (!DICT) {
+        const uint64_t y2 = y + h, y3 = y2 + h;
+        return make_uint4(y < N ? rank[y] : 0u, y2 < N ? rank[y2] : 0u, y3 < N ? rank[y3] : 0u, 0u);
+    }
+    uint4 t = make_uint4(0u, 0u, 0u, (uint32_t)N);
+    if (y >= N) return t;
+    uint2 q = rj[y]; t.x = q.x; t.w = q.y;
+    if (q.y >= N || D[q.y - 1] == EndOfWord) return t;
+    q = rj[q.y]; t.y = q.x; t.w = q.y;
+    if (q.y >= N || D[q.y - 1] == EndOfWord) return t;
+    q = rj[q.y]; t.z = q.x; t.w = q.y;
+    return t;
+}
+// T[y] for every position, in text order (the chain of a dictionary position stays inside its word: neighbouring lines)
+template <bool DICT> __global__ __launch_bounds__(BLOCK) void k_round_table(const uint32_t *rank, const uint2 *rj, uint64_t N, uint32_t h, const uint8_t *D, uint4 *T)
+{
+    const uint64_t y = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (y < N) T[y] = chain3<DICT>(rank, rj, N, y, h, D);
+}
+
+// Workgroup j owns the classes that START in [j*STEP, (j+1)*STEP) of the active list; they end where the first class of
+// the next stripe starts (at most one tile of pairs; a longer range -- a class with thousands of members -- is left
+// alone: its flags stay 0 and the pairs go through the global radix sort, k_round_keys / k_round_finish).
+// Sort keys in LDS: A = (class - first class of the range) << lowbits | first rank; K = 3: B = second rank << lowbits |
+// third rank.
+template <bool DICT, int K> __global__ __launch_bounds__(BLOCK) void k_round(const uint32_t *aslot, const uint32_t *arnk, const uint32_t *ajmp, uint64_t na, uint64_t N,
+                                                                             uint32_t *SA, const uint32_t *rank, const uint2 *rj, const uint4 *T /*K = 3; null: follow the chain*/, uint32_t h, const uint8_t *D,
+                                                                             const uint32_t *M /*run round (K = 1)*/, int lowbits, uint32_t max_range, uint32_t *newr,
+                                                                             uint32_t *xout /*the sorted suffixes, in list order*/, uint32_t *tnj, uint32_t *newj, uint8_t *flags, uint32_t *stripe_keep, unsigned long long *ndone)
+{
+    constexpr int ITEMS = RoundCfg<K>::ITEMS, TILE = RoundCfg<K>::TILE;
+    constexpr uint32_t STEP = RoundCfg<K>::STEP;
     __shared__ uint32_t wh[BLOCK / WAVE][RS_RADIX];
     __shared__ uint64_t skeys[TILE];
+    __shared__ uint64_t skeyb[K == 3 ? TILE : 1];
     __shared__ uint16_t sidx[TILE];                      // payload of the LDS sort: index of the pair in the range
     __shared__ uint16_t shp[TILE + 1];                   // position (in the sorted range) of the head of every pair's new class
     __shared__ unsigned long long red[4];
     __shared__ uint64_t bound[2];
-    const uint64_t w0 = (uint64_t)blockIdx.x * CS_STEP;
-    if (threadIdx.x < 2) bound[threadIdx.x] = class_start_at_or_after(arnk, na, w0 + (uint64_t)threadIdx.x * CS_STEP);
+    const uint64_t w0 = (uint64_t)blockIdx.x * STEP;
+    if (threadIdx.x < 2) bound[threadIdx.x] = class_start_at_or_after(arnk, na, w0 + (uint64_t)threadIdx.x * STEP);
     __syncthreads();
     const uint64_t s = bound[0], e = bound[1];
-    if (s >= w0 + CS_STEP || s >= na) return;             // no class starts in this stripe
+    if (s >= w0 + STEP || s >= na) return;                // no class starts in this stripe
     if (e - s > (uint64_t)max_range) return;              // a class with more members than a tile holds
     const uint32_t n = (uint32_t)(e - s);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -142,12 +184,12 @@ template <bool DICT> __global__ __launch_bounds__(BLOCK) void k_round(const uint
     const uint32_t nit = (n + BLOCK - 1) / BLOCK;
     const uint32_t base = (uint32_t)wave * (nit * WAVE) + lane;   // wave w owns the contiguous pairs [w * nit * 64, (w + 1) * nit * 64)
     const uint32_t hmin = arnk[s];
-    // ---- keys: (rank of the class, rank of the suffix one covered prefix further on).  Three dependent gathers per pair
-    //      (list entry -> SA[slot] -> rank of the target): all of a thread's pairs go through each stage together, so that a
-    //      tile pays three memory latencies, not three per pair (measured: 15.6 -> see DESIGN.md section 4 per full round)
+    // ---- keys.  Dependent gathers per pair (list entry -> SA[slot] -> ranks of the target): all of a thread's pairs go
+    //      through each stage together, so that a tile pays the memory latencies once, not once per pair
     uint32_t xi[ITEMS];                                  // the suffixes of this thread's pairs (by position before the sort)
     {
         uint32_t sl[ITEMS], lowv[ITEMS], njv[ITEMS], yj[ITEMS];
+        uint32_t r2[K == 3 ? ITEMS : 1], r3[K == 3 ? ITEMS : 1];
 #pragma unroll
         for (int it = 0; it < ITEMS; ++it) {
             const uint32_t j = threadIdx.x + (uint32_t)it * BLOCK;
@@ -156,7 +198,16 @@ template <bool DICT> __global__ __launch_bounds__(BLOCK) void k_round(const uint
         }
 #pragma unroll
         for (int it = 0; it < ITEMS; ++it) { const uint32_t j = threadIdx.x + (uint32_t)it * BLOCK; xi[it] = j < n ? SA[sl[it]] : 0u; }
-        if (!DICT) {
+        if (K == 3) {
+#pragma unroll
+            for (int it = 0; it < ITEMS; ++it) {
+                const uint32_t j = threadIdx.x + (uint32_t)it * BLOCK;
+                const uint64_t y = DICT ? (uint64_t)yj[it] : (uint64_t)xi[it] + h;
+                uint4 t = make_uint4(0u, 0u, 0u, (uint32_t)N);
+                if (j < n) { if (T) { if (y < N) t = T[y]; } else t = chain3<DICT>(rank, rj, N, y, h, D); }
+                lowv[it] = t.x; r2[it] = t.y; r3[it] = t.z; njv[it] = t.w;
+            }
+        } else if (!DICT) {
 #pragma unroll
             for (int it = 0; it < ITEMS; ++it) {
                 const uint32_t j = threadIdx.x + (uint32_t)it * BLOCK;
@@ -197,17 +248,20 @@ template <bool DICT> __global__ __launch_bounds__(BLOCK) void k_round(const uint
             if (j < n) {
                 if (DICT) tnj[s + j] = njv[it];
                 skeys[j] = ((uint64_t)(arnk[s + j] - hmin) << lowbits) | lowv[it]; sidx[j] = (uint16_t)j;
+                if (K == 3) skeyb[j] = ((uint64_t)r2[it] << lowbits) | r3[it];
             }
         }
     }
     __syncthreads();
-    // ---- LSD radix sort of the range inside LDS: the low part, then the span of the (already ordered) class part
+    // ---- LSD radix sort of the range inside LDS: (K = 3: the two ranks of B,) the low part of A, then the span of the
+    //      (already ordered) class part
     const uint64_t lomask = lowbits >= 64 ? ~0ULL : ((1ULL << lowbits) - 1);
     const uint64_t hspan = skeys[n - 1] >> lowbits;
+    const int nb = K == 3 ? (2 * lowbits + 7) / 8 : 0;
     const int nlo = (lowbits + 7) / 8;
     int nhi = 0; while (nhi < 8 && (hspan >> (8 * nhi))) ++nhi;
-    for (int p = 0; p < nlo + nhi; ++p) {
-        uint64_t k[ITEMS]; uint16_t v[ITEMS]; unsigned dg[ITEMS];
+    for (int p = 0; p < nb + nlo + nhi; ++p) {
+        uint64_t k[ITEMS], kb[K == 3 ? ITEMS : 1]; uint16_t v[ITEMS]; unsigned dg[ITEMS];
 #pragma unroll
         for (int w = 0; w < BLOCK / WAVE; ++w) wh[w][threadIdx.x] = 0;
         __syncthreads();
@@ -217,7 +271,10 @@ template <bool DICT> __global__ __launch_bounds__(BLOCK) void k_round(const uint
             const uint32_t i = base + (uint32_t)it * WAVE;
             const bool valid = i < n;
             k[it] = valid ? skeys[i] : 0ULL; v[it] = valid ? sidx[i] : (uint16_t)0;
-            const unsigned d = p < nlo ? (unsigned)((k[it] & lomask) >> (8 * p)) & (RS_RADIX - 1) : (unsigned)((k[it] >> lowbits) >> (8 * (p - nlo))) & (RS_RADIX - 1);
+            if (K == 3) kb[it] = valid ? skeyb[i] : 0ULL;
+            unsigned d;
+            if (K == 3 && p < nb) d = (unsigned)(kb[K == 3 ? it : 0] >> (8 * p)) & (RS_RADIX - 1);
+            else { const int q = p - nb; d = q < nlo ? (unsigned)((k[it] & lomask) >> (8 * q)) & (RS_RADIX - 1) : (unsigned)((k[it] >> lowbits) >> (8 * (q - nlo))) & (RS_RADIX - 1); }
             unsigned long long peers = __ballot(valid);
 #pragma unroll
             for (int bb = 0; bb < 8; ++bb) {
@@ -246,7 +303,11 @@ template <bool DICT> __global__ __launch_bounds__(BLOCK) void k_round(const uint
 #pragma unroll
         for (int it = 0; it < ITEMS; ++it) {
             const uint32_t i = base + (uint32_t)it * WAVE;
-            if ((uint32_t)it < nit && i < n) { const uint32_t li = wh[wave][dg[it] & 255u] + (dg[it] >> 8); skeys[li] = k[it]; sidx[li] = v[it]; }
+            if ((uint32_t)it < nit && i < n) {
+                const uint32_t li = wh[wave][dg[it] & 255u] + (dg[it] >> 8);
+                skeys[li] = k[it]; sidx[li] = v[it];
+                if (K == 3) skeyb[li] = kb[K == 3 ? it : 0];
+            }
         }
         __syncthreads();
     }
@@ -255,7 +316,7 @@ template <bool DICT> __global__ __launch_bounds__(BLOCK) void k_round(const uint
     const uint32_t c0 = threadIdx.x * nit, c1 = (c0 + nit < n) ? c0 + nit : n;
     uint32_t runmax = 0;
     for (uint32_t j = c0; j < c1; ++j) {
-        const bool hd = j == 0 || skeys[j] != skeys[j - 1];
+        const bool hd = j == 0 || skeys[j] != skeys[j - 1] || (K == 3 && skeyb[j] != skeyb[j - 1]);
         runmax = hd ? j : runmax;
         shp[j] = (uint16_t)runmax;                       // exact only behind the first head of the chunk; fixed below
     }
@@ -309,7 +370,7 @@ template <bool DICT> __global__ __launch_bounds__(BLOCK) void k_round(const uint
     for (int it = 0; it < ITEMS; ++it) {
         const uint32_t j = threadIdx.x + (uint32_t)it * BLOCK;
         if (j < n) {
-            if (flg[it] & RF_KEEP) keepn += 1ULL << (20 * (uint32_t)((s + j) / CS_STEP - blockIdx.x));
+            if (flg[it] & RF_KEEP) keepn += 1ULL << (20 * (uint32_t)((s + j) / STEP - blockIdx.x));
             if (DICT) newj[s + j] = njo[it];
             SA[slo[it]] = xs[it]; newr[s + j] = nrv[it]; flags[s + j] = flg[it]; xout[s + j] = xs[it];
         }
@@ -322,17 +383,23 @@ template <bool DICT> __global__ __launch_bounds__(BLOCK) void k_round(const uint
     }
 }
 
-// pairs of the ranges k_round left alone: keys for the global radix sort (idx = their positions in the active list)
-template <bool DICT> __global__ __launch_bounds__(BLOCK) void k_round_keys(const uint32_t *idx, uint64_t nl, const uint32_t *aslot, const uint32_t *arnk, const uint32_t *ajmp, uint64_t N,
-                                                                           const uint32_t *SA, const uint32_t *rank, const uint2 *rj, uint32_t h, const uint8_t *D, const uint32_t *M, int lowbits,
-                                                                           uint64_t *keys, uint32_t *vals, uint32_t *tnj)
+// pairs of the ranges k_round left alone (idx = their positions in the active list): keys for the global radix sort, the
+// payload is the pair's index i in this subset; ux / tnj keep its suffix and new jump.  K = 3: the two ranks of kb are
+// sorted first, then (stable) ka.
+template <bool DICT, int K> __global__ __launch_bounds__(BLOCK) void k_round_keys(const uint32_t *idx, uint64_t nl, const uint32_t *aslot, const uint32_t *arnk, const uint32_t *ajmp, uint64_t N,
+                                                                                  const uint32_t *SA, const uint32_t *rank, const uint2 *rj, const uint4 *T, uint32_t h, const uint8_t *D, const uint32_t *M, int lowbits,
+                                                                                  uint64_t *ka, uint64_t *kb, uint32_t *ux, uint32_t *tnj)
 {
     const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= nl) return;
     const uint32_t a = idx[i];
     const uint32_t x = SA[aslot[a]];
     uint32_t low, nx = 0;
-    if (!DICT) { const uint64_t y = (uint64_t)x + h; low = y < N ? rank[y] : 0u; }
+    if (K == 3) {
+        const uint64_t y = DICT ? (uint64_t)ajmp[a] : (uint64_t)x + h;
+        const uint4 t = T ? (y < N ? T[y] : make_uint4(0u, 0u, 0u, (uint32_t)N)) : chain3<DICT>(rank, rj, N, y, h, D);
+        low = t.x; nx = t.w; kb[i] = ((uint64_t)t.y << lowbits) | t.z;
+    } else if (!DICT) { const uint64_t y = (uint64_t)x + h; low = y < N ? rank[y] : 0u; }
     else {
         bool run = false;
         if (M) {
@@ -345,57 +412,63 @@ template <bool DICT> __global__ __launch_bounds__(BLOCK) void k_round_keys(const
             }
         }
         if (!run) { const uint32_t y = ajmp[a]; const uint2 Q = y < N ? rj[y] : make_uint2(0u, (uint32_t)N); low = Q.x; nx = Q.y; }
-        tnj[a] = nx;
     }
-    keys[i] = ((uint64_t)arnk[a] << lowbits) | low; vals[i] = x;
+    if (DICT) tnj[a] = nx;
+    ka[i] = ((uint64_t)arnk[a] << lowbits) | low; ux[i] = x;
 }
-// sorted[i] -> which entry of the unsorted subset it was is not known after a radix sort of (key, x) pairs; the new jump
-// of x is therefore parked in rj[x].y between the two (no k_round of this round reads rj any more)
-__global__ __launch_bounds__(BLOCK) void k_round_park_jumps(const uint32_t *idx, uint64_t nl, const uint32_t *aslot, const uint32_t *SA, const uint32_t *tnj, uint2 *rj)
+__global__ __launch_bounds__(BLOCK) void k_copy_keys_iota(const uint64_t *src, uint64_t n, uint64_t *keys, uint32_t *vals)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) { keys[i] = src[i]; vals[i] = (uint32_t)i; }
+}
+// second sort of K = 3: the pairs, ordered by kb, get their ka as key (in place of the sorted kb)
+__global__ __launch_bounds__(BLOCK) void k_gather_keys(const uint64_t *ka, const uint32_t *perm, uint64_t n, uint64_t *keys)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) keys[i] = ka[perm[i]];
+}
+__global__ __launch_bounds__(BLOCK) void k_round_subset_heads(const uint64_t *keys /*sorted ka*/, const uint64_t *kb /*by subset index; null for K = 1*/, const uint32_t *perm, uint64_t nl, uint32_t *headidx)
 {
     const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= nl) return;
-    const uint32_t a = idx[i];
-    reinterpret_cast<uint32_t *>(rj)[2 * (uint64_t)SA[aslot[a]] + 1] = tnj[a];
-}
-__global__ __launch_bounds__(BLOCK) void k_round_subset_heads(const uint64_t *keys, uint64_t nl, uint32_t *headidx)
-{
-    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i < nl) headidx[i] = (i == 0 || keys[i] != keys[i - 1]) ? (uint32_t)i : 0u;
+    bool hd = i == 0 || keys[i] != keys[i - 1];
+    if (!hd && kb) hd = kb[perm[i]] != kb[perm[i - 1]];
+    headidx[i] = hd ? (uint32_t)i : 0u;
 }
 // the sorted subset goes back to its positions (whole classes, in order): same outputs as k_round
-template <bool DICT> __global__ __launch_bounds__(BLOCK) void k_round_finish(const uint64_t *keys, const uint32_t *vals, const uint32_t *headidx /*max-scanned*/, const uint32_t *idx, uint64_t nl, uint64_t N,
-                                                                             const uint32_t *aslot, const uint32_t *arnk, uint32_t *SA, const uint2 *rj, const uint8_t *D,
+template <bool DICT> __global__ __launch_bounds__(BLOCK) void k_round_finish(const uint32_t *perm, const uint32_t *ux, const uint32_t *tnj, const uint32_t *headidx /*max-scanned*/, const uint32_t *idx, uint64_t nl, uint64_t N,
+                                                                             const uint32_t *aslot, const uint32_t *arnk, uint32_t *SA, const uint8_t *D, uint32_t step,
                                                                              uint32_t *newr, uint32_t *xout, uint32_t *newj, uint8_t *flags, uint32_t *stripe_keep)
 {
     const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= nl) return;
-    const uint32_t a = idx[i], hi = headidx[i], x = vals[i];
+    const uint32_t a = idx[i], hi = headidx[i], src = perm[i], x = ux[src];
     const bool single = hi == (uint32_t)i && (i + 1 == nl || headidx[i + 1] == (uint32_t)(i + 1));
     const uint32_t nr = aslot[idx[hi]];
     bool keep = !single;
     uint8_t fl = RF_DONE;
     if (DICT) {
-        const uint32_t nj = rj[x].y;
+        const uint32_t nj = tnj[idx[src]];
         newj[a] = nj;
         keep = keep && !(nj >= N || D[nj - 1] == EndOfWord);
         fl |= RF_CHANGED;
     } else if (nr != arnk[a]) fl |= RF_CHANGED;
     if (keep) fl |= RF_KEEP;
     SA[aslot[a]] = x; newr[a] = nr; flags[a] = fl; xout[a] = x;
-    if (keep) atomicAdd(&stripe_keep[a / CS_STEP], 1u);
+    if (keep) atomicAdd(&stripe_keep[a / step], 1u);
 }
 
 // second half of a round: ranks (and jumps) that changed go to rank[] / rj[] now, the pairs of classes that still have
 // to be refined move to the next active list -- stripe by stripe, at the offsets the scan of stripe_keep gave
-template <bool DICT> __global__ __launch_bounds__(BLOCK) void k_round_apply(const uint32_t *aslot, uint64_t na, const uint32_t *xsorted, const uint32_t *newr, const uint32_t *newj,
-                                                                            const uint8_t *flags, const uint32_t *stripe_base, uint32_t *rank, uint2 *rj,
-                                                                            uint32_t *oslot, uint32_t *ornk, uint32_t *ojmp, unsigned long long *stat /*nullable (PFP_VERBOSE): ranks scattered*/)
+template <bool DICT, int K> __global__ __launch_bounds__(BLOCK) void k_round_apply(const uint32_t *aslot, uint64_t na, const uint32_t *xsorted, const uint32_t *newr, const uint32_t *newj,
+                                                                                   const uint8_t *flags, const uint32_t *stripe_base, uint32_t *rank, uint2 *rj,
+                                                                                   uint32_t *oslot, uint32_t *ornk, uint32_t *ojmp, unsigned long long *stat /*nullable (PFP_VERBOSE): ranks scattered*/)
 {
-    constexpr int PER = (CS_STEP + BLOCK - 1) / BLOCK;          // a thread owns PER consecutive pairs of the stripe: one block scan per stripe,
+    constexpr uint32_t STEP = RoundCfg<K>::STEP;
+    constexpr int PER = (STEP + BLOCK - 1) / BLOCK;             // a thread owns PER consecutive pairs of the stripe: one block scan per stripe,
     __shared__ uint32_t red[4];                                  // the loads of all its pairs in flight together
-    const uint64_t s = (uint64_t)blockIdx.x * CS_STEP;
-    const uint64_t e = s + CS_STEP < na ? s + CS_STEP : na;
+    const uint64_t s = (uint64_t)blockIdx.x * STEP;
+    const uint64_t e = s + STEP < na ? s + STEP : na;
     const uint64_t a0 = s + (uint64_t)threadIdx.x * PER;
     uint8_t fl[PER]; uint32_t slot[PER], nr[PER], nj[PER], x[PER], kept = 0;
 #pragma unroll
@@ -443,6 +516,78 @@ template <bool DICT> __global__ __launch_bounds__(BLOCK) void k_init_active(cons
     if (DICT) ajmp[o] = vals[a] + (uint32_t)(keys[a] >> 56);
 }
 
+struct RoundBufs {
+    uint32_t *aslot[2], *arnk[2], *ajmp[2], *newr, *xout, *tnj, *newj, *M, *stripe, *lidx, *head, *keep, *pos, *d_cnt;
+    uint8_t *flags; unsigned long long *d_done; uint4 *T;
+    uint64_t *k0, *k1; uint32_t *v0, *v1;
+};
+
+// one refinement round over the active list `cur` (na pairs) -> list cur ^ 1; *na_out = its length
+template <bool DICT, int K> inline int suffix_sort_round(pfp_ctx *c, RoundBufs &b, int cur, uint32_t na, uint64_t N, uint64_t h, const uint8_t *D, bool run_round, int rbits, uint32_t max_range,
+                                                         uint32_t *SA, uint32_t *rank, uint2 *rj, bool verbose, uint32_t *na_out)
+{
+    constexpr uint32_t STEP = RoundCfg<K>::STEP;
+    const int lowbits = run_round ? 32 : rbits;
+    const unsigned gs = nblocks(na, STEP);
+    const uint32_t hh = (uint32_t)(h < N ? h : N);
+    const uint32_t *Mr = run_round ? (const uint32_t *)b.M : (const uint32_t *)nullptr;
+    PFP_HIP(c, hipMemsetAsync(b.flags, 0, na, c->stream));
+    PFP_HIP(c, hipMemsetAsync(b.stripe, 0, ((size_t)gs + 3) * 4, c->stream));
+    PFP_HIP(c, hipMemsetAsync(b.d_done, 0, 8, c->stream));
+    const uint4 *T = nullptr;
+    if (K == 3 && b.T && (uint64_t)na * 8 > N) {     // the table pays for itself when more than ~ N/9 pairs gather from it (28 B per position against two more 128-byte lines per pair)
+        PFP_LAUNCH(c, K_SS_MAKE_KEYS, N * (DICT ? 40 : 28), (k_round_table<DICT>), nblocks(N, BLOCK), (const uint32_t *)rank, (const uint2 *)rj, N, hh, D, b.T);
+        T = b.T;
+    }
+    // algorithmic bytes per active suffix: list entry 8 (+4 jump), SA[slot] 4 in + 4 out, the gathered
+    // rank 4 (K = 3: 12; dictionary: + jump 4, + 1 terminator byte), new rank 4 (+ new jump 4 + 4 through scratch), flag 1
+    PFP_LAUNCH(c, K_CLASS_SORT, (uint64_t)na * ((DICT ? 46 : 25) + (K == 3 ? 8 : 0)), (k_round<DICT, K>), gs, (const uint32_t *)b.aslot[cur], (const uint32_t *)b.arnk[cur], (const uint32_t *)b.ajmp[cur], (uint64_t)na, N, SA,
+               (const uint32_t *)rank, (const uint2 *)rj, T, hh, D, Mr, lowbits, max_range, b.newr, b.xout, b.tnj, b.newj, b.flags, b.stripe, b.d_done);
+    unsigned long long nd = 0;
+    PFP_HIP(c, hipMemcpyAsync(&nd, b.d_done, 8, hipMemcpyDeviceToHost, c->stream));
+    PFP_HIP(c, hipStreamSynchronize(c->stream));
+    const uint64_t nl = na - nd;
+    if (nl) {   // classes too large for a tile: collect their pairs, sort them globally, put them back
+        if (verbose) fprintf(stderr, "[pfbwt_hip]   class sort: %u pairs, %llu in classes too large for one tile\n", na, (unsigned long long)nl);
+        const size_t mk = c->arena.mark_hi();
+        uint64_t *ka, *kb = nullptr; uint32_t *ux;
+        PFP_ALLOC_HI(c, ka, uint64_t, nl); PFP_ALLOC_HI(c, ux, uint32_t, nl);
+        if (K == 3) PFP_ALLOC_HI(c, kb, uint64_t, nl);
+        const unsigned ga = nblocks(na, BLOCK), gl = nblocks(nl, BLOCK);
+        PFP_LAUNCH(c, K_COMPACT, (uint64_t)na * 5, k_not_done, ga, (const uint8_t *)b.flags, (uint64_t)na, b.keep);
+        PFP_TRY(device_compact(c, nullptr, b.keep, na, b.lidx, b.pos, b.d_cnt));
+        PFP_LAUNCH(c, K_SS_MAKE_KEYS, nl * 48, (k_round_keys<DICT, K>), gl, (const uint32_t *)b.lidx, nl, (const uint32_t *)b.aslot[cur], (const uint32_t *)b.arnk[cur], (const uint32_t *)b.ajmp[cur], N, (const uint32_t *)SA,
+                   (const uint32_t *)rank, (const uint2 *)rj, T, hh, D, Mr, lowbits, ka, kb, ux, b.tnj);
+        uint64_t *lsk = b.k0; uint32_t *lsv = b.v0; uint64_t *alk = b.k1; uint32_t *alv = b.v1;
+        if (K == 3) {
+            PFP_LAUNCH(c, K_SS_MAKE_KEYS, nl * 20, k_copy_keys_iota, gl, (const uint64_t *)kb, nl, b.k0, b.v0);
+            BitRange rb = {0, 2 * lowbits};
+            PFP_TRY(radix_sort_pairs<uint64_t>(c, b.k0, b.v0, b.k1, b.v1, nl, &rb, 1, &lsk, &lsv));
+            PFP_LAUNCH(c, K_SS_MAKE_KEYS, nl * 20, k_gather_keys, gl, (const uint64_t *)ka, (const uint32_t *)lsv, nl, lsk);
+            alk = lsk == b.k0 ? b.k1 : b.k0; alv = lsv == b.v0 ? b.v1 : b.v0;
+        } else PFP_LAUNCH(c, K_SS_MAKE_KEYS, nl * 20, k_copy_keys_iota, gl, (const uint64_t *)ka, nl, b.k0, b.v0);
+        BitRange rr = {0, lowbits + rbits};
+        uint64_t *fsk; uint32_t *fsv;
+        PFP_TRY(radix_sort_pairs<uint64_t>(c, lsk, lsv, alk, alv, nl, &rr, 1, &fsk, &fsv));
+        PFP_LAUNCH(c, K_SS_HEADS, nl * 12, k_round_subset_heads, gl, (const uint64_t *)fsk, (const uint64_t *)kb, (const uint32_t *)fsv, nl, b.head);
+        PFP_TRY((device_scan<uint32_t, 1>(c, b.head, b.head, nl, nullptr)));
+        PFP_LAUNCH(c, K_SS_WRITE_RANK, nl * 40, (k_round_finish<DICT>), gl, (const uint32_t *)fsv, (const uint32_t *)ux, (const uint32_t *)b.tnj, (const uint32_t *)b.head, (const uint32_t *)b.lidx, nl, N,
+                   (const uint32_t *)b.aslot[cur], (const uint32_t *)b.arnk[cur], SA, D, STEP, b.newr, b.xout, b.newj, b.flags, b.stripe);
+        c->arena.release_hi(mk);
+    }
+    PFP_TRY((device_scan<uint32_t, 0>(c, b.stripe, b.stripe, (uint64_t)gs, b.d_cnt)));
+    PFP_LAUNCH(c, K_SS_WRITE_RANK, (uint64_t)na * (DICT ? 37 : 25), (k_round_apply<DICT, K>), gs, (const uint32_t *)b.aslot[cur], (uint64_t)na, (const uint32_t *)b.xout, (const uint32_t *)b.newr, (const uint32_t *)b.newj,
+               (const uint8_t *)b.flags, (const uint32_t *)b.stripe, rank, rj, b.aslot[cur ^ 1], b.arnk[cur ^ 1], b.ajmp[cur ^ 1], verbose ? b.d_done : (unsigned long long *)nullptr);
+    if (verbose) {
+        unsigned long long ch = 0;
+        PFP_HIP(c, hipMemcpyAsync(&ch, b.d_done, 8, hipMemcpyDeviceToHost, c->stream));
+        PFP_HIP(c, hipStreamSynchronize(c->stream));
+        fprintf(stderr, "[pfbwt_hip]   K=%d%s: ranks scattered this round: %llu (the round kernel handled %llu pairs)\n", K, T ? " (table)" : "", ch - nd, nd);
+    }
+    PFP_TRY(d2h_u32(c, b.d_cnt, na_out));
+    return PFP_OK;
+}
+
 // Sorts the N suffixes described by (k0, v0) [keys = first characters, vals = x; dictionary keys carry the initial jump
 // offset in bits 56..60].  Outputs SA (slot -> x) and, per x, the slot of its class head: rank[x] (int alphabet,
 // DICT = false: symbols are compared one by one, the covered prefix after the initial sort is h0 symbols) or rj[x].x
@@ -452,84 +597,59 @@ template <bool DICT> inline int suffix_sort_doubling(pfp_ctx *c, uint64_t N, uin
                                                     const BitRange *init_ranges, int n_init_ranges, uint32_t h0, const uint8_t *D, uint32_t *SA, uint32_t *rank, uint2 *rj, int *rounds_out)
 {
     const size_t mk = c->arena.mark_hi();
-    uint32_t *head, *aux, *keep, *pos, *d_cnt;
-    PFP_ALLOC_HI(c, head, uint32_t, N); PFP_ALLOC_HI(c, aux, uint32_t, N); PFP_ALLOC_HI(c, keep, uint32_t, N); PFP_ALLOC_HI(c, pos, uint32_t, N);
-    PFP_ALLOC_HI(c, d_cnt, uint32_t, 4);
+    RoundBufs b{};
+    uint32_t *aux;
+    PFP_ALLOC_HI(c, b.head, uint32_t, N); PFP_ALLOC_HI(c, aux, uint32_t, N); PFP_ALLOC_HI(c, b.keep, uint32_t, N); PFP_ALLOC_HI(c, b.pos, uint32_t, N);
+    PFP_ALLOC_HI(c, b.d_cnt, uint32_t, 4);
     uint64_t *sk; uint32_t *sv;
     PFP_TRY(radix_sort_pairs<uint64_t>(c, k0, v0, k1, v1, N, init_ranges, n_init_ranges, &sk, &sv));
     const unsigned gN = nblocks(N, BLOCK);
-    uint64_t keymask = 0; for (int r = 0; r < n_init_ranges; ++r) for (int b = init_ranges[r].lo; b < init_ranges[r].hi; ++b) keymask |= 1ULL << b;
-    PFP_LAUNCH(c, K_SS_HEADS, N * 24, k_ss_heads, gN, (const uint64_t *)sk, (const uint32_t *)sv, N, keymask, SA, head, aux);
+    uint64_t keymask = 0; for (int r = 0; r < n_init_ranges; ++r) for (int bb = init_ranges[r].lo; bb < init_ranges[r].hi; ++bb) keymask |= 1ULL << bb;
+    PFP_LAUNCH(c, K_SS_HEADS, N * 24, k_ss_heads, gN, (const uint64_t *)sk, (const uint32_t *)sv, N, keymask, SA, b.head, aux);
     PFP_TRY((device_scan<uint32_t, 1>(c, aux, aux, N, nullptr)));
-    PFP_LAUNCH(c, K_SS_WRITE_RANK, N * 24, (k_init_state<DICT>), gN, (const uint64_t *)sk, (const uint32_t *)sv, (const uint32_t *)head, (const uint32_t *)aux, N, rank, rj, keep);
-    PFP_TRY((device_scan<uint32_t, 0>(c, keep, pos, N, d_cnt)));
-    uint32_t na = 0; PFP_TRY(d2h_u32(c, d_cnt, &na));
+    PFP_LAUNCH(c, K_SS_WRITE_RANK, N * 24, (k_init_state<DICT>), gN, (const uint64_t *)sk, (const uint32_t *)sv, (const uint32_t *)b.head, (const uint32_t *)aux, N, rank, rj, b.keep);
+    PFP_TRY((device_scan<uint32_t, 0>(c, b.keep, b.pos, N, b.d_cnt)));
+    uint32_t na = 0; PFP_TRY(d2h_u32(c, b.d_cnt, &na));
     int rounds = 1;
     const int rbits = bits_for(N);
     static const bool verbose = getenv("PFP_VERBOSE") != nullptr;
+    static const int force_k = getenv("PFP_SORT_K") ? atoi(getenv("PFP_SORT_K")) : 0;      // tests / A-B runs: 1 = plain doubling in every round
     if (na > 0) {
         // active lists (two sets, swapped every round) and the per-round outputs; every later list is shorter than the first
-        uint32_t *aslot[2], *arnk[2], *ajmp[2] = {nullptr, nullptr}, *newr, *tnj = nullptr, *newj = nullptr, *M = nullptr, *stripe, *lidx; uint8_t *flags; unsigned long long *d_done;
-        for (int t = 0; t < 2; ++t) { PFP_ALLOC_HI(c, aslot[t], uint32_t, na); PFP_ALLOC_HI(c, arnk[t], uint32_t, na); if (DICT) PFP_ALLOC_HI(c, ajmp[t], uint32_t, na); }
-        uint32_t *xout;
-        PFP_ALLOC_HI(c, newr, uint32_t, na); PFP_ALLOC_HI(c, xout, uint32_t, na); PFP_ALLOC_HI(c, flags, uint8_t, na); PFP_ALLOC_HI(c, d_done, unsigned long long, 1);
-        if (DICT) { PFP_ALLOC_HI(c, tnj, uint32_t, na); PFP_ALLOC_HI(c, newj, uint32_t, na); }
-        const uint64_t max_stripes = nblocks(na, CS_STEP) + 1;
-        PFP_ALLOC_HI(c, stripe, uint32_t, max_stripes + 4);
-        PFP_ALLOC_HI(c, lidx, uint32_t, na);
-        PFP_LAUNCH(c, K_COMPACT, N * 24, (k_init_active<DICT>), gN, (const uint64_t *)sk, (const uint32_t *)sv, (const uint32_t *)aux, (const uint32_t *)keep, (const uint32_t *)pos, N, aslot[0], arnk[0], ajmp[0]);
+        for (int t = 0; t < 2; ++t) { PFP_ALLOC_HI(c, b.aslot[t], uint32_t, na); PFP_ALLOC_HI(c, b.arnk[t], uint32_t, na); if (DICT) PFP_ALLOC_HI(c, b.ajmp[t], uint32_t, na); }
+        PFP_ALLOC_HI(c, b.newr, uint32_t, na); PFP_ALLOC_HI(c, b.xout, uint32_t, na); PFP_ALLOC_HI(c, b.flags, uint8_t, na); PFP_ALLOC_HI(c, b.d_done, unsigned long long, 1);
+        if (DICT) { PFP_ALLOC_HI(c, b.tnj, uint32_t, na); PFP_ALLOC_HI(c, b.newj, uint32_t, na); }
+        const uint64_t max_stripes = nblocks(na, RoundCfg<3>::STEP < RoundCfg<1>::STEP ? RoundCfg<3>::STEP : RoundCfg<1>::STEP) + 1;
+        PFP_ALLOC_HI(c, b.stripe, uint32_t, max_stripes + 4);
+        PFP_ALLOC_HI(c, b.lidx, uint32_t, na);
+        PFP_LAUNCH(c, K_COMPACT, N * 24, (k_init_active<DICT>), gN, (const uint64_t *)sk, (const uint32_t *)sv, (const uint32_t *)aux, (const uint32_t *)b.keep, (const uint32_t *)b.pos, N, b.aslot[0], b.arnk[0], b.ajmp[0]);
         if (DICT && D) {   // run lengths for the run round
-            PFP_ALLOC_HI(c, M, uint32_t, N);
-            PFP_LAUNCH(c, K_SS_MAKE_KEYS, N * 5, k_ss_runend_marks, gN, D, N, M);
-            PFP_TRY((device_scan<uint32_t, 1>(c, M, M, N, nullptr)));
+            PFP_ALLOC_HI(c, b.M, uint32_t, N);
+            PFP_LAUNCH(c, K_SS_MAKE_KEYS, N * 5, k_ss_runend_marks, gN, D, N, b.M);
+            PFP_TRY((device_scan<uint32_t, 1>(c, b.M, b.M, N, nullptr)));
         }
-        static const uint32_t max_range = getenv("PFP_CLASS_SORT_MAXRANGE") ? (uint32_t)atoi(getenv("PFP_CLASS_SORT_MAXRANGE")) : (uint32_t)RS_TILE;   // tests: smaller, to reach the large-class route
-        int cur = 0; uint64_t h = h0;
         // k0 / v0 / k1 / v1 are free from here on: scratch of the large-class route
+        b.k0 = k0; b.k1 = k1; b.v0 = v0; b.v1 = v1;
+        static const bool no_table = getenv("PFP_SORT_NO_TABLE") != nullptr;                   // tests: the K = 3 rounds follow the chains themselves
+        if (force_k != 1 && !no_table && (uint64_t)na * 8 > N && c->arena.hi - c->arena.lo > 16 * (size_t)N + 40 * (size_t)na + ((size_t)1 << 20))
+            PFP_ALLOC_HI(c, b.T, uint4, N);          // optional: without room for it the K = 3 rounds follow the chains themselves
+        static const uint32_t max_range_env = getenv("PFP_CLASS_SORT_MAXRANGE") ? (uint32_t)atoi(getenv("PFP_CLASS_SORT_MAXRANGE")) : 0u;   // tests: smaller, to reach the large-class route
+        int cur = 0; uint64_t h = h0;
         while (na > 0) {
             if (verbose) fprintf(stderr, "[pfbwt_hip] suffix sort N=%llu round %d: %u active\n", (unsigned long long)N, rounds, na);
             if (rounds > 64) return PFP_E_CORRUPT; // cannot happen on well-formed input
-            const bool run_round = (M != nullptr && rounds == 1);
-            const int lowbits = run_round ? 32 : rbits;
-            const unsigned gs = nblocks(na, CS_STEP);
-            PFP_HIP(c, hipMemsetAsync(flags, 0, na, c->stream));
-            PFP_HIP(c, hipMemsetAsync(stripe, 0, ((size_t)gs + 3) * 4, c->stream));
-            PFP_HIP(c, hipMemsetAsync(d_done, 0, 8, c->stream));
-            // algorithmic bytes per active suffix: list entry 8 (+4 jump), SA[slot] 4 in + 4 out, the gathered
-            // rank 4 (rank + jump 8, + 1 terminator byte), new rank 4 (+ new jump 4 + 4 through scratch), flag 1
-            PFP_LAUNCH(c, K_CLASS_SORT, (uint64_t)na * (DICT ? 46 : 25), (k_round<DICT>), gs, (const uint32_t *)aslot[cur], (const uint32_t *)arnk[cur], (const uint32_t *)ajmp[cur], (uint64_t)na, N, SA,
-                       (const uint32_t *)rank, (const uint2 *)rj, (uint32_t)(h < N ? h : N), D, run_round ? (const uint32_t *)M : (const uint32_t *)nullptr, lowbits, max_range, newr, xout, tnj, newj, flags, stripe, d_done);
-            unsigned long long nd = 0;
-            PFP_HIP(c, hipMemcpyAsync(&nd, d_done, 8, hipMemcpyDeviceToHost, c->stream));
-            PFP_HIP(c, hipStreamSynchronize(c->stream));
-            const uint64_t nl = na - nd;
-            if (nl) {   // classes too large for a tile: collect their pairs, sort them globally, put them back
-                if (verbose) fprintf(stderr, "[pfbwt_hip]   class sort: %u pairs, %llu in classes too large for one tile\n", na, (unsigned long long)nl);
-                const unsigned ga = nblocks(na, BLOCK), gl = nblocks(nl, BLOCK);
-                PFP_LAUNCH(c, K_COMPACT, (uint64_t)na * 5, k_not_done, ga, (const uint8_t *)flags, (uint64_t)na, keep);
-                PFP_TRY(device_compact(c, nullptr, keep, na, lidx, pos, d_cnt));
-                PFP_LAUNCH(c, K_SS_MAKE_KEYS, nl * 48, (k_round_keys<DICT>), gl, (const uint32_t *)lidx, nl, (const uint32_t *)aslot[cur], (const uint32_t *)arnk[cur], (const uint32_t *)ajmp[cur], N, (const uint32_t *)SA,
-                           (const uint32_t *)rank, (const uint2 *)rj, (uint32_t)(h < N ? h : N), D, run_round ? (const uint32_t *)M : (const uint32_t *)nullptr, lowbits, k0, v0, tnj);
-                if (DICT) PFP_LAUNCH(c, K_SS_MAKE_KEYS, nl * 20, k_round_park_jumps, gl, (const uint32_t *)lidx, nl, (const uint32_t *)aslot[cur], (const uint32_t *)SA, (const uint32_t *)tnj, rj);
-                BitRange rr = {0, lowbits + rbits};
-                uint64_t *lsk; uint32_t *lsv;
-                PFP_TRY(radix_sort_pairs<uint64_t>(c, k0, v0, k1, v1, nl, &rr, 1, &lsk, &lsv));
-                PFP_LAUNCH(c, K_SS_HEADS, nl * 12, k_round_subset_heads, gl, (const uint64_t *)lsk, nl, head);
-                PFP_TRY((device_scan<uint32_t, 1>(c, head, head, nl, nullptr)));
-                PFP_LAUNCH(c, K_SS_WRITE_RANK, nl * 40, (k_round_finish<DICT>), gl, (const uint64_t *)lsk, (const uint32_t *)lsv, (const uint32_t *)head, (const uint32_t *)lidx, nl, N, (const uint32_t *)aslot[cur],
-                           (const uint32_t *)arnk[cur], SA, (const uint2 *)rj, D, newr, xout, newj, flags, stripe);
+            const bool run_round = (b.M != nullptr && rounds == 1);
+            uint32_t nn = 0;
+            if (run_round || force_k == 1) {
+                const uint32_t mr = max_range_env ? max_range_env : (uint32_t)RoundCfg<1>::TILE;
+                PFP_TRY((suffix_sort_round<DICT, 1>(c, b, cur, na, N, h, D, run_round, rbits, mr < (uint32_t)RoundCfg<1>::TILE ? mr : (uint32_t)RoundCfg<1>::TILE, SA, rank, rj, verbose, &nn)));
+                h *= 2;
+            } else {
+                const uint32_t mr = max_range_env ? max_range_env : (uint32_t)RoundCfg<3>::TILE;
+                PFP_TRY((suffix_sort_round<DICT, 3>(c, b, cur, na, N, h, D, false, rbits, mr < (uint32_t)RoundCfg<3>::TILE ? mr : (uint32_t)RoundCfg<3>::TILE, SA, rank, rj, verbose, &nn)));
+                h *= 4;
             }
-            PFP_TRY((device_scan<uint32_t, 0>(c, stripe, stripe, (uint64_t)gs, d_cnt)));
-            PFP_LAUNCH(c, K_SS_WRITE_RANK, (uint64_t)na * (DICT ? 37 : 25), (k_round_apply<DICT>), gs, (const uint32_t *)aslot[cur], (uint64_t)na, (const uint32_t *)xout, (const uint32_t *)newr, (const uint32_t *)newj,
-                       (const uint8_t *)flags, (const uint32_t *)stripe, rank, rj, aslot[cur ^ 1], arnk[cur ^ 1], ajmp[cur ^ 1], verbose ? d_done : (unsigned long long *)nullptr);
-            if (verbose) {
-                unsigned long long ch = 0;
-                PFP_HIP(c, hipMemcpyAsync(&ch, d_done, 8, hipMemcpyDeviceToHost, c->stream));
-                PFP_HIP(c, hipStreamSynchronize(c->stream));
-                fprintf(stderr, "[pfbwt_hip]   ranks scattered this round: %llu (the counter started at the %llu pairs the round kernel handled)\n", ch - nd, nd);
-            }
-            PFP_TRY(d2h_u32(c, d_cnt, &na));
-            cur ^= 1; ++rounds; h *= 2;
+            na = nn; cur ^= 1; ++rounds;
         }
     }
     if (rounds_out) *rounds_out = rounds;

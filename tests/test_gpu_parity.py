@@ -172,11 +172,13 @@ print("class sort variant ok")
 '''
 
 
-@pytest.mark.parametrize("env", [{"PFP_CLASS_SORT_MAXRANGE": "1930"}, {}, {"PFP_CLASS_SORT_MAXRANGE": "40"}])
+@pytest.mark.parametrize("env", [{"PFP_CLASS_SORT_MAXRANGE": "1160"}, {}, {"PFP_CLASS_SORT_MAXRANGE": "40"},
+                                 {"PFP_SORT_K": "1"}, {"PFP_SORT_K": "1", "PFP_CLASS_SORT_MAXRANGE": "40"}, {"PFP_SORT_NO_TABLE": "1"}])
 def test_doubling_round_sort_routes(env):
-    """the sort of a doubling round: classes sorted inside LDS tiles by the fused round kernel (default), classes too large
-    for a tile collected and radix-sorted (forced by a smaller range limit: some of the pairs, nearly all of them) --
-    every route must give the oracle's arrays"""
+    """the sort of a refinement round: classes sorted inside LDS tiles by the fused round kernel (default: by three further
+    ranks per round, read from the table built in text order; PFP_SORT_NO_TABLE: by following the chains; PFP_SORT_K=1:
+    plain doubling), classes too large for a tile collected and radix-sorted (forced by a smaller range limit: some of
+    the pairs, nearly all of them) -- every route must give the oracle's arrays"""
     import subprocess, sys
     e = dict(os.environ); e.update(env); e["PFP_VERBOSE"] = "1"
     pr = subprocess.run([sys.executable, "-c", CLASS_SORT_CODE, ROOT], env=e, capture_output=True, text=True, timeout=900)
@@ -186,3 +188,6 @@ def test_doubling_round_sort_routes(env):
         assert lines, "no round reported classes too large for a tile"
     else:
         assert not lines, lines[:5]
+    k3 = [l for l in pr.stderr.splitlines() if "K=3" in l]
+    assert bool(k3) == (env.get("PFP_SORT_K") != "1"), pr.stderr[-2000:]
+    assert any("(table)" in l for l in k3) == (not env.get("PFP_SORT_K") and not env.get("PFP_SORT_NO_TABLE")), k3[:5]
