@@ -247,6 +247,19 @@ __global__ __launch_bounds__(BLOCK) void k_seg_small(uint32_t *seg, uint32_t G, 
     total[d] = block_excl_sum((unsigned long long)run, lds, &tot);
 }
 
+// lanes of the wave that hold the same 8-bit digit as this one (two 32-bit halves, AND-ed into plo / phi): per bit a
+// sign-extended copy of it, one ballot, two xnor, two and -- the select-and-mask chain the compiler makes of
+// "peers &= bit ? m : ~m" on 64-bit values is twice as long, and these sorts are VALU-bound
+__device__ __forceinline__ void same_digit_lanes(uint32_t d, uint32_t &plo, uint32_t &phi)
+{
+#pragma unroll
+    for (int bb = 0; bb < 8; ++bb) {
+        const uint32_t neg = (uint32_t)(((int32_t)(d << (31 - bb))) >> 31);
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(neg != 0u);
+        plo &= ~((uint32_t)m ^ neg); phi &= ~((uint32_t)(m >> 32) ^ neg);
+    }
+}
+
 template <typename K, bool STAGE> __global__ __launch_bounds__(BLOCK) void k_seg_scatter(const K *keys, const uint32_t *vals, K *okeys, uint32_t *ovals, uint64_t n, int shift,
                                                                            uint32_t tiles_per_seg, const uint32_t *seg /*[G][256] column prefixes*/, const unsigned long long *dbase)
 {
@@ -257,7 +270,6 @@ template <typename K, bool STAGE> __global__ __launch_bounds__(BLOCK) void k_seg
     __shared__ uint32_t svals[STAGE ? TILE : 1];
     __shared__ uint32_t red[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned long long lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;
     unsigned long long cursor = dbase[threadIdx.x] + seg[(size_t)blockIdx.x * RS_RADIX + threadIdx.x];   // thread d: next output index of digit d
     // software pipeline: the pairs of tile t+1 are requested while tile t is ranked, staged and stored
     K kn[ITEMS]; uint32_t vn[ITEMS];
@@ -283,17 +295,14 @@ template <typename K, bool STAGE> __global__ __launch_bounds__(BLOCK) void k_seg
             // the wave's counter once (no LDS atomics, no serialisation on equal digits)
             const bool valid = i < n;
             const unsigned d = (unsigned)(k[it] >> shift) & (RS_RADIX - 1);
-            unsigned long long peers = __ballot(valid);
-#pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                unsigned long long m = __ballot((d >> b) & 1);
-                peers &= ((d >> b) & 1) ? m : ~m;
-            }
-            const int leader = valid ? (__ffsll((long long)peers) - 1) : lane;
+            const unsigned long long vm = __builtin_amdgcn_ballot_w64(valid);
+            uint32_t plo = (uint32_t)vm, phi = (uint32_t)(vm >> 32);
+            same_digit_lanes(d, plo, phi);
+            const int leader = !valid ? lane : plo ? __builtin_ctz(plo) : 32 + __builtin_ctz(phi);
             uint32_t old = 0;
-            if (valid && lane == leader) { old = wh[wave][d]; wh[wave][d] = old + (uint32_t)__popcll(peers); }
+            if (valid && lane == leader) { old = wh[wave][d]; wh[wave][d] = old + (uint32_t)__builtin_popcount(plo) + (uint32_t)__builtin_popcount(phi); }
             old = __shfl(old, leader);
-            rk[it] = (uint16_t)(old + (uint32_t)__popcll(peers & lt));
+            rk[it] = (uint16_t)(old + __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u)));
         }
         if (tl + 1 < tiles_per_seg) {
             const uint64_t nb = base + TILE;

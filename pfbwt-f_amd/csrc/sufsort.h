@@ -180,7 +180,6 @@ template <bool DICT, int K> __global__ __launch_bounds__(BLOCK) void k_round(con
     if (e - s > (uint64_t)max_range) return;              // a class with more members than a tile holds
     const uint32_t n = (uint32_t)(e - s);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned long long lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;
     const uint32_t nit = (n + BLOCK - 1) / BLOCK;
     const uint32_t base = (uint32_t)wave * (nit * WAVE) + lane;   // wave w owns the contiguous pairs [w * nit * 64, (w + 1) * nit * 64)
     const uint32_t hmin = arnk[s];
@@ -254,13 +253,21 @@ template <bool DICT, int K> __global__ __launch_bounds__(BLOCK) void k_round(con
     }
     __syncthreads();
     // ---- LSD radix sort of the range inside LDS: (K = 3: the two ranks of B,) the low part of A, then the span of the
-    //      (already ordered) class part
-    const uint64_t lomask = lowbits >= 64 ? ~0ULL : ((1ULL << lowbits) - 1);
+    //      (already ordered) class part.  This loop is what bounds the kernel (VALU: ~1.5 ms per pass and 325 M pairs when
+    //      every pair was predicated on "is it one of the n" and the digit's place was worked out per item), hence:
+    //      the range is padded to whole waves with all-ones keys (they stay behind the real ones in a stable sort, so no
+    //      item needs a validity test), the place of a pass's digit is three scalars, and the lanes that hold the same
+    //      digit come from same_digit_lanes (prims.h).  Measured: 26.5 -> 24 ms for a K = 3 round over 325 M pairs.
     const uint64_t hspan = skeys[n - 1] >> lowbits;
+    for (uint32_t j = n + threadIdx.x; j < nit * BLOCK; j += BLOCK) { skeys[j] = ~0ULL; sidx[j] = (uint16_t)j; if (K == 3) skeyb[j] = ~0ULL; }
     const int nb = K == 3 ? (2 * lowbits + 7) / 8 : 0;
     const int nlo = (lowbits + 7) / 8;
     int nhi = 0; while (nhi < 8 && (hspan >> (8 * nhi))) ++nhi;
     for (int p = 0; p < nb + nlo + nhi; ++p) {
+        const bool use_b = p < nb;
+        const int q = p - nb;
+        const int sh = use_b ? 8 * p : q < nlo ? 8 * q : lowbits + 8 * (q - nlo);
+        const uint32_t dmask = (!use_b && q < nlo && lowbits - 8 * q < 8) ? ((1u << (lowbits - 8 * q)) - 1u) : 255u;      // the top digit of the low part stops where the class part starts
         uint64_t k[ITEMS], kb[K == 3 ? ITEMS : 1]; uint16_t v[ITEMS]; unsigned dg[ITEMS];
 #pragma unroll
         for (int w = 0; w < BLOCK / WAVE; ++w) wh[w][threadIdx.x] = 0;
@@ -269,23 +276,16 @@ template <bool DICT, int K> __global__ __launch_bounds__(BLOCK) void k_round(con
         for (int it = 0; it < ITEMS; ++it) {
             if ((uint32_t)it < nit) {                                  // uniform; no break: the loop must unroll (register arrays)
             const uint32_t i = base + (uint32_t)it * WAVE;
-            const bool valid = i < n;
-            k[it] = valid ? skeys[i] : 0ULL; v[it] = valid ? sidx[i] : (uint16_t)0;
-            if (K == 3) kb[it] = valid ? skeyb[i] : 0ULL;
-            unsigned d;
-            if (K == 3 && p < nb) d = (unsigned)(kb[K == 3 ? it : 0] >> (8 * p)) & (RS_RADIX - 1);
-            else { const int q = p - nb; d = q < nlo ? (unsigned)((k[it] & lomask) >> (8 * q)) & (RS_RADIX - 1) : (unsigned)((k[it] >> lowbits) >> (8 * (q - nlo))) & (RS_RADIX - 1); }
-            unsigned long long peers = __ballot(valid);
-#pragma unroll
-            for (int bb = 0; bb < 8; ++bb) {
-                unsigned long long m = __ballot((d >> bb) & 1);
-                peers &= ((d >> bb) & 1) ? m : ~m;
-            }
-            const int leader = valid ? (__ffsll((long long)peers) - 1) : lane;
+            k[it] = skeys[i]; v[it] = sidx[i];
+            if (K == 3) kb[it] = skeyb[i];
+            const uint32_t d = (uint32_t)(((K == 3 && use_b) ? kb[K == 3 ? it : 0] : k[it]) >> sh) & dmask;
+            uint32_t plo = 0xFFFFFFFFu, phi = 0xFFFFFFFFu;            // lanes with the same digit
+            same_digit_lanes(d, plo, phi);
+            const int leader = plo ? __builtin_ctz(plo) : 32 + __builtin_ctz(phi);       // never empty: the lane itself
             uint32_t old = 0;
-            if (valid && lane == leader) { old = wh[wave][d]; wh[wave][d] = old + (uint32_t)__popcll(peers); }
+            if (lane == leader) { old = wh[wave][d]; wh[wave][d] = old + (uint32_t)__builtin_popcount(plo) + (uint32_t)__builtin_popcount(phi); }
             old = __shfl(old, leader);
-            dg[it] = d | ((old + (uint32_t)__popcll(peers & lt)) << 8);        // digit and rank inside the wave
+            dg[it] = d | ((old + __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u))) << 8);        // digit and rank inside the wave
             }
         }
         __syncthreads();
@@ -302,8 +302,7 @@ template <bool DICT, int K> __global__ __launch_bounds__(BLOCK) void k_round(con
         __syncthreads();
 #pragma unroll
         for (int it = 0; it < ITEMS; ++it) {
-            const uint32_t i = base + (uint32_t)it * WAVE;
-            if ((uint32_t)it < nit && i < n) {
+            if ((uint32_t)it < nit) {
                 const uint32_t li = wh[wave][dg[it] & 255u] + (dg[it] >> 8);
                 skeys[li] = k[it]; sidx[li] = v[it];
                 if (K == 3) skeyb[li] = kb[K == 3 ? it : 0];

@@ -146,6 +146,9 @@ static inline unsigned long long __ballot(int pred)
 // the hardware runs a wave's lanes in lock step; a kernel that RELIES on it (the lanes' LDS atomics of one instruction all
 // execute before those of the next) marks the points with this builtin, which is where the emulator lines its fibers up
 static inline void __builtin_amdgcn_wave_barrier() { emu::wave_sync(); }
+static inline unsigned long long __builtin_amdgcn_ballot_w64(bool p) { return __ballot(p ? 1 : 0); }
+static inline unsigned __builtin_amdgcn_mbcnt_lo(unsigned m, unsigned acc) { int l = emu::lane(); return acc + (unsigned)__builtin_popcount(l >= 32 ? m : (l ? (m & (0xFFFFFFFFu >> (32 - l))) : 0u)); }
+static inline unsigned __builtin_amdgcn_mbcnt_hi(unsigned m, unsigned acc) { int l = emu::lane(); return acc + (unsigned)__builtin_popcount(l <= 32 ? 0u : (m & (0xFFFFFFFFu >> (64 - l)))); }
 static inline int __any(int p) { return __ballot(p) != 0; }
 static inline int __all(int p) { emu::State &s = emu::S(); unsigned long long live = 0; int b = emu::wave_base(), e = emu::wave_end(); unsigned long long m = __ballot(p); for (int t = b; t < e; ++t) if (s.st[t] != 2) live |= 1ULL << (t - b); return m == live; }
 template <typename T> static inline T emu_shfl_from(T v, int src)

@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Parse stage only (feed + finalize) of a bench workload, kernel by kernel from the library's own HIP-event profile.
+For experiments on the trigger scan / de-duplication kernels: nothing behind the parse runs, so a build that computes
+wrong occurrence counts on purpose (timing experiments) cannot reach the emission.
+usage: python tools/parse_bench.py [--workload S-32G] [--reps 2]"""
+import argparse, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "pfbwt-f_amd", "python"))
+import torch
+import bench, pfbwt_hip
+
+ap = argparse.ArgumentParser(); ap.add_argument("--workload", default="S-32G"); ap.add_argument("--reps", type=int, default=2)
+a = ap.parse_args()
+L, H, seed, nruns, w, p, u64 = bench.WORKLOADS[a.workload]
+h_all = torch.empty((H, L), dtype=torch.uint8, pin_memory=True)
+bench.synth_seqs(L, H, seed, nruns, out=h_all.numpy())
+d_all = h_all.to("cuda")
+ctx = pfbwt_hip.PfpContext(w=w, p=p, u64=u64, sai=True, device=0)
+for rep in range(a.reps + 1):
+    ctx.profile_enable(True); ctx.profile_reset()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    ctx.feed_device_batch(d_all.data_ptr(), d_all.shape[0], d_all.shape[1], d_all.stride(0))
+    ctx.finalize()
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    rows = sorted(ctx.profile(), key=lambda r: -r["ms"])
+    if rep:
+        print("rep %d: parse %.1f ms; " % (rep, 1e3 * dt) + ", ".join("%s %.1f" % (r["kernel"], r["ms"]) for r in rows[:8]), flush=True)
+    ctx.reset()
