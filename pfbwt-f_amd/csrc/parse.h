@@ -300,18 +300,30 @@ constexpr uint32_t LONG_PHRASE = 2048; // phrases longer than this go to the wor
 // written, so the plain (possibly stale, per-XCD L2) read in front of the compare-and-swap is safe: a stale EMPTY is
 // corrected by the value the CAS returns.  Round 1 sorted (fingerprint, phrase) pairs and compared neighbours instead:
 // 8 radix passes over all phrases and two random phrase reads per phrase.
-constexpr uint64_t HT_EMPTY = ~0ULL;
+constexpr uint64_t HT_EMPTY = ~0ULL, HT_NOINFO = ~0ULL;
 constexpr uint32_t HT_MAX_PROBES = 1u << 16;
 __host__ __device__ __forceinline__ uint64_t mix64(uint64_t z) { z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL; return z ^ (z >> 31); }
-// content hash of s[0..len): a multiply-xorshift chain over the 8-byte little-endian words, the last one masked
-__device__ __forceinline__ uint64_t str_hash(const uint8_t *s, uint32_t len, uint64_t seed)
+// content hash of a string of len bytes whose 8-byte little-endian words come from ld(byte offset): FOUR interleaved
+// multiply-xorshift chains (word q feeds chain q & 3), the last word masked.  One chain is a dependent sequence of
+// 64-bit multiplies as long as the phrase -- and a wave waits for the longest of its 64 phrases.
+template <typename NEXT> __device__ __forceinline__ uint64_t hash_words(uint32_t len, uint64_t seed, NEXT next /* the string's words, in order */)
 {
-    uint64_t h = seed ^ ((uint64_t)len * 0x9E3779B97F4A7C15ULL);
+    const uint64_t M = 0xD6E8FEB86659FD93ULL;
+    uint64_t h0 = seed ^ ((uint64_t)len * 0x9E3779B97F4A7C15ULL), h1 = h0 ^ 0xA0761D6478BD642FULL, h2 = h0 ^ 0xE7037ED1A0B428DBULL, h3 = h0 ^ 0x8EBC6AF09C88C6E3ULL;
     uint32_t i = 0;
-    for (; i + 8 <= len; i += 8) { h = (h ^ ld8(s + i)) * 0xD6E8FEB86659FD93ULL; h ^= h >> 32; }
-    if (i < len) { h = (h ^ (ld8(s + i) & ((1ULL << (8 * (len - i))) - 1ULL))) * 0xD6E8FEB86659FD93ULL; h ^= h >> 32; }
-    return mix64(h);
+    for (; i + 32 <= len; i += 32) {
+        const uint64_t a = next(), b = next(), c = next(), d = next();
+        h0 = (h0 ^ a) * M; h1 = (h1 ^ b) * M; h2 = (h2 ^ c) * M; h3 = (h3 ^ d) * M;
+        h0 ^= h0 >> 32; h1 ^= h1 >> 32; h2 ^= h2 >> 32; h3 ^= h3 >> 32;
+    }
+    // the last 1..31 bytes: up to four more words, the final one masked
+    if (i < len) { uint64_t a = next(); if (len - i < 8) a &= (1ULL << (8 * (len - i))) - 1ULL; h0 = (h0 ^ a) * M; h0 ^= h0 >> 32; }
+    if (i + 8 < len) { uint64_t a = next(); if (len - i - 8 < 8) a &= (1ULL << (8 * (len - i - 8))) - 1ULL; h1 = (h1 ^ a) * M; h1 ^= h1 >> 32; }
+    if (i + 16 < len) { uint64_t a = next(); if (len - i - 16 < 8) a &= (1ULL << (8 * (len - i - 16))) - 1ULL; h2 = (h2 ^ a) * M; h2 ^= h2 >> 32; }
+    if (i + 24 < len) { uint64_t a = next(); a &= (1ULL << (8 * (len - i - 24))) - 1ULL; h3 = (h3 ^ a) * M; h3 ^= h3 >> 32; }
+    return mix64(h0 ^ ((h1 << 17) | (h1 >> 47)) ^ ((h2 << 31) | (h2 >> 33)) ^ ((h3 << 47) | (h3 >> 17)));
 }
+__device__ __forceinline__ uint64_t str_hash(const uint8_t *s, uint32_t len, uint64_t seed) { uint32_t o = 0; return hash_words(len, seed, [s, &o]() { const uint64_t v = ld8(s + o); o += 8; return v; }); }
 __device__ __forceinline__ bool str_equal(const uint8_t *a, const uint8_t *b, uint32_t len)
 {
     uint32_t i = 0;
@@ -319,9 +331,14 @@ __device__ __forceinline__ bool str_equal(const uint8_t *a, const uint8_t *b, ui
     if (i < len) return ((ld8(a + i) ^ ld8(b + i)) & ((1ULL << (8 * (len - i))) - 1ULL)) == 0;
     return true;
 }
+// One entry = one 32-byte piece of a line: what a lookup touches -- the filter | representative word, where the
+// representative's bytes are, the occurrence counter -- arrives with ONE memory transaction (three arrays cost three
+// random sectors per phrase, and this kernel is bound by exactly that traffic: 190 GB per 325 M phrases before).
+// The table is cleared to all-ones: tab == HT_EMPTY, rinfo == HT_NOINFO (its creator has not stored it yet: read the
+// spans), cnt == 2^32 - 1 (occurrences = cnt + 1, wrapping).
+struct DedupEntry { unsigned long long tab, rinfo; uint32_t cnt, pad[3]; };
 struct DedupTable {
-    unsigned long long *tab; uint32_t *cnt; uint64_t mask;        // entries, occurrences per entry, table size - 1
-    unsigned long long *rinfo;                                    // per entry: start << 16 | length of its representative once its creator has stored it (0: read the spans)
+    DedupEntry *ent; uint64_t mask;                               // entries, table size - 1
     uint32_t *slotof;                                             // per phrase: its entry
     uint32_t *dslot; uint64_t *dhash; uint32_t *nd; uint32_t limit;   // the entries in use (appended by whoever created them) and their hashes
     uint32_t *overflow;                                           // != 0: more distinct phrases than `limit` (or a probe sequence too long): retry with a larger table
@@ -332,22 +349,22 @@ __device__ __forceinline__ void dedup_find_or_insert(const uint8_t *Y, const Spa
     const uint64_t filt = h >> 32;
     uint64_t slot = h & t.mask;
     for (uint32_t probe = 0; probe < HT_MAX_PROBES; ++probe, slot = (slot + 1) & t.mask) {
-        unsigned long long cur = t.tab[slot];
+        unsigned long long cur = t.ent[slot].tab;
         if ((probe & 7u) == 7u && *t.overflow) return;          // the table is being abandoned (it may be full: no EMPTY entry would end the walk)
         if (cur == HT_EMPTY) {
             if (*t.overflow) return;
-            cur = atomicCAS(&t.tab[slot], (unsigned long long)HT_EMPTY, (unsigned long long)((filt << 32) | j));
+            cur = atomicCAS(&t.ent[slot].tab, (unsigned long long)HT_EMPTY, (unsigned long long)((filt << 32) | j));
             if (cur == HT_EMPTY) {                               // this phrase is the representative of a new entry
                 const uint32_t k = atomicAdd(t.nd, 1u);
                 if (k >= t.limit) { *t.overflow = 1; return; }
                 t.dslot[k] = (uint32_t)slot; t.dhash[k] = h;
-                t.slotof[j] = (uint32_t)slot; atomicAdd(&t.cnt[slot], 1u);
+                t.slotof[j] = (uint32_t)slot; atomicAdd(&t.ent[slot].cnt, 1u);
                 return;
             }
         }
         if ((cur >> 32) == filt) {
             tpos_t rs; uint32_t rlen; phrase_span(sp, (uint32_t)cur, &rs, &rlen);
-            if (rlen == len && str_equal(Y + ys, Y + rs, len)) { t.slotof[j] = (uint32_t)slot; atomicAdd(&t.cnt[slot], 1u); return; }
+            if (rlen == len && str_equal(Y + ys, Y + rs, len)) { t.slotof[j] = (uint32_t)slot; atomicAdd(&t.ent[slot].cnt, 1u); return; }
         }
     }
     *t.overflow = 2;
@@ -358,14 +375,20 @@ __device__ __forceinline__ void dedup_find_or_insert(const uint8_t *Y, const Spa
 // representative (a dictionary-sized hot set).  A window that does not fit (long phrases, scattered words) falls back to
 // reading the phrase from memory.
 constexpr uint32_t DD_TILE_BYTES = 32768 - 64;
-__device__ __forceinline__ uint64_t lds_ld8(const uint32_t *t32, uint32_t off)
-{   // 8 bytes at an arbitrary byte offset of an LDS array of 32-bit words
-    const uint32_t i = off >> 2, sh = (off & 3u) * 8u;
-    const uint32_t w0 = t32[i], w1 = t32[i + 1];
-    if (!sh) return ((uint64_t)w1 << 32) | w0;
-    const uint32_t w2 = t32[i + 2];
-    return ((uint64_t)((w1 >> sh) | (w2 << (32 - sh))) << 32) | ((w0 >> sh) | (w1 << (32 - sh)));
-}
+// the 8-byte words of a string that starts at an arbitrary byte offset of an LDS array of 32-bit words, one after the
+// other: two new words of LDS per 8 bytes (the third a shifted read needs is the one kept from the step before) -- the
+// threads' offsets are ~110 bytes apart, i.e. these reads hit random banks, and they were what bounded the kernel
+struct LdsWords {
+    const uint32_t *t; uint32_t idx, sh, carry;
+    __device__ __forceinline__ LdsWords(const uint32_t *t32, uint32_t off) : t(t32), idx(off >> 2), sh((off & 3u) * 8u), carry(t32[off >> 2]) {}
+    __device__ __forceinline__ uint64_t next()
+    {
+        const uint32_t w1 = t[idx + 1], w2 = t[idx + 2];
+        const uint32_t lo = (uint32_t)((((uint64_t)w1 << 32) | carry) >> sh), hi = (uint32_t)((((uint64_t)w2 << 32) | w1) >> sh);
+        carry = w2; idx += 2;
+        return ((uint64_t)hi << 32) | lo;
+    }
+};
 __global__ __launch_bounds__(BLOCK) void k_dedup_insert(const uint8_t *Y, Spans sp, uint64_t m, uint64_t seed, DedupTable t, uint32_t *longlist, uint32_t *nlong)
 {
     __shared__ uint32_t tile[DD_TILE_BYTES / 4 + 20];
@@ -400,48 +423,49 @@ __global__ __launch_bounds__(BLOCK) void k_dedup_insert(const uint8_t *Y, Spans 
     if (!live || lng) return;
     if (!tiled) { dedup_find_or_insert(Y, sp, t, (uint32_t)j, ys, len, str_hash(Y + ys, len, seed)); return; }
     const uint32_t off = (uint32_t)(ys - base);
-    uint64_t h = seed ^ ((uint64_t)len * 0x9E3779B97F4A7C15ULL);
-    {
-        uint32_t i = 0;
-        for (; i + 8 <= len; i += 8) { h = (h ^ lds_ld8(tile, off + i)) * 0xD6E8FEB86659FD93ULL; h ^= h >> 32; }
-        if (i < len) { h = (h ^ (lds_ld8(tile, off + i) & ((1ULL << (8 * (len - i))) - 1ULL))) * 0xD6E8FEB86659FD93ULL; h ^= h >> 32; }
-        h = mix64(h);
-    }
+    LdsWords hw(tile, off);
+    const uint64_t h = hash_words(len, seed, [&hw]() { return hw.next(); });
     const uint64_t filt = h >> 32;
     uint64_t slot = h & t.mask;
     for (uint32_t probe = 0; probe < HT_MAX_PROBES; ++probe, slot = (slot + 1) & t.mask) {
-        unsigned long long cur = t.tab[slot];
-        unsigned long long ri = t.rinfo[slot];                    // requested together with the entry: the representative's bytes are one dependent load away, not three
+        unsigned long long cur = t.ent[slot].tab;
+        unsigned long long ri = t.ent[slot].rinfo;                    // requested together with the entry: the representative's bytes are one dependent load away, not three
         if ((probe & 7u) == 7u && *t.overflow) return;          // the table is being abandoned (it may be full: no EMPTY entry would end the walk)
         if (cur == HT_EMPTY) {
             if (*t.overflow) return;
-            cur = atomicCAS(&t.tab[slot], (unsigned long long)HT_EMPTY, (unsigned long long)((filt << 32) | (uint32_t)j));
+            cur = atomicCAS(&t.ent[slot].tab, (unsigned long long)HT_EMPTY, (unsigned long long)((filt << 32) | (uint32_t)j));
             if (cur == HT_EMPTY) {
                 const uint32_t k = atomicAdd(t.nd, 1u);
                 if (k >= t.limit) { *t.overflow = 1; return; }
-                t.rinfo[slot] = ((unsigned long long)ys << 16) | len;
+                t.ent[slot].rinfo = ((unsigned long long)ys << 16) | len;
                 t.dslot[k] = (uint32_t)slot; t.dhash[k] = h;
-                t.slotof[j] = (uint32_t)slot; atomicAdd(&t.cnt[slot], 1u);
+                t.slotof[j] = (uint32_t)slot; atomicAdd(&t.ent[slot].cnt, 1u);
                 return;
             }
-            ri = 0;
+            ri = HT_NOINFO;
         }
         if ((cur >> 32) == filt) {
             tpos_t rs; uint32_t rlen;
-            if (ri) { rs = (tpos_t)(ri >> 16); rlen = (uint32_t)(ri & 0xFFFFu); }
+            if (ri != HT_NOINFO) { rs = (tpos_t)(ri >> 16); rlen = (uint32_t)(ri & 0xFFFFu); }
             else phrase_span(sp, (uint32_t)cur, &rs, &rlen);
             if (rlen == len) {
-                // no early exit: an entry whose filter bits agree is the same phrase all but never, and independent loads overlap
+                // no early exit (an entry whose filter bits agree is the same phrase all but never), and the representative's
+                // bytes are requested 128 at a time: a wave is as slow as the longest of its 64 phrases (~470 bytes at
+                // p = 100), which was 15 dependent round trips when 32 bytes were in flight
                 const uint8_t *r = Y + rs;
                 uint64_t diff = 0;
-                uint32_t i = 0;
-                for (; i + 32 <= len; i += 32) {
-                    const uint64_t a0 = ld8(r + i), a1 = ld8(r + i + 8), a2 = ld8(r + i + 16), a3 = ld8(r + i + 24);
-                    diff |= (a0 ^ lds_ld8(tile, off + i)) | (a1 ^ lds_ld8(tile, off + i + 8)) | (a2 ^ lds_ld8(tile, off + i + 16)) | (a3 ^ lds_ld8(tile, off + i + 24));
+                LdsWords cw(tile, off);
+                for (uint32_t c0 = 0; c0 < len; c0 += 128u) {
+                    uint64_t a[16];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) { const uint32_t i = c0 + 8u * (uint32_t)q; a[q] = i < len ? ld8(r + i) : 0ULL; }
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const uint32_t i = c0 + 8u * (uint32_t)q;
+                        if (i < len) { uint64_t x = a[q] ^ cw.next(); if (len - i < 8) x &= (1ULL << (8 * (len - i))) - 1ULL; diff |= x; }
+                    }
                 }
-                for (; i + 8 <= len; i += 8) diff |= ld8(r + i) ^ lds_ld8(tile, off + i);
-                if (i < len) diff |= (lds_ld8(tile, off + i) ^ ld8(r + i)) & ((1ULL << (8 * (len - i))) - 1ULL);
-                if (!diff) { t.slotof[j] = (uint32_t)slot; atomicAdd(&t.cnt[slot], 1u); return; }
+                if (!diff) { t.slotof[j] = (uint32_t)slot; atomicAdd(&t.ent[slot].cnt, 1u); return; }
             }
         }
     }
@@ -477,15 +501,15 @@ __global__ __launch_bounds__(DL_THREADS) void k_dedup_insert_long(const uint8_t 
     for (uint32_t probe = 0; probe < HT_MAX_PROBES; ++probe) {
         if (threadIdx.x == 0) {
             int st = 0;
-            unsigned long long cur = t.tab[slot];
+            unsigned long long cur = t.ent[slot].tab;
             if (cur == HT_EMPTY) {
                 if (*t.overflow) st = 1;
                 else {
-                    cur = atomicCAS(&t.tab[slot], (unsigned long long)HT_EMPTY, (unsigned long long)((filt << 32) | j));
+                    cur = atomicCAS(&t.ent[slot].tab, (unsigned long long)HT_EMPTY, (unsigned long long)((filt << 32) | j));
                     if (cur == HT_EMPTY) {
                         const uint32_t k = atomicAdd(t.nd, 1u);
                         if (k >= t.limit) *t.overflow = 1;
-                        else { t.dslot[k] = (uint32_t)slot; t.dhash[k] = h; t.slotof[j] = (uint32_t)slot; atomicAdd(&t.cnt[slot], 1u); }
+                        else { t.dslot[k] = (uint32_t)slot; t.dhash[k] = h; t.slotof[j] = (uint32_t)slot; atomicAdd(&t.ent[slot].cnt, 1u); }
                         st = 1;
                     }
                 }
@@ -511,7 +535,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dedup_insert_long(const uint8_t 
             __syncthreads();
             const bool same = s_diff == 0;
             __syncthreads();
-            if (same) { if (threadIdx.x == 0) { t.slotof[j] = (uint32_t)slot; atomicAdd(&t.cnt[slot], 1u); } return; }
+            if (same) { if (threadIdx.x == 0) { t.slotof[j] = (uint32_t)slot; atomicAdd(&t.ent[slot].cnt, 1u); } return; }
             if (threadIdx.x == 0) s_diff = 0;
         }
         slot = (slot + 1) & t.mask;
@@ -526,13 +550,13 @@ __global__ __launch_bounds__(BLOCK) void k_dedup_assign(const uint32_t *order, u
     const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= nd) return;
     const uint32_t slot = t.dslot[order[i]];
-    rep[i] = (uint32_t)t.tab[slot]; occw[i] = t.cnt[slot];
-    t.tab[slot] = (unsigned long long)i;
+    rep[i] = (uint32_t)t.ent[slot].tab; occw[i] = t.ent[slot].cnt + 1u;
+    t.ent[slot].tab = (unsigned long long)i;
 }
-__global__ __launch_bounds__(BLOCK) void k_dedup_ids(const unsigned long long *tab, const uint32_t *slotof, uint64_t m, uint32_t *pid)
+__global__ __launch_bounds__(BLOCK) void k_dedup_ids(const DedupEntry *ent, const uint32_t *slotof, uint64_t m, uint32_t *pid)
 {
     const uint64_t j = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (j < m) pid[j] = (uint32_t)tab[slotof[j]];
+    if (j < m) pid[j] = (uint32_t)ent[slotof[j]].tab;
 }
 __global__ __launch_bounds__(BLOCK) void k_iota_u32(uint32_t *v, uint64_t n)
 {

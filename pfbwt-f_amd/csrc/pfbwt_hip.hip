@@ -329,17 +329,17 @@ static int dedup_strings(pfp_ctx *c, const uint8_t *Y, Spans sp, uint64_t m, uin
         // first guess: a collection is repetitive (distinct strings << strings); if more than half of that table fills up, the
         // second table holds twice the number of strings, which cannot overflow
         uint64_t want = attempt == 0 ? m / 4 : 2 * m;
-        int lg = 20; while ((1ULL << lg) < want) ++lg;        // at least 2^20 entries: a text of up to half a million phrases never retries
+        const uint64_t floor_ = 4 * m < (1ULL << 20) ? 4 * m : (1ULL << 20);     // small inputs: 4 entries per string (cannot overflow); else at least 2^20
+        if (want < floor_) want = floor_;
+        int lg = 10; while ((1ULL << lg) < want) ++lg;
         if (attempt == 0 && force_small) lg = force_small;
         const uint64_t T = 1ULL << lg;
         const uint64_t limit = T >= 2 * m ? m + 1 : T / 2;
         if (limit >= 0xFFFFFFFFULL) return PFP_E_TOO_LARGE;
-        PFP_ALLOC_HI(c, t.tab, unsigned long long, T); PFP_ALLOC_HI(c, t.cnt, uint32_t, T); PFP_ALLOC_HI(c, t.rinfo, unsigned long long, T);
+        PFP_ALLOC_HI(c, t.ent, DedupEntry, T);
         PFP_ALLOC_HI(c, t.dslot, uint32_t, limit); PFP_ALLOC_HI(c, t.dhash, uint64_t, limit);
         t.mask = T - 1; t.slotof = slotof; t.nd = d_u32; t.limit = (uint32_t)limit; t.overflow = d_u32 + 1;
-        PFP_HIP(c, hipMemsetAsync(t.tab, 0xFF, T * 8, c->stream));
-        PFP_HIP(c, hipMemsetAsync(t.cnt, 0, T * 4, c->stream));
-        PFP_HIP(c, hipMemsetAsync(t.rinfo, 0, T * 8, c->stream));
+        PFP_HIP(c, hipMemsetAsync(t.ent, 0xFF, T * sizeof(DedupEntry), c->stream));
         PFP_HIP(c, hipMemsetAsync(d_u32, 0, 32, c->stream));
         PFP_LAUNCH(c, K_PHRASE_HASH, 2 * total_bytes + m * 24, k_dedup_insert, gm, Y, sp, m, c->hash_seed, t, longlist, d_u32 + 2);
         uint32_t h3[3];
@@ -363,8 +363,8 @@ static int dedup_strings(pfp_ctx *c, const uint8_t *Y, Spans sp, uint64_t m, uin
     BitRange full = {0, 64};
     PFP_TRY(radix_sort_pairs<uint64_t>(c, t.dhash, v0, k1, v1, nd, &full, 1, &sk, &sv));
     PFP_LAUNCH(c, K_DEDUP_HEADS, (uint64_t)nd * 40, k_dedup_assign, nblocks(nd, BLOCK), (const uint32_t *)sv, (uint64_t)nd, t, rep, occw);
-    PFP_LAUNCH(c, K_DEDUP_HEADS, m * 16, k_dedup_ids, gm, (const unsigned long long *)t.tab, (const uint32_t *)slotof, m, d_id);
-    // the table (20 bytes per entry) is dead now: give its space back and keep only rep / occw, moved to the top of what it
+    PFP_LAUNCH(c, K_DEDUP_HEADS, m * 16, k_dedup_ids, gm, (const DedupEntry *)t.ent, (const uint32_t *)slotof, m, d_id);
+    // the table (32 bytes per entry) is dead now: give its space back and keep only rep / occw, moved to the top of what it
     // occupied (they were allocated below it, and are smaller than it: the two regions cannot overlap)
     c->arena.release_hi(mk0);
     uint32_t *rep2, *occw2;
