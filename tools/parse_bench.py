@@ -20,7 +20,10 @@ for rep in range(a.reps + 1):
     ctx.profile_enable(True); ctx.profile_reset()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     ctx.feed_device_batch(d_all.data_ptr(), d_all.shape[0], d_all.shape[1], d_all.stride(0))
-    ctx.finalize()
+    try:
+        ctx.finalize()
+    except pfbwt_hip.PfpError as e:      # timing experiments (PFP_EXP) leave the table unusable on purpose
+        print("finalize:", e)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     rows = sorted(ctx.profile(), key=lambda r: -r["ms"])
     if rep:
