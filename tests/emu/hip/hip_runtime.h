@@ -47,12 +47,41 @@ enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDevice
 #define hipHostMallocDefault 0
 
 namespace emu {
+// Fiber switch.  x86-64: six callee-saved registers and the stack pointer (glibc's swapcontext also saves the signal
+// mask with a system call per switch, and AddressSanitizer's interceptor of it clears shadow memory for the whole stack:
+// a third of the CPU suite's time, five times that in the sanitizer build).  Elsewhere: ucontext.
+#if defined(__x86_64__)
+struct Ctx { void *sp; };
+__attribute__((naked, noinline)) static void emu_switch(void ** /*save sp here: rdi*/, void * /*continue on this sp: rsi*/)
+{
+    __asm__ volatile("pushq %rbp\n\tpushq %rbx\n\tpushq %r12\n\tpushq %r13\n\tpushq %r14\n\tpushq %r15\n\t"
+                     "movq %rsp, (%rdi)\n\tmovq %rsi, %rsp\n\t"
+                     "popq %r15\n\tpopq %r14\n\tpopq %r13\n\tpopq %r12\n\tpopq %rbx\n\tpopq %rbp\n\tret");
+}
+inline void ctx_switch(Ctx *from, Ctx *to) { emu_switch(&from->sp, to->sp); }
+inline void ctx_make(Ctx *c, char *stack, size_t size, void (*entry)(), Ctx *)
+{
+    void **sp = (void **)(((uintptr_t)stack + size) & ~(uintptr_t)15);
+    *--sp = nullptr;                    // where entry would return to: it never does
+    *--sp = (void *)entry;              // taken by the ret of the first switch: entry starts with rsp = 8 mod 16, as after a call
+    for (int i = 0; i < 6; ++i) *--sp = nullptr;
+    c->sp = sp;
+}
+#else
+struct Ctx { ucontext_t u; };
+inline void ctx_switch(Ctx *from, Ctx *to) { swapcontext(&from->u, &to->u); }
+inline void ctx_make(Ctx *c, char *stack, size_t size, void (*entry)(), Ctx *back)
+{
+    getcontext(&c->u); c->u.uc_stack.ss_sp = stack; c->u.uc_stack.ss_size = size; c->u.uc_link = &back->u;
+    makecontext(&c->u, entry, 0);
+}
+#endif
 struct State {
     dim3 tid, bid, bdim, gdim;
     int cur = -1;               // running fiber
     int nthreads = 0;
-    ucontext_t sched;
-    std::vector<ucontext_t> ctx;
+    Ctx sched;
+    std::vector<Ctx> ctx;
     std::vector<char *> stacks;
     std::vector<int> st;        // 0 ready, 1 at block barrier, 2 done, 3 at wave rendezvous
     std::vector<uint64_t> lane_val;
@@ -61,8 +90,8 @@ struct State {
 };
 inline State &S() { static State s; return s; }
 
-inline void yield_to_sched() { State &s = S(); int me = s.cur; swapcontext(&s.ctx[me], &s.sched); }
-inline void fiber_main() { State &s = S(); s.body(); s.st[s.cur] = 2; swapcontext(&s.ctx[s.cur], &s.sched); }
+inline void yield_to_sched() { State &s = S(); int me = s.cur; ctx_switch(&s.ctx[me], &s.sched); }
+inline void fiber_main() { State &s = S(); s.body(); s.st[s.cur] = 2; ctx_switch(&s.ctx[s.cur], &s.sched); abort(); /* a finished fiber is never resumed */ }
 
 inline void set_tid(int t) { State &s = S(); s.cur = t; s.tid.x = t % s.bdim.x; s.tid.y = (t / s.bdim.x) % s.bdim.y; s.tid.z = t / (s.bdim.x * s.bdim.y); }
 
@@ -74,15 +103,13 @@ inline void run_block()
     if ((int)s.ctx.size() < T) { s.ctx.resize(T); s.st.resize(T); s.lane_val.resize(T); s.lane_pred.resize(T); }
     while ((int)s.stacks.size() < T) s.stacks.push_back((char *)malloc(STK));
     for (int t = 0; t < T; ++t) {
-        getcontext(&s.ctx[t]);
-        s.ctx[t].uc_stack.ss_sp = s.stacks[t]; s.ctx[t].uc_stack.ss_size = STK; s.ctx[t].uc_link = &s.sched;
-        makecontext(&s.ctx[t], (void (*)())fiber_main, 0);
+        ctx_make(&s.ctx[t], s.stacks[t], STK, (void (*)())fiber_main, &s.sched);
         s.st[t] = 0;
     }
     for (;;) {
         bool progress = false; int done = 0;
         for (int t = 0; t < T; ++t) {
-            if (s.st[t] == 0) { set_tid(t); swapcontext(&s.sched, &s.ctx[t]); progress = true; }
+            if (s.st[t] == 0) { set_tid(t); ctx_switch(&s.sched, &s.ctx[t]); progress = true; }
         }
         // block barrier release
         int at_bar = 0; done = 0;
