@@ -217,3 +217,54 @@ def check_ragged(factory):
                 continue
             bad = compare(engine_run(factory, seqs, w, p, 4), ref, 4)
             assert bad == [], (name, w, p, bad)
+
+
+def random_cases(seed, count):
+    """Seeded random collections for differential testing: panels of mutated copies (the repetitive case), unrelated
+    records, runs of N and of one base, IUPAC / lower-case letters (with non_acgt_to_a), every w from 1 to 12 and 32,
+    small and large p, both uint_t widths, every output combination."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for c in range(count):
+        w = int(rng.choice([1, 2, 3, 4, 5, 6, 8, 10, 12, 32])); p = int(rng.choice([2, 3, 5, 7, 11, 20, 50, 100]))
+        kind = int(rng.integers(0, 4))
+        base = rng.choice(list(b"ACGT"), int(rng.integers(200, 4000))).astype(np.uint8)
+        seqs = []
+        if kind == 0:      # a panel: copies of one sequence with point changes, a few insertions / deletions
+            for h in range(int(rng.integers(2, 12))):
+                b = base.copy()
+                for _ in range(int(rng.integers(0, 12))): b[int(rng.integers(0, b.size))] = rng.choice(list(b"ACGT"))
+                if rng.random() < 0.5: k = int(rng.integers(0, b.size)); b = np.concatenate([b[:k], rng.choice(list(b"ACGT"), int(rng.integers(1, 30))).astype(np.uint8), b[k:]])
+                if rng.random() < 0.5: k = int(rng.integers(0, b.size - 40)); b = np.concatenate([b[:k], b[k + int(rng.integers(1, 40)):]])
+                seqs.append(bytes(b))
+        elif kind == 1:    # unrelated records of very different lengths
+            seqs = [bytes(rng.choice(list(b"ACGT"), int(n)).astype(np.uint8)) for n in rng.integers(0, 1500, int(rng.integers(1, 9)))]
+            if sum(len(x) for x in seqs) < 50: seqs.append(bytes(base))
+        elif kind == 2:    # runs: N stretches, homopolymers, a short tandem repeat
+            b = base.copy(); k = int(rng.integers(0, b.size // 2)); b[k:k + int(rng.integers(20, 600))] = ord("N")
+            seqs = [bytes(b), b"A" * int(rng.integers(20, 300)) + bytes(base[:100]) + b"T" * int(rng.integers(20, 300)), b"ACG" * int(rng.integers(10, 200))]
+        else:              # letters outside ACGTN, lower case (valid with non_acgt_to_a)
+            b = base.copy()
+            for _ in range(20): b[int(rng.integers(0, b.size))] = rng.choice(list(b"RYKMacgtn"))
+            seqs = [bytes(b), bytes(base[::2])]
+        out.append(dict(seqs=seqs, w=w, p=p, U=int(rng.choice([4, 8])), non_acgt_to_a=(kind == 3), sa=bool(rng.integers(0, 2)), rssa=bool(rng.integers(0, 2))))
+    return out
+
+
+def check_random(factory, seed, count):
+    """engine == oracle on every array of every random case (or both refuse a one-word parse)"""
+    import pfbwt_hip
+    for ci, c in enumerate(random_cases(seed, count)):
+        ref = oracle_run(c["seqs"], w=c["w"], p=c["p"], U=c["U"], non_acgt_to_a=c["non_acgt_to_a"])
+        tag = (seed, ci, c["w"], c["p"], c["U"], c["sa"], c["rssa"], [len(x) for x in c["seqs"]][:6])
+        if ref.get("err") == "one_word":
+            try:
+                engine_run(factory, c["seqs"], c["w"], c["p"], c["U"], non_acgt_to_a=c["non_acgt_to_a"])
+                raise AssertionError("engine accepted a one-word parse: %r" % (tag,))
+            except pfbwt_hip.PfpError as e:
+                assert e.status == pfbwt_hip.E_ONE_WORD, (tag, e)
+            continue
+        res = engine_run(factory, c["seqs"], c["w"], c["p"], c["U"], non_acgt_to_a=c["non_acgt_to_a"], sa=c["sa"], rssa=c["rssa"])
+        names = ["dict", "occ", "parse", "last", "sai", "bwlast", "ilist", "bwsai", "bwt"] + (["sa"] if c["sa"] else []) + (["ssa", "esa"] if c["rssa"] else [])
+        bad = compare(res, ref, c["U"], names=tuple(names))
+        assert bad == [] and res["r"] == ref["r"], (tag, bad)

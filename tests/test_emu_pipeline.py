@@ -92,6 +92,14 @@ def test_emu_error_paths(emu_factory):
     ctx.close()
 
 
+@pytest.mark.parametrize("seed", [101, 202, 303])
+def test_emu_random_differential(emu_factory, seed):
+    """seeded random collections (panels with indels, unrelated records, N runs / homopolymers / tandem repeats, IUPAC and
+    lower case), random w, p, uint_t width and output combination: every array equals the oracle's"""
+    from pfp_testlib import check_random
+    check_random(emu_factory, seed, 25)
+
+
 def test_emu_ragged_inputs(emu_factory):
     from pfp_testlib import check_ragged
     check_ragged(emu_factory)

@@ -157,6 +157,14 @@ def test_engine_ragged_inputs(gpu_ctx_factory):
     check_ragged(gpu_ctx_factory)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [101, 202, 303, 404, 505, 606])
+def test_random_differential_gpu(gpu_ctx_factory, seed):
+    """the seeded random sweep of tests/pfp_testlib.random_cases on the card (seeds 101..303 also run on the emulator)"""
+    from pfp_testlib import check_random
+    check_random(gpu_ctx_factory, seed, 25)
+
+
 CLASS_SORT_CODE = r'''
 import sys
 sys.path.insert(0, sys.argv[1] + "/tests")
