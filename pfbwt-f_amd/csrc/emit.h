@@ -610,6 +610,7 @@ template <typename EBT> __global__ __launch_bounds__(BLOCK) void k_slice_bounds(
 // s_pc too and are overwritten by k_emit afterwards (same stream).  bwt points at row a.w0 and (bwt - a.w0) is 16-byte
 // aligned (host).
 constexpr int FILL_PER_THREAD = 16, FILL_SUB = BLOCK * FILL_PER_THREAD;      // 4096 rows = 2 emission tiles
+constexpr uint32_t FILL_MAX_SUBS = 16;                                        // sub-tiles per workgroup, at most
 static_assert(FILL_SUB % EMIT_TILE == 0, "fill tiles are whole emission tiles");
 template <typename EBT> __global__ __launch_bounds__(BLOCK) void k_fill(EmitArgs a, uint8_t *bwt, uint32_t subs_per_wg)
 {
@@ -622,19 +623,30 @@ template <typename EBT> __global__ __launch_bounds__(BLOCK) void k_fill(EmitArgs
     const uint64_t st0 = a.w0 / FILL_SUB + (uint64_t)blockIdx.x * subs_per_wg;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;
+    constexpr uint64_t TPS = FILL_SUB / EMIT_TILE;
+    // A sub-tile is a chain of dependent accesses (first slot under it -> the slots' row counts -> their first rows and bytes ->
+    // the stores) with 4 KB of output at its end, and that latency, not HBM, bounded the kernel (1.7 TB/s): the slot bounds of
+    // all the workgroup's sub-tiles are fetched up front, and a slot's first row and byte are requested together with its count.
+    __shared__ uint32_t sts[FILL_MAX_SUBS + 1];
+    if (threadIdx.x <= subs_per_wg) {
+        const uint64_t t = (st0 + threadIdx.x) * TPS;
+        sts[threadIdx.x] = a.tile_slot[t < ntiles ? t : ntiles];
+    }
+    __syncthreads();
     for (uint32_t ss = 0; ss < subs_per_wg; ++ss) {
         const uint64_t st = st0 + ss, tstart = st * FILL_SUB;
         const uint64_t o0 = tstart > a.w0 ? tstart : a.w0;
         const uint64_t o1 = tstart + FILL_SUB < a.w1 ? tstart + FILL_SUB : a.w1;
         if (o0 >= o1) break;                                  // uniform
-        constexpr uint64_t TPS = FILL_SUB / EMIT_TILE;
-        const uint64_t t1 = (st + 1) * TPS < ntiles ? (st + 1) * TPS : ntiles;
-        const uint32_t i0 = a.tile_slot[st * TPS], i1 = a.tile_slot[t1];
+        const uint32_t i0 = sts[ss], i1 = sts[ss + 1];
         const uint32_t ns = i1 - i0 + 1u;
         uint32_t nz = 0;                                      // slots with rows so far (the same in every thread)
         for (uint32_t k0 = 0; k0 < ns; k0 += BLOCK) {
             const uint32_t k = k0 + threadIdx.x;
-            const bool has = k < ns && cnt[i0 + k] != 0;
+            const EBT cn = k < ns ? cnt[i0 + k] : (EBT)0;
+            const uint64_t e = k < ns ? (uint64_t)EB[i0 + k] : 0ULL;
+            const uint8_t pc = k < ns ? a.s_pc[i0 + k] : (uint8_t)0;
+            const bool has = cn != 0;
             const unsigned long long bal = __ballot(has);
             __syncthreads();                                  // wcnt (and, first round, eb / pcs of the previous tile) are free
             if (lane == 0) wcnt[wave] = (uint32_t)__popcll(bal);
@@ -643,9 +655,8 @@ template <typename EBT> __global__ __launch_bounds__(BLOCK) void k_fill(EmitArgs
 #pragma unroll
             for (int v = 0; v < BLOCK / WAVE; ++v) { const uint32_t cw = wcnt[v]; if (v < wave) base += cw; tot += cw; }
             if (has) {
-                const uint64_t e = (uint64_t)EB[i0 + k];
                 const uint32_t pos = base + (uint32_t)__popcll(bal & lt);
-                eb[pos] = e > tstart ? (uint32_t)(e - tstart) : 0u; pcs[pos] = a.s_pc[i0 + k];
+                eb[pos] = e > tstart ? (uint32_t)(e - tstart) : 0u; pcs[pos] = pc;
             }
             nz += tot;
         }
@@ -658,13 +669,18 @@ template <typename EBT> __global__ __launch_bounds__(BLOCK) void k_fill(EmitArgs
         uint32_t rel = (uint32_t)(lo - tstart);
         uint32_t s = upper_bound_t<uint32_t>(eb, nz, rel) - 1u;      // last slot with rows that starts at or before rel (eb[0] == 0: the slot of the tile's first row)
         uint32_t nxt = eb[s + 1], c = pcs[s];
+        if (lo == ra && hi == ra + FILL_PER_THREAD && nxt >= rel + FILL_PER_THREAD) {
+            // the thread's 16 rows lie inside one slot's rows (runs are ~180 rows long on a pangenome): one byte, replicated
+            wd[0] = wd[1] = wd[2] = wd[3] = c * 0x01010101u;
+        } else {
 #pragma unroll
-        for (int j = 0; j < FILL_PER_THREAD; ++j) {
-            const uint64_t o = ra + j;
-            if (o >= lo && o < hi) {
-                while (rel >= nxt) { ++s; nxt = eb[s + 1]; c = pcs[s]; }      // every step moves at least one row on
-                wd[j >> 2] |= c << (8 * (j & 3));
-                ++rel;
+            for (int j = 0; j < FILL_PER_THREAD; ++j) {
+                const uint64_t o = ra + j;
+                if (o >= lo && o < hi) {
+                    while (rel >= nxt) { ++s; nxt = eb[s + 1]; c = pcs[s]; }      // every step moves at least one row on
+                    wd[j >> 2] |= c << (8 * (j & 3));
+                    ++rel;
+                }
             }
         }
         uint8_t *dst = bwt + (ra - a.w0);                     // may point in front of the buffer when ra < w0: only rows in [lo, hi) are stored

@@ -1099,7 +1099,8 @@ template <typename SAT, typename EBT> static int emit_and_sample(pfp_ctx *c, Emi
     }
     ea.big_keys = bk0; ea.big_vals = bv0; ea.big_count = d_b + 4; ea.big_cap = ea.big_total;
     const BitRange big_ranges[2] = {{0, bits_for(c->nrows)}, {32, 32 + bits_for(ea.dsize)}};
-    static const uint32_t fill_subs = getenv("PFP_FILL_SUBS") ? (uint32_t)atoi(getenv("PFP_FILL_SUBS")) : 4u;
+    static const uint32_t fill_subs_env = getenv("PFP_FILL_SUBS") ? (uint32_t)atoi(getenv("PFP_FILL_SUBS")) : 4u;
+    const uint32_t fill_subs = fill_subs_env < 1u ? 1u : fill_subs_env > FILL_MAX_SUBS ? FILL_MAX_SUBS : fill_subs_env;
     // emits the rows whose output position lies in [cs - cl, ce); bwt_at / sa_at point at that first position; q_at receives
     // the parse row of every row written (all rows) resp. of every special row enumerated (run-aware)
     auto emit_window = [&](const Win &wn, uint8_t *bwt_at, SAT *sa_at, uint32_t *q_at, bool fill) -> int {
