@@ -610,35 +610,36 @@ template <typename EBT> __global__ __launch_bounds__(BLOCK) void k_slice_bounds(
 // s_pc too and are overwritten by k_emit afterwards (same stream).  bwt points at row a.w0 and (bwt - a.w0) is 16-byte
 // aligned (host).
 constexpr int FILL_PER_THREAD = 16, FILL_SUB = BLOCK * FILL_PER_THREAD;      // 4096 rows = 2 emission tiles
-constexpr uint32_t FILL_MAX_SUBS = 16;                                        // sub-tiles per workgroup, at most
+constexpr int FILL_GROUPS = 4;                                                // groups of FILL_SUB rows that share one slot list (a super-tile)
+constexpr uint32_t FILL_MAX_SUBS = 8;                                         // super-tiles per workgroup, at most
 static_assert(FILL_SUB % EMIT_TILE == 0, "fill tiles are whole emission tiles");
 template <typename EBT> __global__ __launch_bounds__(BLOCK) void k_fill(EmitArgs a, uint8_t *bwt, uint32_t subs_per_wg)
 {
-    __shared__ uint32_t eb[FILL_SUB + 2];       // first row (relative to the tile start, clamped to 0) of the k-th slot with rows
+    // A workgroup walks `subs_per_wg` super-tiles of FILL_GROUPS x FILL_SUB rows.  One super-tile is one chain of dependent
+    // accesses (first slot under it -> the slots' row counts, first rows and bytes -> compaction in LDS -> stores), and that
+    // latency, not HBM, bounded the kernel when a chain ended in 4 KB of output (1.7 TB/s): the list of slots with rows is
+    // built once for the whole super-tile (a pangenome has ~25 such slots under 4096 rows) and every thread then writes one
+    // 16-row piece in each of the FILL_GROUPS groups (each store instruction of a wave is 1 KB contiguous).  A super-tile
+    // with more than FILL_SUB slots with rows (non-repetitive text: about one slot per row) is done group by group.
+    __shared__ uint32_t eb[FILL_SUB + 2];       // first row (relative to the base row, clamped to 0) of the k-th slot with rows
     __shared__ uint8_t pcs[FILL_SUB + 2];
     __shared__ uint32_t wcnt[BLOCK / WAVE];
+    __shared__ uint32_t sts[FILL_MAX_SUBS * FILL_GROUPS + 1];
     const EBT *EB = reinterpret_cast<const EBT *>(a.EB);
     const EBT *cnt = reinterpret_cast<const EBT *>(a.cnt);
     const uint64_t ntiles = (a.nout + EMIT_TILE - 1) / EMIT_TILE;
-    const uint64_t st0 = a.w0 / FILL_SUB + (uint64_t)blockIdx.x * subs_per_wg;
+    constexpr uint64_t TPS = FILL_SUB / EMIT_TILE;
+    constexpr uint64_t SUPER = (uint64_t)FILL_GROUPS * FILL_SUB;
+    const uint64_t st0 = a.w0 / SUPER + (uint64_t)blockIdx.x * subs_per_wg;       // first super-tile of the workgroup
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;
-    constexpr uint64_t TPS = FILL_SUB / EMIT_TILE;
-    // A sub-tile is a chain of dependent accesses (first slot under it -> the slots' row counts -> their first rows and bytes ->
-    // the stores) with 4 KB of output at its end, and that latency, not HBM, bounded the kernel (1.7 TB/s): the slot bounds of
-    // all the workgroup's sub-tiles are fetched up front, and a slot's first row and byte are requested together with its count.
-    __shared__ uint32_t sts[FILL_MAX_SUBS + 1];
-    if (threadIdx.x <= subs_per_wg) {
-        const uint64_t t = (st0 + threadIdx.x) * TPS;
-        sts[threadIdx.x] = a.tile_slot[t < ntiles ? t : ntiles];
+    for (uint32_t k = threadIdx.x; k <= subs_per_wg * FILL_GROUPS; k += BLOCK) {   // slot under the first row of every group
+        const uint64_t t = (st0 * FILL_GROUPS + k) * TPS;
+        sts[k] = a.tile_slot[t < ntiles ? t : ntiles];
     }
     __syncthreads();
-    for (uint32_t ss = 0; ss < subs_per_wg; ++ss) {
-        const uint64_t st = st0 + ss, tstart = st * FILL_SUB;
-        const uint64_t o0 = tstart > a.w0 ? tstart : a.w0;
-        const uint64_t o1 = tstart + FILL_SUB < a.w1 ? tstart + FILL_SUB : a.w1;
-        if (o0 >= o1) break;                                  // uniform
-        const uint32_t i0 = sts[ss], i1 = sts[ss + 1];
+    // slots with rows among [i0, i1] -> eb / pcs (rows relative to `base`); returns how many, or ~0u when the list would not fit
+    auto compact = [&](uint32_t i0, uint32_t i1, uint64_t base) -> uint32_t {
         const uint32_t ns = i1 - i0 + 1u;
         uint32_t nz = 0;                                      // slots with rows so far (the same in every thread)
         for (uint32_t k0 = 0; k0 < ns; k0 += BLOCK) {
@@ -648,30 +649,33 @@ template <typename EBT> __global__ __launch_bounds__(BLOCK) void k_fill(EmitArgs
             const uint8_t pc = k < ns ? a.s_pc[i0 + k] : (uint8_t)0;
             const bool has = cn != 0;
             const unsigned long long bal = __ballot(has);
-            __syncthreads();                                  // wcnt (and, first round, eb / pcs of the previous tile) are free
+            __syncthreads();                                  // wcnt (and, first round, eb / pcs of the previous list) are free
             if (lane == 0) wcnt[wave] = (uint32_t)__popcll(bal);
             __syncthreads();
-            uint32_t base = nz, tot = 0;
+            uint32_t pos = nz, tot = 0;
 #pragma unroll
-            for (int v = 0; v < BLOCK / WAVE; ++v) { const uint32_t cw = wcnt[v]; if (v < wave) base += cw; tot += cw; }
-            if (has) {
-                const uint32_t pos = base + (uint32_t)__popcll(bal & lt);
-                eb[pos] = e > tstart ? (uint32_t)(e - tstart) : 0u; pcs[pos] = pc;
-            }
+            for (int v = 0; v < BLOCK / WAVE; ++v) { const uint32_t cw = wcnt[v]; if (v < wave) pos += cw; tot += cw; }
+            if (nz + tot > (uint32_t)FILL_SUB + 1u) return ~0u;        // uniform; FILL_SUB rows have at most FILL_SUB + 1 slots with rows around them
+            if (has) { pos += (uint32_t)__popcll(bal & lt); eb[pos] = e > base ? (uint32_t)(e - base) : 0u; pcs[pos] = pc; }
             nz += tot;
         }
         if (threadIdx.x == 0) eb[nz] = 0xFFFFFFFFu;
         __syncthreads();
-        const uint64_t ra = tstart + (uint64_t)threadIdx.x * FILL_PER_THREAD;
+        return nz;
+    };
+    // the thread's 16 rows of the group that starts at row g0 (list in LDS: nz slots, rows relative to `base`)
+    auto write_group = [&](uint64_t g0, uint64_t base, uint32_t nz) {
+        const uint64_t o0 = g0 > a.w0 ? g0 : a.w0;
+        const uint64_t o1 = g0 + FILL_SUB < a.w1 ? g0 + FILL_SUB : a.w1;
+        const uint64_t ra = g0 + (uint64_t)threadIdx.x * FILL_PER_THREAD;
         const uint64_t lo = ra > o0 ? ra : o0, hi = ra + FILL_PER_THREAD < o1 ? ra + FILL_PER_THREAD : o1;
-        if (lo >= hi) continue;
+        if (lo >= hi) return;
         uint32_t wd[FILL_PER_THREAD / 4] = {0, 0, 0, 0};
-        uint32_t rel = (uint32_t)(lo - tstart);
-        uint32_t s = upper_bound_t<uint32_t>(eb, nz, rel) - 1u;      // last slot with rows that starts at or before rel (eb[0] == 0: the slot of the tile's first row)
+        uint32_t rel = (uint32_t)(lo - base);
+        uint32_t s = upper_bound_t<uint32_t>(eb, nz, rel) - 1u;      // last slot with rows that starts at or before rel (eb[0] == 0: the slot of the first row)
         uint32_t nxt = eb[s + 1], c = pcs[s];
         if (lo == ra && hi == ra + FILL_PER_THREAD && nxt >= rel + FILL_PER_THREAD) {
-            // the thread's 16 rows lie inside one slot's rows (runs are ~180 rows long on a pangenome): one byte, replicated
-            wd[0] = wd[1] = wd[2] = wd[3] = c * 0x01010101u;
+            wd[0] = wd[1] = wd[2] = wd[3] = c * 0x01010101u;  // the 16 rows lie inside one slot's rows (runs are ~180 rows long on a pangenome)
         } else {
 #pragma unroll
             for (int j = 0; j < FILL_PER_THREAD; ++j) {
@@ -686,6 +690,23 @@ template <typename EBT> __global__ __launch_bounds__(BLOCK) void k_fill(EmitArgs
         uint8_t *dst = bwt + (ra - a.w0);                     // may point in front of the buffer when ra < w0: only rows in [lo, hi) are stored
         if (lo == ra && hi == ra + FILL_PER_THREAD) *reinterpret_cast<uint4 *>(dst) = make_uint4(wd[0], wd[1], wd[2], wd[3]);
         else for (uint64_t o = lo; o < hi; ++o) { const int j = (int)(o - ra); dst[j] = (uint8_t)(wd[j >> 2] >> (8 * (j & 3))); }
+    };
+    for (uint32_t ss = 0; ss < subs_per_wg; ++ss) {
+        const uint64_t tstart = (st0 + ss) * SUPER;
+        if (tstart >= a.w1) break;                            // uniform
+        const uint64_t tend = tstart + SUPER < a.w1 ? tstart + SUPER : a.w1;
+        const uint32_t ng = (uint32_t)((tend - tstart + FILL_SUB - 1) / FILL_SUB);      // groups with rows of the window
+        const uint32_t *gs = sts + ss * FILL_GROUPS;
+        uint32_t nz = compact(gs[0], gs[ng], tstart);
+        if (nz != ~0u) {
+            for (uint32_t g = 0; g < ng; ++g) write_group(tstart + (uint64_t)g * FILL_SUB, tstart, nz);
+        } else {
+            for (uint32_t g = 0; g < ng; ++g) {
+                const uint64_t g0 = tstart + (uint64_t)g * FILL_SUB;
+                nz = compact(gs[g], gs[g + 1], g0);           // at most FILL_SUB slots have rows among FILL_SUB rows
+                write_group(g0, g0, nz);
+            }
+        }
     }
 }
 

@@ -505,7 +505,7 @@ static int parse_finalize_impl(pfp_ctx *c, pfp_parse_sizes *out)
     if (m > 0xFFFFFFFEULL - 64) return PFP_E_TOO_LARGE;       // pfparser.hpp:399-404: more than 2^32-2 phrases is a hard limit of the reference too
     c->m = m;
     PFP_ALLOC_LO(c, c->d_ye, tpos_t, m);
-    PFP_LAUNCH(c, K_PHRASE_ENDS, n / 8 + m * 4, k_phrase_ends, gts, (const uint16_t *)mask16, (const uint64_t *)blockcnt, c->d_ye);
+    PFP_LAUNCH(c, K_PHRASE_ENDS, n / 8 + m * 4, k_phrase_ends, nblocks(gts, PE_BLOCKS), (const uint16_t *)mask16, (const uint64_t *)blockcnt, (uint64_t)gts, c->d_ye);
     PFP_LAUNCH(c, K_MISC, 8, k_set_u64, 1, c->d_ye, m - 1, (uint64_t)(n + (uint64_t)w));
 
     // 2. distinct phrases, dictionary
@@ -1099,7 +1099,7 @@ template <typename SAT, typename EBT> static int emit_and_sample(pfp_ctx *c, Emi
     }
     ea.big_keys = bk0; ea.big_vals = bv0; ea.big_count = d_b + 4; ea.big_cap = ea.big_total;
     const BitRange big_ranges[2] = {{0, bits_for(c->nrows)}, {32, 32 + bits_for(ea.dsize)}};
-    static const uint32_t fill_subs_env = getenv("PFP_FILL_SUBS") ? (uint32_t)atoi(getenv("PFP_FILL_SUBS")) : 4u;
+    static const uint32_t fill_subs_env = getenv("PFP_FILL_SUBS") ? (uint32_t)atoi(getenv("PFP_FILL_SUBS")) : 2u;     // super-tiles (4 x 4096 rows) per workgroup
     const uint32_t fill_subs = fill_subs_env < 1u ? 1u : fill_subs_env > FILL_MAX_SUBS ? FILL_MAX_SUBS : fill_subs_env;
     // emits the rows whose output position lies in [cs - cl, ce); bwt_at / sa_at point at that first position; q_at receives
     // the parse row of every row written (all rows) resp. of every special row enumerated (run-aware)
@@ -1110,7 +1110,8 @@ template <typename SAT, typename EBT> static int emit_and_sample(pfp_ctx *c, Emi
         if (runaware) {
             ea.e0 = wn.q0; ea.e1 = wn.q1; ea.q0 = wn.q0;
             if (fill) {
-                const uint64_t nsub = (ea.w1 - 1) / FILL_SUB - ea.w0 / FILL_SUB + 1;
+                const uint64_t super = (uint64_t)FILL_GROUPS * FILL_SUB;
+                const uint64_t nsub = (ea.w1 - 1) / super - ea.w0 / super + 1;
                 PFP_LAUNCH(c, K_FILL, rows, (k_fill<EBT>), nblocks(nsub, fill_subs), ea, bwt_at, fill_subs);
             }
             if (ea.e1 > ea.e0)
