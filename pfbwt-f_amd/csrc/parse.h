@@ -353,7 +353,12 @@ __device__ __forceinline__ bool str_equal(const uint8_t *a, const uint8_t *b, ui
 // random sectors per phrase, and this kernel is bound by exactly that traffic: 190 GB per 325 M phrases before).
 // The table is cleared to all-ones: tab == HT_EMPTY, rinfo == HT_NOINFO (its creator has not stored it yet: read the
 // spans), cnt == 2^32 - 1 (occurrences = cnt + 1, wrapping).
-struct DedupEntry { unsigned long long tab, rinfo; uint32_t cnt, pad[3]; };
+struct DedupEntry { unsigned long long tab, rinfo; uint32_t cnt, kidx, pad[2]; };
+// slotof[j] (the entry of string j) holds the entry's DENSE index kidx (the order in which the entries were created:
+// k_dedup_ids then gathers from an array of nd ids that stays in L2, not from the table), or, when the creator's store of
+// it was not visible yet, HT_BYSLOT | slot.
+constexpr uint32_t HT_NOIDX = ~0u, HT_BYSLOT = 0x80000000u;
+__device__ __forceinline__ uint32_t entry_ref(const DedupEntry *ent, uint64_t slot) { const uint32_t k = ent[slot].kidx; return k != HT_NOIDX ? k : (HT_BYSLOT | (uint32_t)slot); }
 struct DedupTable {
     DedupEntry *ent; uint64_t mask;                               // entries, table size - 1
     uint32_t *slotof;                                             // per phrase: its entry
@@ -374,14 +379,14 @@ __device__ __forceinline__ void dedup_find_or_insert(const uint8_t *Y, const Spa
             if (cur == HT_EMPTY) {                               // this phrase is the representative of a new entry
                 const uint32_t k = atomicAdd(t.nd, 1u);
                 if (k >= t.limit) { *t.overflow = 1; return; }
-                t.dslot[k] = (uint32_t)slot; t.dhash[k] = h;
-                t.slotof[j] = (uint32_t)slot; atomicAdd(&t.ent[slot].cnt, 1u);
+                t.dslot[k] = (uint32_t)slot; t.dhash[k] = h; t.ent[slot].kidx = k;
+                t.slotof[j] = k; atomicAdd(&t.ent[slot].cnt, 1u);
                 return;
             }
         }
         if ((cur >> 32) == filt) {
             tpos_t rs; uint32_t rlen; phrase_span(sp, (uint32_t)cur, &rs, &rlen);
-            if (rlen == len && str_equal(Y + ys, Y + rs, len)) { t.slotof[j] = (uint32_t)slot; atomicAdd(&t.ent[slot].cnt, 1u); return; }
+            if (rlen == len && str_equal(Y + ys, Y + rs, len)) { t.slotof[j] = entry_ref(t.ent, slot); atomicAdd(&t.ent[slot].cnt, 1u); return; }
         }
     }
     *t.overflow = 2;
@@ -406,7 +411,7 @@ struct LdsWords {
         return ((uint64_t)hi << 32) | lo;
     }
 };
-__global__ __launch_bounds__(BLOCK) void k_dedup_insert(const uint8_t *Y, Spans sp, uint64_t m, uint64_t seed, DedupTable t, uint32_t *longlist, uint32_t *nlong)
+__global__ __launch_bounds__(BLOCK) void k_dedup_insert(const uint8_t *Y, Spans sp, uint64_t m, uint64_t seed, DedupTable t, uint32_t *longlist, uint32_t *nlong, uint8_t *last /*nullable: last[j] = Y[ye[j] - w], pfparser.hpp:599*/)
 {
     __shared__ uint32_t tile[DD_TILE_BYTES / 4 + 20];
     __shared__ unsigned long long wlo[BLOCK / WAVE], whi[BLOCK / WAVE];
@@ -437,9 +442,14 @@ __global__ __launch_bounds__(BLOCK) void k_dedup_insert(const uint8_t *Y, Spans 
         }
     }
     __syncthreads();
-    if (!live || lng) return;
+    if (!live) return;
+    // the character in front of the phrase's closing window, while the phrase is at hand (in LDS, normally): a kernel of its own
+    // read one sector per phrase for this byte
+    if (last && (lng || !tiled)) last[j] = Y[ys + len - 1u - (uint32_t)sp.w];
+    if (lng) return;
     if (!tiled) { dedup_find_or_insert(Y, sp, t, (uint32_t)j, ys, len, str_hash(Y + ys, len, seed)); return; }
     const uint32_t off = (uint32_t)(ys - base);
+    if (last) { const uint32_t o = off + len - 1u - (uint32_t)sp.w; last[j] = (uint8_t)(tile[o >> 2] >> (8u * (o & 3u))); }
     LdsWords hw(tile, off);
     const uint64_t h = hash_words(len, seed, [&hw]() { return hw.next(); });
     const uint64_t filt = h >> 32;
@@ -455,8 +465,8 @@ __global__ __launch_bounds__(BLOCK) void k_dedup_insert(const uint8_t *Y, Spans 
                 const uint32_t k = atomicAdd(t.nd, 1u);
                 if (k >= t.limit) { *t.overflow = 1; return; }
                 t.ent[slot].rinfo = ((unsigned long long)ys << 16) | len;
-                t.dslot[k] = (uint32_t)slot; t.dhash[k] = h;
-                t.slotof[j] = (uint32_t)slot; atomicAdd(&t.ent[slot].cnt, 1u);
+                t.dslot[k] = (uint32_t)slot; t.dhash[k] = h; t.ent[slot].kidx = k;
+                t.slotof[j] = k; atomicAdd(&t.ent[slot].cnt, 1u);
                 return;
             }
             ri = HT_NOINFO;
@@ -482,7 +492,7 @@ __global__ __launch_bounds__(BLOCK) void k_dedup_insert(const uint8_t *Y, Spans 
                         if (i < len) { uint64_t x = a[q] ^ cw.next(); if (len - i < 8) x &= (1ULL << (8 * (len - i))) - 1ULL; diff |= x; }
                     }
                 }
-                if (!diff) { t.slotof[j] = (uint32_t)slot; atomicAdd(&t.ent[slot].cnt, 1u); return; }
+                if (!diff) { t.slotof[j] = entry_ref(t.ent, slot); atomicAdd(&t.ent[slot].cnt, 1u); return; }
             }
         }
     }
@@ -526,7 +536,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dedup_insert_long(const uint8_t 
                     if (cur == HT_EMPTY) {
                         const uint32_t k = atomicAdd(t.nd, 1u);
                         if (k >= t.limit) *t.overflow = 1;
-                        else { t.dslot[k] = (uint32_t)slot; t.dhash[k] = h; t.slotof[j] = (uint32_t)slot; atomicAdd(&t.ent[slot].cnt, 1u); }
+                        else { t.dslot[k] = (uint32_t)slot; t.dhash[k] = h; t.ent[slot].kidx = k; t.slotof[j] = k; atomicAdd(&t.ent[slot].cnt, 1u); }
                         st = 1;
                     }
                 }
@@ -552,7 +562,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dedup_insert_long(const uint8_t 
             __syncthreads();
             const bool same = s_diff == 0;
             __syncthreads();
-            if (same) { if (threadIdx.x == 0) { t.slotof[j] = (uint32_t)slot; atomicAdd(&t.ent[slot].cnt, 1u); } return; }
+            if (same) { if (threadIdx.x == 0) { t.slotof[j] = entry_ref(t.ent, slot); atomicAdd(&t.ent[slot].cnt, 1u); } return; }
             if (threadIdx.x == 0) s_diff = 0;
         }
         slot = (slot + 1) & t.mask;
@@ -562,18 +572,20 @@ __global__ __launch_bounds__(DL_THREADS) void k_dedup_insert_long(const uint8_t 
 }
 // ids = position of an entry's hash among the sorted hashes of the entries in use (deterministic whatever thread created
 // the entry): rep[id] = its representative phrase, occw[id] = its occurrences; the entry then holds the id
-__global__ __launch_bounds__(BLOCK) void k_dedup_assign(const uint32_t *order, uint64_t nd, DedupTable t, uint32_t *rep, uint32_t *occw)
+__global__ __launch_bounds__(BLOCK) void k_dedup_assign(const uint32_t *order, uint64_t nd, DedupTable t, uint32_t *rep, uint32_t *occw, uint32_t *idofk)
 {
     const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= nd) return;
-    const uint32_t slot = t.dslot[order[i]];
+    const uint32_t k = order[i], slot = t.dslot[k];
     rep[i] = (uint32_t)t.ent[slot].tab; occw[i] = t.ent[slot].cnt + 1u;
-    t.ent[slot].tab = (unsigned long long)i;
+    t.ent[slot].tab = (unsigned long long)i; idofk[k] = (uint32_t)i;
 }
-__global__ __launch_bounds__(BLOCK) void k_dedup_ids(const DedupEntry *ent, const uint32_t *slotof, uint64_t m, uint32_t *pid)
+__global__ __launch_bounds__(BLOCK) void k_dedup_ids(const DedupEntry *ent, const uint32_t *idofk, const uint32_t *slotof, uint64_t m, uint32_t *pid)
 {
     const uint64_t j = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (j < m) pid[j] = (uint32_t)ent[slotof[j]].tab;
+    if (j >= m) return;
+    const uint32_t v = slotof[j];
+    pid[j] = (v & HT_BYSLOT) ? (uint32_t)ent[v & ~HT_BYSLOT].tab : idofk[v];
 }
 __global__ __launch_bounds__(BLOCK) void k_iota_u32(uint32_t *v, uint64_t n)
 {
@@ -641,12 +653,6 @@ __global__ __launch_bounds__(BLOCK) void k_rep_starts(Spans sp, const uint32_t *
     if (id >= dwords) return;
     tpos_t ys; uint32_t len; phrase_span(sp, rep[id], &ys, &len);
     srcstart[id] = ys;
-}
-// last[j] = Y[ye[j] - w]   (pfparser.hpp:599)
-__global__ __launch_bounds__(BLOCK) void k_last_chars(const uint8_t *Y, const tpos_t *ye, uint64_t m, int w, uint8_t *last)
-{
-    const uint64_t j = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (j < m) last[j] = Y[ye[j] - (tpos_t)w];
 }
 __global__ __launch_bounds__(BLOCK) void k_fill_u8(uint8_t *p, uint64_t n, uint8_t v)
 {

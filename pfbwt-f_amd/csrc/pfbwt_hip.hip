@@ -312,7 +312,7 @@ static int sort_dict_suffixes(pfp_ctx *c)
 // De-duplicates the m byte strings described by (Y, sp) -- the std::map of pfparser.hpp:69-70, 595-597 -- exactly, with a
 // hash table of representatives (parse.h).  Outputs: number of distinct strings, d_id[j] = id of string j (ids follow the
 // sorted hashes of the distinct strings), rep[id] = a string with that id, occw[id] = how many strings have it.
-static int dedup_strings(pfp_ctx *c, const uint8_t *Y, Spans sp, uint64_t m, uint64_t total_bytes, uint32_t *d_id, uint64_t *ndistinct, uint32_t **rep_out, uint32_t **occw_out)
+static int dedup_strings(pfp_ctx *c, const uint8_t *Y, Spans sp, uint64_t m, uint64_t total_bytes, uint32_t *d_id, uint64_t *ndistinct, uint32_t **rep_out, uint32_t **occw_out, uint8_t *last_out)
 {
     uint32_t *longlist, *d_u32, *slotof;
     const size_t mk0 = c->arena.mark_hi();
@@ -335,13 +335,13 @@ static int dedup_strings(pfp_ctx *c, const uint8_t *Y, Spans sp, uint64_t m, uin
         if (attempt == 0 && force_small) lg = force_small;
         const uint64_t T = 1ULL << lg;
         const uint64_t limit = T >= 2 * m ? m + 1 : T / 2;
-        if (limit >= 0xFFFFFFFFULL) return PFP_E_TOO_LARGE;
+        if (limit >= 0x7FFFFFFFULL || T > 0x80000000ULL) return PFP_E_TOO_LARGE;      // dense entry indices and slots share 31 bits of slotof[]
         PFP_ALLOC_HI(c, t.ent, DedupEntry, T);
         PFP_ALLOC_HI(c, t.dslot, uint32_t, limit); PFP_ALLOC_HI(c, t.dhash, uint64_t, limit);
         t.mask = T - 1; t.slotof = slotof; t.nd = d_u32; t.limit = (uint32_t)limit; t.overflow = d_u32 + 1;
         PFP_HIP(c, hipMemsetAsync(t.ent, 0xFF, T * sizeof(DedupEntry), c->stream));
         PFP_HIP(c, hipMemsetAsync(d_u32, 0, 32, c->stream));
-        PFP_LAUNCH(c, K_PHRASE_HASH, 2 * total_bytes + m * 24, k_dedup_insert, gm, Y, sp, m, c->hash_seed, t, longlist, d_u32 + 2);
+        PFP_LAUNCH(c, K_PHRASE_HASH, 2 * total_bytes + m * 24, k_dedup_insert, gm, Y, sp, m, c->hash_seed, t, longlist, d_u32 + 2, last_out);
         uint32_t h3[3];
         PFP_HIP(c, hipMemcpyAsync(h3, d_u32, 12, hipMemcpyDeviceToHost, c->stream));
         PFP_HIP(c, hipStreamSynchronize(c->stream));
@@ -362,8 +362,10 @@ static int dedup_strings(pfp_ctx *c, const uint8_t *Y, Spans sp, uint64_t m, uin
     PFP_LAUNCH(c, K_MISC, nd * 4, k_iota_u32, nblocks(nd, BLOCK), v0, (uint64_t)nd);
     BitRange full = {0, 64};
     PFP_TRY(radix_sort_pairs<uint64_t>(c, t.dhash, v0, k1, v1, nd, &full, 1, &sk, &sv));
-    PFP_LAUNCH(c, K_DEDUP_HEADS, (uint64_t)nd * 40, k_dedup_assign, nblocks(nd, BLOCK), (const uint32_t *)sv, (uint64_t)nd, t, rep, occw);
-    PFP_LAUNCH(c, K_DEDUP_HEADS, m * 16, k_dedup_ids, gm, (const DedupEntry *)t.ent, (const uint32_t *)slotof, m, d_id);
+    uint32_t *idofk;
+    PFP_ALLOC_HI(c, idofk, uint32_t, nd);
+    PFP_LAUNCH(c, K_DEDUP_HEADS, (uint64_t)nd * 44, k_dedup_assign, nblocks(nd, BLOCK), (const uint32_t *)sv, (uint64_t)nd, t, rep, occw, idofk);
+    PFP_LAUNCH(c, K_DEDUP_HEADS, m * 12, k_dedup_ids, gm, (const DedupEntry *)t.ent, (const uint32_t *)idofk, (const uint32_t *)slotof, m, d_id);
     // the table (32 bytes per entry) is dead now: give its space back and keep only rep / occw, moved to the top of what it
     // occupied (they were allocated below it, and are smaller than it: the two regions cannot overlap)
     c->arena.release_hi(mk0);
@@ -513,9 +515,8 @@ static int parse_finalize_impl(pfp_ctx *c, pfp_parse_sizes *out)
     uint64_t dwords = 0; uint32_t *rep, *occw;
     PFP_ALLOC_LO(c, c->d_pid, uint32_t, m);
     PFP_ALLOC_LO(c, c->d_last, uint8_t, m);
-    PFP_TRY(dedup_strings(c, Y, sp, m, n + (uint64_t)w + 1 + m * (uint64_t)w, c->d_pid, &dwords, &rep, &occw));
+    PFP_TRY(dedup_strings(c, Y, sp, m, n + (uint64_t)w + 1 + m * (uint64_t)w, c->d_pid, &dwords, &rep, &occw, c->d_last));      // + last[j] = Y[ye[j] - w], pfparser.hpp:599
     PFP_TRY(build_dictionary(c, Y, sp, rep, dwords));
-    PFP_LAUNCH(c, K_MISC, m * 6, k_last_chars, nblocks(m, BLOCK), Y, (const tpos_t *)c->d_ye, m, w, c->d_last);
     // 3. dictionary suffix sort, ranks, occ, parse, sorted .dict image
     PFP_TRY(finish_parse(c, occw));
     PFP_HIP(c, hipStreamSynchronize(c->stream));
@@ -793,7 +794,7 @@ static int merge_shards_impl(pfp_ctx *c, int nshards, const pfp_shard_view *v, p
     // ---- global distinct words, dictionary
     Spans sp; sp.ye = nullptr; sp.ys32 = cys; sp.ye32 = cye; sp.w = 0;
     uint64_t dwords = 0; uint32_t *rep, *occ_cand, *occw;
-    PFP_TRY(dedup_strings(c, U, sp, call, dtot + junc.size(), cand_id, &dwords, &rep, &occ_cand));
+    PFP_TRY(dedup_strings(c, U, sp, call, dtot + junc.size(), cand_id, &dwords, &rep, &occ_cand, (uint8_t *)nullptr));
     PFP_TRY(build_dictionary(c, U, sp, rep, dwords));
     // ---- global phrase sequence
     c->n = ntot; c->m = mtot;
