@@ -1174,7 +1174,7 @@ template <typename SAT, typename EBT> static int emit_and_sample(pfp_ctx *c, Emi
             if (!overflow && run_base + rc > cap) overflow = true;
             if (!overflow) {
                 const bool last = wn.ce == total;
-                PFP_LAUNCH(c, K_SAMPLES, rows / 8 + (uint64_t)rc * 4 * sizeof(SAT), (k_sample_rows<SAT>), ntiles, (const uint16_t *)rmask, rows, (const uint32_t *)tilebase, wn.cs, run_base, total,
+                PFP_LAUNCH(c, K_SAMPLES, rows / 8 + (uint64_t)rc * 4 * sizeof(SAT), (k_sample_rows<SAT>), nblocks(ntiles, SR_TILES), (const uint16_t *)rmask, rows, (uint64_t)ntiles, (const uint32_t *)tilebase, wn.cs, run_base, total,
                            last ? run_base + rc + 1 : (uint64_t)0, ssa, esa_w);
                 PFP_LAUNCH(c, K_SAMPLES, (uint64_t)rc * (2 * 60 + 4 * sizeof(SAT)), (k_sample_values<SAT, EBT>), nblocks((uint64_t)rc + 1, BLOCK), ea, (const SAT *)nullptr, (const uint32_t *)qtmp, wn.cs - wn.cl, (uint64_t)rc, run_base,
                            (int)last, last ? (uint64_t)(run_base + rc - 1) : (uint64_t)0, ssa, esa_w);
@@ -1228,7 +1228,7 @@ template <typename SAT, typename EBT> static int emit_and_sample(pfp_ctx *c, Emi
             uint32_t rc = 0; PFP_TRY(d2h_u32(c, d_cnt, &rc));
             if (run_base + rc > r) return PFP_E_CORRUPT;
             const bool last = wn.ce == total;
-            PFP_LAUNCH(c, K_SAMPLES, rows / 8 + (uint64_t)rc * 4 * sizeof(SAT), (k_sample_rows<SAT>), ntiles, (const uint16_t *)rmask, rows, (const uint32_t *)tilebase, wn.cs, run_base, total, last ? r + 1 : (uint64_t)0, ssa, esa_w);
+            PFP_LAUNCH(c, K_SAMPLES, rows / 8 + (uint64_t)rc * 4 * sizeof(SAT), (k_sample_rows<SAT>), nblocks(ntiles, SR_TILES), (const uint16_t *)rmask, rows, (uint64_t)ntiles, (const uint32_t *)tilebase, wn.cs, run_base, total, last ? r + 1 : (uint64_t)0, ssa, esa_w);
             PFP_LAUNCH(c, K_SAMPLES, (uint64_t)rc * (2 * 60 + 4 * sizeof(SAT)), (k_sample_values<SAT, EBT>), nblocks((uint64_t)rc + 1, BLOCK), ea, sabuf ? (const SAT *)(sabuf + (wn.cs - wn.cl - (s0 - lead))) : (const SAT *)nullptr,
                        (const uint32_t *)qtmp, wn.cs - wn.cl, (uint64_t)rc, run_base, (int)last, last ? (uint64_t)(r - 1) : (uint64_t)0, ssa, esa_w);
             run_base += rc;
