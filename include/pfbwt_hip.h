@@ -98,6 +98,11 @@ int pfp_text_view(pfp_ctx *ctx, const uint8_t **d_text, uint64_t *n);
 /* PfParser::finalize pfparser.hpp:484-517 (+ process_phrase :595-601 for every phrase): trigger scan,
  * phrase de-duplication, dictionary sort, ranks, occ, last, sai.  Results stay on the device. */
 int pfp_parse_finalize(pfp_ctx *ctx, pfp_parse_sizes *out);
+/* The same for a shard that is only going to be merged (pfp_shard_view_get + pfp_merge_shards): phrases, dictionary words
+ * and phrase ids, but no dictionary sort, ranks, .parse or .occ -- the merge produces those for the united dictionary.  The
+ * context then answers pfp_shard_view_get only (pfp_parse_get / pfp_parse_bwt: PFP_E_STATE), like one filled by
+ * pfp_shard_load. */
+int pfp_parse_finalize_shard(pfp_ctx *ctx, pfp_parse_sizes *out);
 /* save_parser pfbwt_io.hpp:234-249 getters: copy results to caller-owned host buffers (NULL skips).
  * dict: dsize bytes (.dict image); occ: dwords U-wide; parse: m uint32 (1-based ranks);
  * last: m bytes; sai: m U-wide (only with PFP_FLAG_SAI). */

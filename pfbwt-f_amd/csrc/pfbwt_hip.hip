@@ -441,21 +441,23 @@ struct ArenaGuard {
     }
 };
 
-static int parse_finalize_impl(pfp_ctx *c, pfp_parse_sizes *out);
-int pfp_parse_finalize(pfp_ctx *c, pfp_parse_sizes *out)
+static int parse_finalize_impl(pfp_ctx *c, pfp_parse_sizes *out, bool shard_only);
+static int parse_finalize_entry(pfp_ctx *c, pfp_parse_sizes *out, bool shard_only)
 {
     if (!c) return PFP_E_ARG;
     if (c->stage != 0) return PFP_E_STATE;
     if (c->n == 0) return PFP_E_ARG;
     PFP_HIP(c, hipSetDevice(c->device));
     ArenaGuard g(c);
-    const int rc = g.done(parse_finalize_impl(c, out));
+    const int rc = g.done(parse_finalize_impl(c, out, shard_only));
     // after a failure the fed text is still there (stage 0): finalize can be retried (more workspace), more text can be
     // appended, or pfp_reset drops it
     if (rc != PFP_OK) { c->m = c->dwords = c->dsize = 0; c->gsa_valid = false; }
     return rc;
 }
-static int parse_finalize_impl(pfp_ctx *c, pfp_parse_sizes *out)
+int pfp_parse_finalize(pfp_ctx *c, pfp_parse_sizes *out) { return parse_finalize_entry(c, out, false); }
+int pfp_parse_finalize_shard(pfp_ctx *c, pfp_parse_sizes *out) { return parse_finalize_entry(c, out, true); }
+static int parse_finalize_impl(pfp_ctx *c, pfp_parse_sizes *out, bool shard_only)
 {
     HostTimer timer;
     const uint64_t n = c->n; const int w = c->w;
@@ -517,8 +519,9 @@ static int parse_finalize_impl(pfp_ctx *c, pfp_parse_sizes *out)
     PFP_ALLOC_LO(c, c->d_last, uint8_t, m);
     PFP_TRY(dedup_strings(c, Y, sp, m, n + (uint64_t)w + 1 + m * (uint64_t)w, c->d_pid, &dwords, &rep, &occw, c->d_last));      // + last[j] = Y[ye[j] - w], pfparser.hpp:599
     PFP_TRY(build_dictionary(c, Y, sp, rep, dwords));
-    // 3. dictionary suffix sort, ranks, occ, parse, sorted .dict image
-    PFP_TRY(finish_parse(c, occw));
+    // 3. dictionary suffix sort, ranks, occ, parse, sorted .dict image -- not for a shard that is only going to be merged: the
+    //    merge sorts the united dictionary, and a shard's dictionary is nearly as large as the whole collection's
+    if (!shard_only) PFP_TRY(finish_parse(c, occw));
     PFP_HIP(c, hipStreamSynchronize(c->stream));
     c->arena.release_hi(mk);
     c->stage = 1;

@@ -74,7 +74,7 @@ int main(int argc, char **argv)
                 pfbwtf::engine_check(sh.ctx, pfp_parse_feed(sh.ctx, (const uint8_t *)rec.seq.data(), rec.seq.size(), 1), "pfp_parse_feed");
                 fed += rec.seq.size() + (uint64_t)w;
             }
-            pfbwtf::engine_check(sh.ctx, pfp_parse_finalize(sh.ctx, nullptr), "pfp_parse_finalize");
+            pfbwtf::engine_check(sh.ctx, pfp_parse_finalize_shard(sh.ctx, nullptr), "pfp_parse_finalize_shard");
         } else {
             fprintf(stderr, "ERROR: %s not found, cannot add it to parse!\n", prefix.data());
             continue;

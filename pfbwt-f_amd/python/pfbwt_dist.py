@@ -74,7 +74,7 @@ def sharded_build(ctx, feed_local, w, device, sa=True, rssa=False, group=None):
         if rank > 0:
             ctx.feed_left_context(w)
         feed_local(ctx)
-        sz_local = ctx.finalize()
+        sz_local = ctx.finalize(shard=True)        # no dictionary sort / ranks on a shard: the merge makes them for the union
         if sz_local.m < 2 and world > 1:      # pfp_merge_shards needs the first and the last phrase of a shard to be different phrases
             raise ValueError("shard of rank %d has a single phrase (no trigger window inside it): give it more sequence or use fewer ranks" % rank)
     except Exception as e:      # an invalid character, a shard that is too small, ...: every rank must learn of it BEFORE the

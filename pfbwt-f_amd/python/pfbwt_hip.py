@@ -66,6 +66,7 @@ def load_library(path=None):
     L.pfp_parse_feed_batch.argtypes = [vp, vp, u64, u64, u64]
     L.pfp_parse_feed_device.argtypes = [vp, vp, u64, i32]
     L.pfp_parse_finalize.argtypes = [vp, C.POINTER(ParseSizes)]
+    L.pfp_parse_finalize_shard.argtypes = [vp, C.POINTER(ParseSizes)]
     L.pfp_parse_get.argtypes = [vp, vp, vp, vp, vp, vp]
     L.pfp_parse_bwt.argtypes = [vp]
     L.pfp_parse_bwt_get.argtypes = [vp, vp, vp, vp]
@@ -147,9 +148,10 @@ class PfpContext:
     def feed_device(self, dptr, nbytes, end_of_seq=True):
         self._check(self.L.pfp_parse_feed_device(self.h, C.c_void_p(int(dptr)), int(nbytes), 1 if end_of_seq else 0))
 
-    def finalize(self):
+    def finalize(self, shard=False):
+        """shard=True: pfp_parse_finalize_shard -- phrases, dictionary words and ids only (a shard that is going to be merged)"""
         s = ParseSizes()
-        self._check(self.L.pfp_parse_finalize(self.h, C.byref(s)))
+        self._check((self.L.pfp_parse_finalize_shard if shard else self.L.pfp_parse_finalize)(self.h, C.byref(s)))
         self.sizes = s
         return s
 

@@ -28,7 +28,7 @@ def test_product_header_holds_no_development_hooks():
 
 def test_header_declares_expected_entry_points():
     syms = declared_symbols()
-    for s in ("pfp_create", "pfp_parse_feed", "pfp_parse_finalize", "pfp_parse_bwt", "pfp_bwt_load", "pfp_bwt_build", "pfp_bwt_get", "pfp_sacak_int_u32"):
+    for s in ("pfp_create", "pfp_parse_feed", "pfp_parse_finalize", "pfp_parse_finalize_shard", "pfp_parse_bwt", "pfp_bwt_load", "pfp_bwt_build", "pfp_bwt_get", "pfp_sacak_int_u32"):
         assert s in syms
 
 

@@ -35,7 +35,7 @@ def sharded_single_process(factory, seqs, shards, w, p, U, mode="context"):
                 c.feed_left_context(w)
             for i in grp:
                 c.feed(seqs[i], True)
-            c.finalize()
+            c.finalize(shard=(len(shards) % 2 == 1))      # both ways: a shard needs no dictionary sort / ranks of its own
         ctxs.append(c); views.append(c.shard_view())
         assert views[-1].left_context == (w if (r > 0 and mode == "context") else 0)
     g = factory(w=w, p=p, u64=(U == 8), sai=True)
@@ -66,6 +66,21 @@ def seam_trigger_seqs():
     """sequences whose first w windows hold triggers for (w, p) = (4, 3) and (6, 2): a stand-alone parse cannot cut there"""
     rng = np.random.default_rng(17)
     return [bytes(rng.choice(list(b"ACGT"), n).astype(np.uint8)) for n in (900, 35, 700, 5, 1200, 64, 300)]
+
+
+def test_shard_finalize_state_emu(emu_factory):
+    """pfp_parse_finalize_shard: the context answers pfp_shard_view_get and nothing that needs ranks (PFP_E_STATE)"""
+    import pfbwt_hip
+    c = emu_factory(w=4, p=7, u64=True, sai=True)
+    for s in synth(3, 3000, 2): c.feed(s, True)
+    sz = c.finalize(shard=True)
+    v = c.shard_view()
+    assert v.m == sz.m and v.dwords == sz.dwords and sz.m > 2
+    for call in (c.parse_get, c.parse_bwt):
+        with pytest.raises(pfbwt_hip.PfpError) as e:
+            call()
+        assert e.value.status == pfbwt_hip.E_STATE
+    c.close()
 
 
 @pytest.mark.parametrize("mode", ["standalone", "loaded"])

@@ -46,7 +46,7 @@ for r in range(a.ranks):
             ctx.feed_left_context(w)
         for h in range(r * Hl, (r + 1) * Hl):
             ctx.feed(big[h], True)
-        t1 = time.time(); sz = ctx.finalize(); sync(); t2 = time.time()
+        t1 = time.time(); sz = ctx.finalize(shard=True); sync(); t2 = time.time()
     buf, meta = pfbwt_dist.pack_local_shard(ctx, dev); sync(); t3 = time.time()
     packed.append(buf); metas.append(meta); t_parse.append(t2 - t1)
     print("rank %d: local n=%d m=%d dwords=%d dsize=%d | feed(H2D) %.2fs parse %.3fs pack %.3fs payload %.1f MB"
