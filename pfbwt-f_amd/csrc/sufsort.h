@@ -612,7 +612,7 @@ template <bool DICT> inline int suffix_sort_doubling(pfp_ctx *c, uint64_t N, uin
     int rounds = 1;
     const int rbits = bits_for(N);
     static const bool verbose = getenv("PFP_VERBOSE") != nullptr;
-    static const int force_k = getenv("PFP_SORT_K") ? atoi(getenv("PFP_SORT_K")) : 0;      // tests / A-B runs: 1 = plain doubling in every round
+    static const int force_k = getenv("PFP_SORT_K") ? atoi(getenv("PFP_SORT_K")) : 0;      // tests / A-B runs: 1 = plain doubling in every round, 3 = three ranks in every round but the run round
     if (na > 0) {
         // active lists (two sets, swapped every round) and the per-round outputs; every later list is shorter than the first
         for (int t = 0; t < 2; ++t) { PFP_ALLOC_HI(c, b.aslot[t], uint32_t, na); PFP_ALLOC_HI(c, b.arnk[t], uint32_t, na); if (DICT) PFP_ALLOC_HI(c, b.ajmp[t], uint32_t, na); }
@@ -634,12 +634,18 @@ template <bool DICT> inline int suffix_sort_doubling(pfp_ctx *c, uint64_t N, uin
             PFP_ALLOC_HI(c, b.T, uint4, N);          // optional: without room for it the K = 3 rounds follow the chains themselves
         static const uint32_t max_range_env = getenv("PFP_CLASS_SORT_MAXRANGE") ? (uint32_t)atoi(getenv("PFP_CLASS_SORT_MAXRANGE")) : 0u;   // tests: smaller, to reach the large-class route
         int cur = 0; uint64_t h = h0;
+        uint32_t na_before = 0;                 // length of the list the previous round started from (0: no previous round)
         while (na > 0) {
             if (verbose) fprintf(stderr, "[pfbwt_hip] suffix sort N=%llu round %d: %u active\n", (unsigned long long)N, rounds, na);
             if (rounds > 64) return PFP_E_CORRUPT; // cannot happen on well-formed input
             const bool run_round = (b.M != nullptr && rounds == 1);
             uint32_t nn = 0;
-            if (run_round || force_k == 1) {
+            // K = 3 pays while the classes keep splitting without dissolving (14 LDS passes instead of 6, but half the rounds);
+            // once a round has resolved more than half of its pairs, most of the rest is decided by the FIRST further rank and
+            // the two extra ranks are sorted for nothing: plain doubling (6 passes) from there on
+            const bool resolving = na_before != 0 && (uint64_t)na * 2 < na_before;
+            na_before = na;
+            if (run_round || force_k == 1 || (resolving && force_k != 3)) {
                 const uint32_t mr = max_range_env ? max_range_env : (uint32_t)RoundCfg<1>::TILE;
                 PFP_TRY((suffix_sort_round<DICT, 1>(c, b, cur, na, N, h, D, run_round, rbits, mr < (uint32_t)RoundCfg<1>::TILE ? mr : (uint32_t)RoundCfg<1>::TILE, SA, rank, rj, verbose, &nn)));
                 h *= 2;
