@@ -1,5 +1,6 @@
-// pfbwt-f_amd/csrc/sufsort.h -- suffix sorting on the device by prefix doubling with radix sort
-// and active-set filtering.  Two uses:
+// pfbwt-f_amd/csrc/sufsort.h -- suffix sorting on the device by prefix refinement (initial radix sort, then
+// rounds that order every class of equal prefixes by the ranks of one -- or three: the covered prefix grows 4x --
+// further prefixes, inside LDS) with active-set filtering.  Two uses:
 //   * the parse (integer alphabet): stands in for sacak_int, gsa/gsacak.c:2499-2502 -> SACA_K :1397-1526,
 //     called at include/pfparser.hpp:425;
 //   * the dictionary (bytes, words ended by EndOfWord): stands in for gsacak + LCP,
