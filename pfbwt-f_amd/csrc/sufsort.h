@@ -85,15 +85,13 @@ __global__ __launch_bounds__(BLOCK) void k_ss_runend_marks(const uint8_t *D, uin
 
 // ---- state of the refinement -------------------------------------------------------------------------------------
 //   SA[slot] = x                          suffixes in the order found so far; a class = a contiguous range of slots
-//   int alphabet:  rank[x]                the label of x's class: a slot of the class's own slot range (the head's at first,
-//                                         see k_round: a class keeps its label through a split when it can) -- order-
-//                                         preserving because the ranges are disjoint; jumps are uniform there: the suffix one
-//                                         covered prefix on is x + h
+//   int alphabet:  rank[x]                slot of the head of x's class (jumps are uniform there: the suffix one covered
+//                                         prefix on is x + h)
 //   dictionary:    rj[x] = {rank, jump}   jump = end of the prefix [x, jump) the rank orders x by; never past the first
 //                                         byte after the word's EndOfWord, so "the covered prefix contains the
 //                                         terminator" (the class is a group of identical suffixes, final) is
 //                                         D[jump - 1] == EndOfWord
-//   active list, in slot order:  aslot[a], arnk[a] = label of its class (dictionary: slot of the class head), ajmp[a] (dictionary)
+//   active list, in slot order:  aslot[a], arnk[a] = rank of its class (= slot of the class head), ajmp[a] (dictionary)
 // One round = k_round (sort inside every class by the ranks of the next K covered prefixes, new heads, new ranks, SA;
 // the pairs cross HBM once) + k_round_apply (ranks that changed are scattered to rank[] / rj[] only now -- a round must
 // read the ranks of ONE state --, the list of classes that still have to be refined is compacted per stripe).
@@ -335,15 +333,8 @@ template <bool DICT, int K> __global__ __launch_bounds__(BLOCK) void k_round(con
     // the keys are not needed any more: their LDS holds the suffixes now, indexed by position before the sort, so that the
     // output below does not gather SA a second time
     uint32_t *sx = reinterpret_cast<uint32_t *>(skeys);
-    // int alphabet: last position of every new class, stored at its head position (the label rule below needs the class's
-    // slot range); the free half of the key array holds it
-    uint16_t *tailpos = reinterpret_cast<uint16_t *>(sx + TILE);
-    static_assert(sizeof(uint64_t) * TILE >= sizeof(uint32_t) * TILE + sizeof(uint16_t) * TILE, "suffixes + tail positions fit the key array");
 #pragma unroll
-    for (int it = 0; it < ITEMS; ++it) {
-        const uint32_t j = threadIdx.x + (uint32_t)it * BLOCK;
-        if (j < n) { sx[j] = xi[it]; if (!DICT && shp[j + 1] != shp[j]) tailpos[shp[j]] = (uint16_t)j; }
-    }
+    for (int it = 0; it < ITEMS; ++it) { const uint32_t j = threadIdx.x + (uint32_t)it * BLOCK; if (j < n) sx[j] = xi[it]; }
     __syncthreads();
     // ---- output: all gathers first (the old SA of the range's slots is overwritten below; loads of all of a thread's pairs
     //      are in flight together), then the stores
@@ -355,18 +346,8 @@ template <bool DICT, int K> __global__ __launch_bounds__(BLOCK) void k_round(con
         const uint32_t src = ok ? sidx[j] : 0u, hp = ok ? shp[j] : 0u;
         xs[it] = ok ? sx[src] : 0u;
         slo[it] = ok ? aslot[s + j] : 0u;
+        nrv[it] = ok ? aslot[s + hp] : 0u;
         oldr[it] = ok ? arnk[s + j] : 0u;
-        if (DICT) nrv[it] = ok ? aslot[s + hp] : 0u;       // the class's label = the slot of its head (what the emission indexes groups by)
-        else {
-            // int alphabet: ANY slot of a class's own slot range is an order-preserving label (the ranges of different classes
-            // are disjoint and ordered).  The class that contains the old label's slot keeps it -- none of its members' ranks
-            // has to be scattered --, every other new class takes its middle slot, which a majority sub-class of a later split
-            // contains again.  With head-slot labels only the lexicographically FIRST sub-class kept the label, and 50-87 % of
-            // the ranks of a pangenome's parse were re-written in every round.
-            const uint32_t tp = ok ? tailpos[hp] : 0u;
-            const uint32_t first = ok ? aslot[s + hp] : 0u, last = ok ? aslot[s + tp] : 0u, mid = ok ? aslot[s + ((hp + tp) >> 1)] : 0u;
-            nrv[it] = (oldr[it] >= first && oldr[it] <= last) ? oldr[it] : mid;
-        }
         njo[it] = (DICT && ok) ? tnj[s + src] : 0u;
         const bool single = ok && hp == j && shp[j + 1] == j + 1;
         flg[it] = ok ? (uint8_t)(RF_DONE | (single ? 0 : RF_KEEP)) : (uint8_t)0;
