@@ -485,7 +485,12 @@ __global__ __launch_bounds__(BLOCK) void k_dedup_insert(const uint8_t *Y, Spans 
                 for (uint32_t c0 = 0; c0 < len; c0 += 128u) {
                     uint64_t a[16];
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) { const uint32_t i = c0 + 8u * (uint32_t)q; a[q] = i < len ? ld8(r + i) : 0ULL; }
+                    for (int q = 0; q < 16; q += 2) {      // 16 bytes per request: every lane reads another line, and the requests, not the bytes, are what the memory pipeline counts (callers keep 15 readable bytes behind every string)
+                        const uint32_t i = c0 + 8u * (uint32_t)q;
+                        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                        if (i < len) __builtin_memcpy(&v, r + i, 16);
+                        a[q] = ((uint64_t)v.y << 32) | v.x; a[q + 1] = ((uint64_t)v.w << 32) | v.z;
+                    }
 #pragma unroll
                     for (int q = 0; q < 16; ++q) {
                         const uint32_t i = c0 + 8u * (uint32_t)q;
