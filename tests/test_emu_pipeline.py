@@ -100,6 +100,34 @@ def test_emu_random_differential(emu_factory, seed):
     check_random(emu_factory, seed, 25)
 
 
+def test_emu_workspace_sweep(emu_factory):
+    """explicit workspace sizes from far too small to ample: every build either equals the oracle or reports PFP_E_NOMEM at a
+    stage boundary (the optional allocations -- the table of the three-rank rounds -- must give way, not fail the build)"""
+    import pfbwt_hip
+    rng = np.random.default_rng(5)
+    base = rng.choice(list(b"ACGT"), 60000).astype(np.uint8)
+    seqs = []
+    for h in range(6):
+        b = base.copy()
+        for _ in range(200): b[int(rng.integers(0, b.size))] = rng.choice(list(b"ACGT"))
+        seqs.append(bytes(b))
+    ref = oracle_run(seqs, w=10, p=20, U=8)
+    outcomes = []
+    for ws in (1 << 20, 10 << 20, 14 << 20, 18 << 20, 24 << 20, 64 << 20):
+        c = emu_factory(w=10, p=20, u64=True, sai=True, workspace_bytes=ws)
+        try:
+            for s in seqs: c.feed(s, True)
+            c.finalize(); c.parse_bwt(); b = c.bwt_build(sa=True, rssa=True)
+            res = c.bwt_get(); res["r"] = b.r
+            assert compare(res, ref, 8, names=("bwt", "sa", "ssa", "esa")) == [] and b.r == ref["r"], ws
+            outcomes.append("ok")
+        except pfbwt_hip.PfpError as e:
+            assert e.status == pfbwt_hip.E_NOMEM, (ws, e)
+            outcomes.append("nomem")
+        c.close()
+    assert outcomes[0] == "nomem" and outcomes[-1] == "ok" and outcomes == sorted(outcomes, key=lambda o: o == "ok"), outcomes
+
+
 def test_emu_ragged_inputs(emu_factory):
     from pfp_testlib import check_ragged
     check_ragged(emu_factory)
