@@ -243,13 +243,18 @@ __global__ __launch_bounds__(TS_THREADS) void k_trigger_scan_tab(uint8_t *X, uin
             cur[threadIdx.x] = hv;
         }
         __syncthreads();       // the one barrier per tile (tile k + 2 reuses this buffer only after every wave has passed the barrier of tile k + 1)
-        uint32_t kmer = cur[threadIdx.x + 1];                      // the 16 bases in front: enough for w <= 10
+        // the k-mer that ends at base b is a window of the 64-bit string {the 16 bases in front : this thread's 16 bases}
+        // (hash.hpp:32): its table word and its bit come straight out of that pair by constant shifts (v_alignbit_b32) -- 6
+        // VALU instructions per base where shifting the k-mer along base by base took 9-10, and the scan is VALU-bound
+        const uint64_t both = ((uint64_t)cur[threadIdx.x + 1] << 32) | mine;
+        const uint32_t amask = (kmask >> 5) << 2, bmask = kmask & 31u;        // byte offset of the table word; bit inside it
+        const uint8_t *stab8 = reinterpret_cast<const uint8_t *>(stab);
         uint32_t trig = 0;
 #pragma unroll
         for (int b = 0; b < 16; ++b) {
-            kmer = (kmer << 2) | ((mine >> (30 - 2 * b)) & 3u);   // hash.hpp:32
-            const uint32_t km = kmer & kmask;
-            trig |= ((stab[km >> 5] >> (km & 31u)) & 1u) << b;
+            const uint32_t word = *reinterpret_cast<const uint32_t *>(stab8 + ((uint32_t)(both >> (33 - 2 * b)) & amask));
+            const uint32_t bit = (uint32_t)(both >> (30 - 2 * b)) & bmask;
+            trig |= ((word >> bit) & 1u) << b;
         }
         // pfparser.hpp:347: pos_ > w  <=>  pos >= w; nothing at or behind n
         if (base < (uint64_t)w) trig &= ~((1u << (unsigned)((uint64_t)w - base > 16 ? 16 : (uint64_t)w - base)) - 1u);
