@@ -11,18 +11,38 @@ ENVS = [{}, {"PFP_CLASS_SORT_MAXRANGE": "40"}, {"PFP_SORT_NO_TABLE": "1", "PFP_F
 ap = argparse.ArgumentParser()
 ap.add_argument("--seeds", type=int, nargs=2, default=[1000, 1010]); ap.add_argument("--count", type=int, default=25)
 ap.add_argument("--emu", action="store_true"); ap.add_argument("--envs", action="store_true"); ap.add_argument("--child", action="store_true")
+ap.add_argument("--medium", type=int, default=0, help="instead of the small cases: this many synthetic panels of 0.5-10 Mbase (bench generator: variant sites with skewed allele frequencies, optional N runs)")
 a = ap.parse_args()
 if a.envs and not a.child:
     for e in ENVS:
         env = dict(os.environ); env.update(e)
         t0 = time.time()
-        pr = subprocess.run([sys.executable, os.path.abspath(__file__), "--seeds", str(a.seeds[0]), str(a.seeds[1]), "--count", str(a.count), "--child"] + (["--emu"] if a.emu else []), env=env, capture_output=True, text=True)
+        pr = subprocess.run([sys.executable, os.path.abspath(__file__), "--seeds", str(a.seeds[0]), str(a.seeds[1]), "--count", str(a.count), "--medium", str(a.medium), "--child"] + (["--emu"] if a.emu else []), env=env, capture_output=True, text=True)
         print("%s: rc=%d %.0fs %s" % (e or "default", pr.returncode, time.time() - t0, pr.stdout.strip().splitlines()[-1] if pr.stdout.strip() else pr.stderr[-800:]), flush=True)
         if pr.returncode: sys.exit(1)
     sys.exit(0)
 import pfbwt_hip
 from pfp_testlib import EMU_SO, check_random
 factory = (lambda **kw: pfbwt_hip.PfpContext(lib=EMU_SO, **kw)) if a.emu else (lambda **kw: pfbwt_hip.PfpContext(**kw))
+if a.medium:
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    import bench
+    from pfp_testlib import compare, engine_run, oracle_run
+    rng = np.random.default_rng(a.seeds[0])
+    for ci in range(a.medium):
+        H = int(rng.integers(2, 120)); L = int(rng.integers(20_000, 400_000)); L = min(L, 10_000_000 // H)
+        w = int(rng.choice([4, 6, 8, 10, 10, 10, 12])); p = int(rng.choice([7, 20, 50, 100, 100])); U = int(rng.choice([4, 8]))
+        nruns = (int(rng.integers(0, L // 2)), int(rng.integers(0, 5000)), 0, 0) if rng.random() < 0.4 else (0, 0, 0, 0)
+        seqs = [bytes(x) for x in bench.synth_seqs(L, H, int(rng.integers(1, 1 << 30)), nruns)]
+        sa, rssa = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        ref = oracle_run(seqs, w=w, p=p, U=U)
+        res = engine_run(factory, seqs, w, p, U, sa=sa, rssa=rssa)
+        names = ["dict", "occ", "parse", "last", "sai", "bwlast", "ilist", "bwsai", "bwt"] + (["sa"] if sa else []) + (["ssa", "esa"] if rssa else [])
+        bad = compare(res, ref, U, names=tuple(names))
+        assert bad == [] and res["r"] == ref["r"], (ci, H, L, w, p, U, nruns, bad)
+    print("ok: %d medium panels (0.5-10 Mbase), seed %d" % (a.medium, a.seeds[0]))
+    sys.exit(0)
 n = 0
 for seed in range(a.seeds[0], a.seeds[1]):
     check_random(factory, seed, a.count); n += a.count
