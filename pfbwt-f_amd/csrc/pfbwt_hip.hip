@@ -671,11 +671,16 @@ static int merge_shards_impl(pfp_ctx *c, int nshards, const pfp_shard_view *v, p
     HostTimer timer;
     const uint32_t w = (uint32_t)c->w;
     uint64_t ntot = 0, mtot = 0, dtot = 0, ctot = 0;
+    // interior phrases of shard r = [ia[r], ib[r]): all but the head fragment (r > 0) and the tail fragment (r < N-1); a shard
+    // of ONE phrase (a short record or contig without a trigger window) in the middle is both at once and has none
+    std::vector<uint64_t> ia((size_t)nshards), ib((size_t)nshards);
     for (int r = 0; r < nshards; ++r) {
         const uint64_t lc = v[r].left_context;
         if ((lc != 0 && lc != w) || (r == 0 && lc != 0)) return PFP_E_ARG;
-        if (v[r].m < 2 || v[r].n < lc + 1 || !v[r].d_dict || !v[r].d_ws || !v[r].d_pid || !v[r].d_ye || !v[r].d_last) return PFP_E_ARG;
-        ntot += v[r].n - lc; mtot += v[r].m - (r ? 1 : 0); dtot += v[r].dsize; ctot += v[r].dwords;
+        if (v[r].m < 1 || v[r].n < lc + 1 || !v[r].d_dict || !v[r].d_ws || !v[r].d_pid || !v[r].d_ye || !v[r].d_last) return PFP_E_ARG;
+        ia[r] = r ? 1 : 0; ib[r] = r + 1 < nshards ? v[r].m - 1 : v[r].m;
+        if (ib[r] < ia[r]) ib[r] = ia[r];
+        ntot += v[r].n - lc; mtot += ib[r] - ia[r]; dtot += v[r].dsize; ctot += v[r].dwords;
     }
     if (ntot + w + 64 >= ((c->flags & PFP_FLAG_U64) ? (1ULL << 40) : 0xFFFFFFFFULL) || dtot + 64 >= 0xFFFFFFFFULL || mtot > 0xFFFFFFFEULL - 64) return PFP_E_TOO_LARGE;
     reset_results(c);
@@ -683,8 +688,8 @@ static int merge_shards_impl(pfp_ctx *c, int nshards, const pfp_shard_view *v, p
     c->arena.reset();
     PFP_HIP(c, hipStreamSynchronize(c->stream));
     const size_t mk = c->arena.mark_hi();
-    // ---- host: the two fragment words of every boundary -> junction words
-    struct Frag { uint32_t id0 = 0xFFFFFFFFu, idl = 0xFFFFFFFFu; tpos_t ye0 = 0; uint32_t last0 = 0; std::vector<uint8_t> w0, wl; };
+    // ---- host: the fragment words of every boundary
+    struct Frag { uint32_t id0 = 0xFFFFFFFFu, idl = 0xFFFFFFFFu; std::vector<uint8_t> w0, wl; };
     std::vector<Frag> fr((size_t)nshards);
     auto fetch_word = [&](const pfp_shard_view &sv, uint32_t id, std::vector<uint8_t> &dst) -> int {
         uint32_t se[2];
@@ -694,26 +699,26 @@ static int merge_shards_impl(pfp_ctx *c, int nshards, const pfp_shard_view *v, p
         return PFP_OK;
     };
     for (int r = 0; r < nshards; ++r) {
-        if (r > 0) {
+        if (r > 0 || (v[r].m == 1 && nshards > 1)) {      // first phrase: head fragment (shard 0 with one phrase: the start of the first junction phrase)
             PFP_HIP(c, hipMemcpy(&fr[r].id0, v[r].d_pid, 4, hipMemcpyDeviceToHost));
-            PFP_HIP(c, hipMemcpy(&fr[r].ye0, v[r].d_ye, sizeof(tpos_t), hipMemcpyDeviceToHost));
-            uint8_t l0 = 0; PFP_HIP(c, hipMemcpy(&l0, v[r].d_last, 1, hipMemcpyDeviceToHost)); fr[r].last0 = l0;
             PFP_TRY(fetch_word(v[r], fr[r].id0, fr[r].w0));
             if (fr[r].w0.size() < 1 + (size_t)w) return PFP_E_CORRUPT;
         }
-        if (r + 1 < nshards) {
+        if (r + 1 < nshards && v[r].m > 1) {
             PFP_HIP(c, hipMemcpy(&fr[r].idl, v[r].d_pid + (v[r].m - 1), 4, hipMemcpyDeviceToHost));
             PFP_TRY(fetch_word(v[r], fr[r].idl, fr[r].wl));
             if (fr[r].wl.size() < (size_t)w) return PFP_E_CORRUPT;
         }
     }
-    // Junction phrases of every seam r | r+1.  tail = last phrase of shard r without its w Dollars, head = first phrase of
-    // shard r+1 without its Dollar (and without the left context, if it was parsed with one).  A shard that knew its left
-    // context has already cut its head at every trigger; a stand-alone shard could not trigger in its first w windows
-    // (pfparser.hpp:347 "pos_ > w"), so those windows are re-tested here exactly as PfParser::operator+= does (:226-245): the k-mer
-    // of window i < w sees the w 'A's that end shard r as zeros.  Piece 0 = tail + head[0..t_1], piece j = the phrase that
-    // ends at trigger t_{j+1} (it starts w-1 characters before t_j: in the 'A' pad for t_j < w-1), the last piece ends where
-    // the head ends.
+    // Junction phrases.  PfParser::operator+= (pfparser.hpp:194-263) pops the last phrase of the left operand, strips its w Dollars and
+    // goes on appending the first phrase of the right operand without its Dollar (and without the left context, if the shard was
+    // parsed with one).  A shard that knew its left context has already cut its head at every trigger; a stand-alone shard could
+    // not trigger in its first w windows (pfparser.hpp:347 "pos_ > w"), so those windows are re-tested here exactly as :226-245 does:
+    // the hasher starts from w 'A's, a trigger closes the open phrase and the next one starts with the open phrase's real last
+    // w characters (:241).  The head of a shard with two or more phrases ends in a trigger window and closes the open phrase; the
+    // head of a one-phrase shard (no window of its own triggered) leaves it open for the next operand -- folding the operands one
+    // by one, as the reference does, gives the same chain.  All junction phrases are "extra" phrases: pieces[s] = the phrases
+    // closed while the head of shard s was appended, in text order; they sit between the interior phrases of shards s-1 and s.
     struct Piece { uint32_t js, je; tpos_t ye; uint8_t last; };               // span in the junction buffer, global end position, last char
     std::vector<uint8_t> junc; std::vector<std::vector<Piece>> pieces((size_t)nshards);
     std::vector<tpos_t> shift((size_t)nshards);
@@ -721,49 +726,53 @@ static int merge_shards_impl(pfp_ctx *c, int nshards, const pfp_shard_view *v, p
     const DivTest dt = make_divtest(c->p);
     const uint64_t kmask = (w == 32) ? 0ULL : ((1ULL << (2 * w)) - 1ULL);
     uint64_t extra = 0;
-    for (int r = 0; r + 1 < nshards; ++r) {
-        const uint32_t lc = (uint32_t)v[r + 1].left_context;
-        if (fr[r + 1].w0.size() < 1 + (size_t)lc + 1) return PFP_E_CORRUPT;
-        const std::vector<uint8_t> tail(fr[r].wl.begin(), fr[r].wl.end() - w);
-        const std::vector<uint8_t> head(fr[r + 1].w0.begin() + 1 + lc, fr[r + 1].w0.end());
-        std::vector<uint32_t> trig;                                            // trigger positions inside the head's first w windows
-        if (lc == 0) {
-            uint64_t kmer = 0;
-            for (uint32_t i = 0; i < w && i < head.size(); ++i) {
-                const uint8_t ch = head[i];
-                const uint64_t code = (ch == 'C') ? 1 : (ch == 'G') ? 2 : (ch == 'T' || ch == '-') ? 3 : 0;      // the text is normalised: A, N -> 0
-                kmer = ((kmer << 2) | code) & kmask;
-                if (i + 1 < head.size() && divisible(wang_hash(kmer), dt)) trig.push_back(i);   // the head's own last character ends its phrase anyway
+    if (nshards > 1) {
+        std::vector<uint8_t> cur;                                              // the open phrase
+        if (v[0].m == 1) cur.assign(fr[0].w0.begin(), fr[0].w0.end() - w);     // Dollar + text of shard 0 (its w Dollars stripped, :211-214)
+        else cur.assign(fr[0].wl.begin(), fr[0].wl.end() - w);
+        for (int s = 1; s < nshards; ++s) {
+            const uint32_t lc = (uint32_t)v[s].left_context;
+            const bool one = v[s].m == 1, lastshard = s + 1 == nshards;
+            const bool closes = !one || lastshard;                             // the head ends the open phrase (a trigger window, or the end of the text)
+            if (fr[s].w0.size() < 1 + (size_t)lc + 1 + ((one && !lastshard) ? (size_t)w : 0)) return PFP_E_CORRUPT;
+            const std::vector<uint8_t> head(fr[s].w0.begin() + 1 + lc, fr[s].w0.end() - ((one && !lastshard) ? w : 0));
+            const size_t textlen = one && lastshard ? (head.size() >= (size_t)w ? head.size() - w : 0) : head.size();      // head characters that are text (not the final Dollars)
+            const tpos_t G = shift[s] + lc;                                    // global index of the head's first character
+            auto add_piece = [&](tpos_t ye) -> int {
+                if (cur.size() <= (size_t)w) return PFP_E_CORRUPT;
+                Piece pc; pc.js = (uint32_t)junc.size(); junc.insert(junc.end(), cur.begin(), cur.end()); pc.je = (uint32_t)junc.size() - 1u;
+                pc.ye = ye; pc.last = cur[cur.size() - w - 1];
+                pieces[s].push_back(pc);
+                return PFP_OK;
+            };
+            size_t from = 0;                                                   // first head character not yet appended to the open phrase
+            if (lc == 0) {
+                uint64_t kmer = 0;
+                for (uint32_t i = 0; i < w && i < textlen; ++i) {
+                    const uint8_t ch = head[i];
+                    const uint64_t code = (ch == 'C') ? 1 : (ch == 'G') ? 2 : (ch == 'T' || ch == '-') ? 3 : 0;      // the text is normalised: A, N -> 0
+                    kmer = ((kmer << 2) | code) & kmask;
+                    if (!divisible(wang_hash(kmer), dt)) continue;
+                    if (closes && (size_t)i + 1 == head.size()) continue;      // the head's own last character ends the phrase anyway
+                    cur.insert(cur.end(), head.begin() + from, head.begin() + i + 1); from = (size_t)i + 1;
+                    PFP_TRY(add_piece((tpos_t)(G + i + 1)));
+                    if (cur.size() < (size_t)w) return PFP_E_ARG;              // (the reference's phrase.erase would throw)
+                    cur.erase(cur.begin(), cur.end() - w);                     // the next phrase starts with the real last w characters, :241
+                }
             }
-        }
-        const tpos_t G = shift[r + 1] + lc;                                    // global index of the head's first character
-        auto add_piece = [&](const std::vector<uint8_t> &bytes, tpos_t ye) {
-            Piece pc; pc.js = (uint32_t)junc.size(); junc.insert(junc.end(), bytes.begin(), bytes.end()); pc.je = (uint32_t)junc.size() - 1u;
-            pc.ye = ye; pc.last = bytes.size() > (size_t)w ? bytes[bytes.size() - w - 1] : (uint8_t)Dollar;
-            pieces[r].push_back(pc);
-        };
-        uint32_t from = 0;                                                     // first head character of the current piece
-        std::vector<uint8_t> cur(tail);
-        for (size_t k = 0; k <= trig.size(); ++k) {
-            const uint32_t to = k < trig.size() ? trig[k] : (uint32_t)head.size() - 1u;      // last head character of the piece
-            cur.insert(cur.end(), head.begin() + from, head.begin() + to + 1);
-            add_piece(cur, (tpos_t)(G + to + 1));
-            if (k < trig.size()) {   // the next phrase starts w - 1 characters before the trigger: 'A's of the pad, then head characters
-                cur.clear();
-                const uint32_t t = trig[k];
-                if (t + 1 < w) cur.assign((size_t)(w - 1 - t), (uint8_t)'A');
-                const uint32_t hs = t + 1 >= w ? t + 1 - w : 0;
-                cur.insert(cur.end(), head.begin() + hs, head.begin() + t + 1);
-                from = t + 1;
+            cur.insert(cur.end(), head.begin() + from, head.end());
+            if (closes) {
+                PFP_TRY(add_piece((tpos_t)(G + head.size())));
+                if (!lastshard) cur.assign(fr[s].wl.begin(), fr[s].wl.end() - w);      // the next open phrase: this shard's last one without its Dollars
             }
+            extra += pieces[s].size();
         }
-        extra += pieces[r].size() - 1;
     }
     if (mtot + extra > 0xFFFFFFFEULL - 64) return PFP_E_TOO_LARGE;
     mtot += extra;
     // ---- device: one buffer with all dictionaries + junction words, candidate spans
     uint8_t *U; uint32_t *cys, *cye, *cand_id;
-    const uint64_t call = ctot + extra;                                        // the shards' words + the extra junction phrases
+    const uint64_t call = ctot + extra;                                        // the shards' words + the junction phrases
     PFP_ALLOC_HI(c, U, uint8_t, dtot + junc.size() + 64);
     PFP_ALLOC_HI(c, cys, uint32_t, call); PFP_ALLOC_HI(c, cye, uint32_t, call); PFP_ALLOC_HI(c, cand_id, uint32_t, call);
     std::vector<uint32_t> ubase((size_t)nshards), coff((size_t)nshards);
@@ -771,19 +780,19 @@ static int merge_shards_impl(pfp_ctx *c, int nshards, const pfp_shard_view *v, p
     for (int r = 0; r < nshards; ++r) PFP_HIP(c, hipMemcpyAsync(U + ubase[r], v[r].d_dict, (size_t)v[r].dsize, hipMemcpyDeviceToDevice, c->stream));
     if (!junc.empty()) PFP_HIP(c, hipMemcpyAsync(U + dtot, junc.data(), junc.size(), hipMemcpyHostToDevice, c->stream));
     const uint32_t jb = (uint32_t)dtot;
-    for (int r = 0; r < nshards; ++r) {
-        // the first word of a shard r > 0 and the last word of a shard r < N-1 are fragments: both are re-pointed at piece 0 of
-        // their seam (the first word is referenced by no phrase that is kept)
-        const uint32_t f0s = r > 0 ? jb + pieces[r - 1][0].js : 0, f0e = r > 0 ? jb + pieces[r - 1][0].je : 0;
-        const uint32_t fls = r + 1 < nshards ? jb + pieces[r][0].js : 0, fle = r + 1 < nshards ? jb + pieces[r][0].je : 0;
-        PFP_LAUNCH(c, K_MISC, v[r].dwords * 12, k_merge_spans, nblocks(v[r].dwords, BLOCK), v[r].d_ws, (uint32_t)v[r].dwords, ubase[r], coff[r],
-                   fr[r].id0, f0s, f0e, fr[r].idl, fls, fle, cys, cye);
-    }
     std::vector<uint32_t> xs, xe, xlast; std::vector<tpos_t> xye; std::vector<uint32_t> xfirst((size_t)nshards + 1, 0);
-    for (int r = 0; r + 1 < nshards; ++r) {
-        xfirst[r] = (uint32_t)xs.size();
-        for (size_t k = 1; k < pieces[r].size(); ++k) { xs.push_back(jb + pieces[r][k].js); xe.push_back(jb + pieces[r][k].je); xye.push_back(pieces[r][k].ye); xlast.push_back(pieces[r][k].last); }
-        xfirst[r + 1] = (uint32_t)xs.size();
+    for (int s = 0; s < nshards; ++s) {
+        xfirst[s] = (uint32_t)xs.size();
+        for (const Piece &pc : pieces[s]) { xs.push_back(jb + pc.js); xe.push_back(jb + pc.je); xye.push_back(pc.ye); xlast.push_back(pc.last); }
+    }
+    xfirst[nshards] = (uint32_t)xs.size();
+    for (int r = 0; r < nshards; ++r) {
+        // fragment words are referenced by no phrase that is kept: they are re-pointed at the first junction phrase, so that the
+        // united dictionary holds no orphan
+        const bool f0 = r > 0 || (v[r].m == 1 && nshards > 1), fl = r + 1 < nshards && v[r].m > 1;
+        const uint32_t fs = extra ? xs[0] : 0u, fe = extra ? xe[0] : 0u;
+        PFP_LAUNCH(c, K_MISC, v[r].dwords * 12, k_merge_spans, nblocks(v[r].dwords, BLOCK), v[r].d_ws, (uint32_t)v[r].dwords, ubase[r], coff[r],
+                   f0 ? fr[r].id0 : 0xFFFFFFFFu, fs, fe, fl ? fr[r].idl : 0xFFFFFFFFu, fs, fe, cys, cye);
     }
     tpos_t *d_xye = nullptr; uint32_t *d_xlast = nullptr;
     if (extra) {
@@ -799,7 +808,7 @@ static int merge_shards_impl(pfp_ctx *c, int nshards, const pfp_shard_view *v, p
     uint64_t dwords = 0; uint32_t *rep, *occ_cand, *occw;
     PFP_TRY(dedup_strings(c, U, sp, call, dtot + junc.size(), cand_id, &dwords, &rep, &occ_cand, (uint8_t *)nullptr));
     PFP_TRY(build_dictionary(c, U, sp, rep, dwords));
-    // ---- global phrase sequence
+    // ---- global phrase sequence: junction phrases closed by the head of shard r, then the interior phrases of shard r
     c->n = ntot; c->m = mtot;
     PFP_ALLOC_LO(c, c->d_pid, uint32_t, mtot); PFP_ALLOC_LO(c, c->d_ye, tpos_t, mtot); PFP_ALLOC_LO(c, c->d_last, uint8_t, mtot);
     PFP_ALLOC_HI(c, occw, uint32_t, dwords);
@@ -807,17 +816,17 @@ static int merge_shards_impl(pfp_ctx *c, int nshards, const pfp_shard_view *v, p
     {
         uint64_t goff = 0;
         for (int r = 0; r < nshards; ++r) {
-            const uint32_t j0 = r ? 1u : 0u, cnt = (uint32_t)v[r].m - j0;
-            const int hj = r + 1 < nshards;
-            const tpos_t jye = hj ? pieces[r][0].ye : (tpos_t)0; const uint32_t jl = hj ? pieces[r][0].last : 0u;
-            PFP_LAUNCH(c, K_MISC, cnt * 24, k_merge_phrases, nblocks(cnt, BLOCK), v[r].d_pid, v[r].d_ye, v[r].d_last, (uint32_t)v[r].m, j0, (uint32_t)goff, coff[r], shift[r],
-                       (const uint32_t *)cand_id, jye, jl, hj, c->d_pid, c->d_ye, c->d_last, occw);
-            goff += cnt;
-            if (hj && pieces[r].size() > 1) {   // the extra junction phrases of this seam follow piece 0
-                const uint32_t nx = (uint32_t)pieces[r].size() - 1u;
+            const uint32_t nx = xfirst[r + 1] - xfirst[r];
+            if (nx) {
                 PFP_LAUNCH(c, K_MISC, nx * 24, k_merge_extra, nblocks(nx, BLOCK), (const uint32_t *)cand_id + ctot + xfirst[r], (const tpos_t *)d_xye + xfirst[r], (const uint32_t *)d_xlast + xfirst[r], nx, (uint32_t)goff,
                            c->d_pid, c->d_ye, c->d_last, occw);
                 goff += nx;
+            }
+            const uint32_t cnt = (uint32_t)(ib[r] - ia[r]);
+            if (cnt) {
+                PFP_LAUNCH(c, K_MISC, cnt * 24, k_merge_phrases, nblocks(cnt, BLOCK), v[r].d_pid, v[r].d_ye, v[r].d_last, (uint32_t)ib[r], (uint32_t)ia[r], (uint32_t)goff, coff[r], shift[r],
+                           (const uint32_t *)cand_id, (tpos_t)0, 0u, 0, c->d_pid, c->d_ye, c->d_last, occw);
+                goff += cnt;
             }
         }
         if (goff != mtot) return PFP_E_CORRUPT;

@@ -99,6 +99,38 @@ def test_merge_of_standalone_shards_emu(emu_factory, mode):
     assert extra_seen, "no seam of the test inputs needed an extra junction phrase"
 
 
+def one_phrase_cases():
+    """operands with a single phrase (a record shorter than any trigger window allows: nothing of it closes a phrase) in first,
+    middle and last position, two of them in a row, every operand a single phrase, and a single operand"""
+    rng = np.random.default_rng(23)
+    big = [bytes(rng.choice(list(b"ACGT"), n).astype(np.uint8)) for n in (3000, 2000, 1500)]
+    tiny = [bytes(rng.choice(list(b"ACGT"), n).astype(np.uint8)) for n in (30, 12, 1, 0, 25)]
+    return [([big[0], tiny[0], big[1]], [[0], [1], [2]]), ([tiny[0], big[0], big[1]], [[0], [1], [2]]), ([big[0], big[1], tiny[1]], [[0], [1], [2]]),
+            ([big[0], tiny[0], tiny[1], tiny[2], big[1], tiny[3]], [[0], [1], [2], [3], [4], [5]]), ([tiny[0], tiny[1], tiny[4]], [[0], [1], [2]]),
+            ([tiny[4], tiny[3], big[2]], [[0], [1], [2]]), ([big[0], big[1]], [[0, 1]]), ([tiny[0]], [[0]])]
+
+
+def check_one_phrase_operands(factory, modes):
+    import pfbwt_hip
+    for seqs, shards in one_phrase_cases():
+        for w, p in ((10, 100), (4, 3)):
+            ref = oracle_run(seqs, w=w, p=p, U=8)
+            parts = [int(oracle_run([seqs[i] for i in g], w=w, p=p, U=8)["m"]) for g in shards]
+            for mode in modes:
+                if int(ref["m"]) < 2:      # "only one dict word total" (pfparser.hpp:390-392): the merge itself must still succeed
+                    with pytest.raises(pfbwt_hip.PfpError) as e:
+                        sharded_single_process(factory, seqs, shards, w, p, 8, mode=mode)
+                    assert e.value.status == pfbwt_hip.E_ONE_WORD, (mode, w, p, parts)
+                    continue
+                assert compare(sharded_single_process(factory, seqs, shards, w, p, 8, mode=mode), ref, 8) == [], (mode, w, p, parts)
+
+
+def test_merge_with_one_phrase_operands_emu(emu_factory):
+    """ADVICE r2 (merge_pfp.cpp:88): an operand whose parse is ONE phrase is head and tail fragment of its seams at once; the
+    reference folds it into the open phrase (PfParser::operator+=, pfparser.hpp:194-263) and so does pfp_merge_shards"""
+    check_one_phrase_operands(emu_factory, ("standalone", "loaded", "context"))
+
+
 WORKER = r'''
 import os, sys, numpy as np, torch, torch.distributed as dist
 sys.path.insert(0, os.path.join(sys.argv[1], "tests")); sys.path.insert(0, os.path.join(sys.argv[1], "pfbwt-f_amd", "python"))
@@ -250,6 +282,11 @@ def test_merge_of_standalone_shards_gpu(gpu_ctx_factory, mode):
     seqs = synth(9, 300000, 6, (50000, 40000, 200000, 500))
     ref = oracle_run(seqs, w=10, p=100, U=4)
     assert compare(sharded_single_process(gpu_ctx_factory, seqs, [[0, 1], [2, 3], [4, 5]], 10, 100, 4, mode=mode), ref, 4) == []
+
+
+@pytest.mark.gpu
+def test_merge_with_one_phrase_operands_gpu(gpu_ctx_factory):
+    check_one_phrase_operands(gpu_ctx_factory, ("standalone", "loaded", "context"))
 
 
 NCCL_WORKER = r'''
