@@ -22,6 +22,13 @@ int pfp_profile_get(pfp_ctx *ctx, int idx, const char **name, uint64_t *launches
 /* wall-clock milliseconds of the last call of each stage (host timer around a stream sync):
  * [0] parse_finalize [1] parse_bwt [2] bwt_build */
 int pfp_stage_ms(pfp_ctx *ctx, double out[3]);
+/* Route and tuning switches of ONE context (tests force the routes that only huge inputs take; A/B measurements):
+ *   verbose, seg_grid, seg_stage, sort_k (1 | 3), sort_no_table, class_sort_maxrange, dedup_table_log2, no_trigger_table,
+ *   emit_chunk_rows, fill_subs, sample_cap (< 0: none), no_runaware, big_group_members (< 0: never), force_wide_rows.
+ * Returns PFP_E_ARG for an unknown key.  In a process started with PFP_TEST_HOOKS=1 pfp_create presets a new context from the
+ * environment variables PFP_<KEY IN UPPER CASE>; without PFP_TEST_HOOKS=1 the environment is ignored (PFP_VERBOSE excepted,
+ * which only prints). */
+int pfp_debug_set(pfp_ctx *ctx, const char *key, long long value);
 /* development aid: sorts n pseudo-random (key, value) pairs with `bits` significant key bits, returns the best
  * wall time of `reps` runs and the number of out-of-order neighbours (must be 0) */
 int pfp_debug_sort(pfp_ctx *ctx, uint64_t n, int bits, int reps, double *ms_out, uint32_t *unsorted_pairs);

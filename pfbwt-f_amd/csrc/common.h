@@ -61,6 +61,26 @@ struct Arena {
     void release_lo(size_t m) { lo = m; }
 };
 
+// Route and tuning switches of a context.  The defaults are the product's; tests and A/B measurements change them with
+// pfp_debug_set (include/pfbwt_hip_dev.h) or -- only in a process started with PFP_TEST_HOOKS=1 -- through PFP_<NAME>
+// environment variables that pfp_create reads into the new context.  Nothing here is latched per process.
+struct Tunables {
+    int verbose = 0;                   // PFP_VERBOSE (diagnostics on stderr; honoured without PFP_TEST_HOOKS: it changes no route)
+    int seg_grid = 768;                // workgroups per pass of the global radix sort (3 per CU of a 256-CU device)
+    int seg_stage = 1;                 // global radix scatter staged through LDS
+    int sort_k = 0;                    // 1: plain doubling in every refinement round, 3: three ranks in every round but the run round
+    int sort_no_table = 0;             // the K = 3 rounds follow the chains themselves
+    uint32_t class_sort_maxrange = 0;  // smaller LDS class-sort ranges (reaches the large-class route on small inputs)
+    int dedup_table_log2 = 0;          // a first phrase table that overflows
+    int no_trigger_table = 0;          // trigger test by hashing every window
+    uint64_t emit_chunk_rows = 1ULL << 30;
+    uint32_t fill_subs = 2;            // super-tiles (4 x 4096 rows) per workgroup of k_fill
+    uint64_t sample_cap = ~0ULL;       // cap of the one-pass run-sample arrays (forces the two-pass fallback)
+    int no_runaware = 0;               // -r with every row enumerated, as with a full SA
+    long big_group_members = -2;       // -2: BIG_GROUP_MEMBERS (emit.h); < 0 otherwise: never take the sort route
+    int force_wide_rows = 0;           // 64-bit row counters on small texts
+};
+
 } // namespace pfp
 
 struct pfp_ctx {
@@ -110,6 +130,7 @@ struct pfp_ctx {
     // --- ingest: pageable host memory goes through two pinned staging buffers, so that the host-side copy of chunk
     //     k + 1 overlaps the DMA of chunk k (pinned sources are copied directly)
     uint8_t *hstage[2] = {nullptr, nullptr}; hipEvent_t hstage_ev[2] = {nullptr, nullptr}; bool hstage_used[2] = {false, false};
+    pfp::Tunables tun;
     uint64_t hash_seed = 0x9E3779B97F4A7C15ULL;
     uint32_t *d_trigtab = nullptr;      // w <= 10: one bit per k-mer, "wang_hash(kmer) % p == 0" (128 KiB for w = 10; lives in LDS during the trigger scan)
 };

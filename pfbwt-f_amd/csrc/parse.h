@@ -59,13 +59,7 @@ __device__ __forceinline__ uint32_t ntoa_code(uint32_t c)
 // 8-entry byte table looked up for four bytes at once: byte i of the result = byte (sel.byte[i] & 7) of {hi, lo} (v_perm_b32)
 __device__ __forceinline__ uint32_t lut8x4(uint32_t hi, uint32_t lo, uint32_t sel)
 {
-#if defined(__HIP_DEVICE_COMPILE__)
     return __builtin_amdgcn_perm(hi, lo, sel);
-#else
-    const uint64_t tbl = ((uint64_t)hi << 32) | lo; uint32_t r = 0;
-    for (int i = 0; i < 4; ++i) r |= (uint32_t)((tbl >> (8 * ((sel >> (8 * i)) & 7))) & 0xff) << (8 * i);
-    return r;
-#endif
 }
 // Four bases at once (norm_base + ntoa_code of every byte, 4-way SWAR; ~9 instead of ~35 instructions per base -- the
 // scan was bound by this, not by the hash).  (c >> 1) & 7 is a perfect hash of the valid symbols, either case:

@@ -68,9 +68,49 @@ static void reset_results(pfp_ctx *c)
     c->arena.reset();
 }
 
+// ---- route / tuning switches (pfbwt_hip_dev.h) -----------------------------------------------------
+static const char *const tunable_names[] = {"verbose", "seg_grid", "seg_stage", "sort_k", "sort_no_table", "class_sort_maxrange", "dedup_table_log2", "no_trigger_table",
+                                            "emit_chunk_rows", "fill_subs", "sample_cap", "no_runaware", "big_group_members", "force_wide_rows"};
+static int set_tunable(pfp_ctx *c, const char *key, long long v)
+{
+    Tunables &t = c->tun;
+    if (!strcmp(key, "verbose")) t.verbose = (int)v;
+    else if (!strcmp(key, "seg_grid")) t.seg_grid = (int)v;
+    else if (!strcmp(key, "seg_stage")) t.seg_stage = (int)v;
+    else if (!strcmp(key, "sort_k")) t.sort_k = (int)v;
+    else if (!strcmp(key, "sort_no_table")) t.sort_no_table = (int)v;
+    else if (!strcmp(key, "class_sort_maxrange")) t.class_sort_maxrange = (uint32_t)v;
+    else if (!strcmp(key, "dedup_table_log2")) t.dedup_table_log2 = (int)v;
+    else if (!strcmp(key, "no_trigger_table")) t.no_trigger_table = (int)v;
+    else if (!strcmp(key, "emit_chunk_rows")) t.emit_chunk_rows = v > 0 ? (uint64_t)v : (1ULL << 30);
+    else if (!strcmp(key, "fill_subs")) t.fill_subs = (uint32_t)v;
+    else if (!strcmp(key, "sample_cap")) t.sample_cap = v < 0 ? ~0ULL : (uint64_t)v;
+    else if (!strcmp(key, "no_runaware")) t.no_runaware = (int)v;
+    else if (!strcmp(key, "big_group_members")) t.big_group_members = (long)v;
+    else if (!strcmp(key, "force_wide_rows")) t.force_wide_rows = (int)v;
+    else return PFP_E_ARG;
+    return PFP_OK;
+}
+// PFP_VERBOSE is honoured always (it changes no route); every other PFP_<NAME> only in a process started with PFP_TEST_HOOKS=1,
+// so that a user's environment cannot silently change routes or tile sizes
+static void load_tunables_from_env(pfp_ctx *c)
+{
+    if (getenv("PFP_VERBOSE")) c->tun.verbose = 1;
+    const char *hooks = getenv("PFP_TEST_HOOKS");
+    if (!hooks || strcmp(hooks, "1")) return;
+    for (const char *name : tunable_names) {
+        char env[64] = "PFP_"; size_t k = 4;
+        for (const char *q = name; *q && k + 1 < sizeof env; ++q) env[k++] = (char)((*q >= 'a' && *q <= 'z') ? *q - 32 : *q);
+        env[k] = 0;
+        const char *e = getenv(env);
+        if (e) (void)set_tunable(c, name, *e ? atoll(e) : 1LL);
+    }
+}
+
 extern "C" {
 
 const char *pfp_backend(void) { return PFP_BACKEND_NAME; }
+int pfp_debug_set(pfp_ctx *c, const char *key, long long value) { return (c && key) ? set_tunable(c, key, value) : PFP_E_ARG; }
 
 const char *pfp_strerror(int s)
 {
@@ -100,6 +140,7 @@ pfp_ctx *pfp_create(int w, uint64_t p, unsigned flags, int device, uint64_t work
         else {
             c = new pfp_ctx();
             c->w = w; c->p = p; c->flags = flags; c->device = device; c->arena_request = (size_t)workspace_bytes;
+            load_tunables_from_env(c);
             if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; c = nullptr; st = PFP_E_HIP; }
         }
     }
@@ -321,7 +362,7 @@ static int dedup_strings(pfp_ctx *c, const uint8_t *Y, Spans sp, uint64_t m, uin
     PFP_ALLOC_HI(c, d_u32, uint32_t, 8);
     PFP_ALLOC_HI(c, slotof, uint32_t, m);
     const unsigned gm = nblocks(m, BLOCK);
-    static const int force_small = getenv("PFP_DEDUP_TABLE_LOG2") ? atoi(getenv("PFP_DEDUP_TABLE_LOG2")) : 0;      // tests: a first table that overflows
+    const int force_small = c->tun.dedup_table_log2;      // tests: a first table that overflows
     DedupTable t; uint32_t nd = 0;
     for (int attempt = 0;; ++attempt) {
         if (attempt == 2) return PFP_E_CORRUPT;
@@ -351,8 +392,7 @@ static int dedup_strings(pfp_ctx *c, const uint8_t *Y, Spans sp, uint64_t m, uin
             PFP_HIP(c, hipStreamSynchronize(c->stream));
         }
         if (!h3[1]) { nd = h3[0]; break; }
-        static const bool verbose = getenv("PFP_VERBOSE") != nullptr;
-        if (verbose) fprintf(stderr, "[pfbwt_hip] phrase table of 2^%d entries overflowed (%u distinct so far, state %u): retry\n", lg, h3[0], h3[1]);
+        if (c->tun.verbose) fprintf(stderr, "[pfbwt_hip] phrase table of 2^%d entries overflowed (%u distinct so far, state %u): retry\n", lg, h3[0], h3[1]);
         c->arena.release_hi(mk);
     }
     // ids in the order of the hashes of the distinct strings
@@ -479,7 +519,7 @@ static int parse_finalize_impl(pfp_ctx *c, pfp_parse_sizes *out, bool shard_only
     PFP_HIP(c, hipMemsetAsync(d_err, 0xff, 8, c->stream));
     PFP_HIP(c, hipMemsetAsync(d_u32, 0, 32, c->stream));
     const uint64_t kmask = (w == 32) ? 0ULL : ((1ULL << (2 * w)) - 1ULL);   // hash.hpp:26 (w == 32: observed x86 value)
-    static const bool no_trigtab = getenv("PFP_NO_TRIGGER_TABLE") != nullptr;      // tests / measurements: the hash evaluated per base
+    const bool no_trigtab = c->tun.no_trigger_table != 0;      // tests / measurements: the hash evaluated per base
     if (w <= TS_MAX_W && !no_trigtab) {
         const uint32_t tabwords = (1u << (2 * w)) >= 32u ? (1u << (2 * w)) / 32u : 1u;
         if (!c->d_trigtab) {      // w and p are fixed for the life of a context
@@ -1069,8 +1109,7 @@ template <typename SAT, typename EBT> static int emit_and_sample(pfp_ctx *c, Emi
     const uint64_t lead = s0 ? 1 : 0;                     // the row in front of the slice (run detection needs its BWT byte)
     const uint64_t nrows = s1 - s0;
     c->slice_begin = s0; c->slice_rows = nrows;
-    static uint64_t chunk_rows = 0;
-    if (!chunk_rows) { const char *e = getenv("PFP_EMIT_CHUNK_ROWS"); chunk_rows = (e && atoll(e) > 0) ? (uint64_t)atoll(e) : (1ULL << 30); }
+    const uint64_t chunk_rows = c->tun.emit_chunk_rows ? c->tun.emit_chunk_rows : (1ULL << 30);
     const uint64_t nchunks = (nrows + chunk_rows - 1) / chunk_rows;
     const bool windowed = nslices > 1 || nchunks > 1;
     const bool runaware = ea.special != 0;
@@ -1112,7 +1151,7 @@ template <typename SAT, typename EBT> static int emit_and_sample(pfp_ctx *c, Emi
     }
     ea.big_keys = bk0; ea.big_vals = bv0; ea.big_count = d_b + 4; ea.big_cap = ea.big_total;
     const BitRange big_ranges[2] = {{0, bits_for(c->nrows)}, {32, 32 + bits_for(ea.dsize)}};
-    static const uint32_t fill_subs_env = getenv("PFP_FILL_SUBS") ? (uint32_t)atoi(getenv("PFP_FILL_SUBS")) : 2u;     // super-tiles (4 x 4096 rows) per workgroup
+    const uint32_t fill_subs_env = c->tun.fill_subs;     // super-tiles (4 x 4096 rows) per workgroup
     const uint32_t fill_subs = fill_subs_env < 1u ? 1u : fill_subs_env > FILL_MAX_SUBS ? FILL_MAX_SUBS : fill_subs_env;
     // emits the rows whose output position lies in [cs - cl, ce); bwt_at / sa_at point at that first position; q_at receives
     // the parse row of every row written (all rows) resp. of every special row enumerated (run-aware)
@@ -1167,7 +1206,7 @@ template <typename SAT, typename EBT> static int emit_and_sample(pfp_ctx *c, Emi
         const size_t freeb = c->arena.hi > c->arena.lo + ((size_t)256 << 20) ? c->arena.hi - c->arena.lo - ((size_t)256 << 20) : 0;
         uint64_t cap = freeb / (4 * sizeof(SAT));
         if (cap > nrows) cap = nrows;
-        if (const char *e = getenv("PFP_SAMPLE_CAP")) { const uint64_t lim = (uint64_t)atoll(e); if (lim < cap) cap = lim; }   // tests: force the fallback
+        if (c->tun.sample_cap < cap) cap = c->tun.sample_cap;   // tests: force the fallback
         SAT *samp = nullptr;
         if (cap) PFP_ALLOC_LO(c, samp, SAT, 4 * cap + 4);
         SAT *ssa = samp, *esa = samp ? samp + 2 * cap : nullptr;
@@ -1254,7 +1293,7 @@ template <typename SAT, typename EBT> static int emit_and_sample(pfp_ctx *c, Emi
 template <typename EBT> static int emit_stage(pfp_ctx *c, EmitArgs ea, int want_sa, int want_rssa, int slice, int nslices)
 {
     const uint64_t dsize = c->dsize;
-    static const bool no_runaware = getenv("PFP_NO_RUNAWARE") != nullptr;      // tests / measurements: every row enumerated, as with a full SA
+    const bool no_runaware = c->tun.no_runaware != 0;      // tests / measurements: every row enumerated, as with a full SA
     const bool runaware = !want_sa && !no_runaware;
     EBT *cnt, *EB, *d_tot, *cnt2 = nullptr; unsigned long long *d_hard;
     PFP_ALLOC_HI(c, cnt, EBT, dsize); PFP_ALLOC_HI(c, EB, EBT, dsize); PFP_ALLOC_HI(c, d_hard, unsigned long long, 2); PFP_ALLOC_HI(c, d_tot, EBT, 2);
@@ -1272,7 +1311,7 @@ template <typename EBT> static int emit_stage(pfp_ctx *c, EmitArgs ea, int want_
     ea.s_g0 = s_g0; ea.gk = gk; ea.cnt = cnt; ea.gqf = gqf; ea.gql = gql;
     uint4 *sinfo; PFP_ALLOC_HI(c, sinfo, uint4, dsize); ea.sinfo = sinfo;
     PFP_LAUNCH(c, K_EMIT_COUNT, dsize * (30 + sizeof(EBT)), (k_emit_slots<EBT>), nblocks(dsize, BLOCK), ea, cnt, d_hard, (uint32_t *)ea.s_sl, (uint32_t *)ea.s_fb, (uint8_t *)ea.s_fl, (uint8_t *)ea.s_pc, s_g0, gk, gfl, gnu);
-    static const long big_members = getenv("PFP_BIG_GROUP_MEMBERS") ? atol(getenv("PFP_BIG_GROUP_MEMBERS")) : (long)BIG_GROUP_MEMBERS;   // < 0: never
+    const long big_members = c->tun.big_group_members == -2 ? (long)BIG_GROUP_MEMBERS : c->tun.big_group_members;   // < 0: never
     PFP_LAUNCH(c, K_EMIT_COUNT, dsize * 14, (k_big_mark<EBT>), nblocks(dsize, BLOCK), (const EBT *)cnt, (const uint32_t *)s_g0, (const uint32_t *)gk, (const uint8_t *)gfl, (const uint8_t *)gnu, (const uint32_t *)ea.s_fb, ea.ilist, dsize,
                big_members >= 0 ? (uint32_t)big_members : 0xFFFFFFFFu, runaware ? 1 : 0, (uint8_t *)ea.s_fl, sinfo, cnt2, gqf, gql, d_hard + 1);
     PFP_TRY((device_scan<EBT, 0>(c, cnt, EB, dsize, d_tot)));
@@ -1314,8 +1353,7 @@ template <typename EBT> static int emit_stage(pfp_ctx *c, EmitArgs ea, int want_
         } else PFP_HIP(c, hipMemsetAsync(ENBc, 0, sizeof(EBT), c->stream));
         ea.ENB = ENBc; ea.elist = spl; ea.cpos = cpos; ea.ecount = nsp; ea.special = 1;
     }
-    static const bool verbose = getenv("PFP_VERBOSE") != nullptr;
-    if (verbose) {
+    if (c->tun.verbose) {
         unsigned long long *d_hist, hist[64]; PFP_ALLOC_HI(c, d_hist, unsigned long long, 64);
         PFP_HIP(c, hipMemsetAsync(d_hist, 0, 512, c->stream));
         PFP_LAUNCH(c, K_MISC, dsize * 20, (k_group_stats<EBT>), nblocks(dsize, BLOCK), (const EBT *)cnt, (const EBT *)EB, (const uint32_t *)s_g0, (const uint32_t *)gk, (const uint8_t *)ea.s_fl, dsize, (uint64_t)tot, d_hist);
@@ -1382,7 +1420,7 @@ static int bwt_build_body(pfp_ctx *c, int want_sa, int want_rssa, int slice, int
     ea.EB = nullptr; ea.s_sl = s_sl; ea.s_fb = s_fb; ea.s_fl = s_fl; ea.s_pc = s_pc; ea.nout = 0; ea.n = 0; ea.e0 = ea.e1 = ea.w0 = ea.w1 = 0;
     c->have_sa = want_sa != 0; c->have_rssa = want_rssa != 0;
     // 64-bit row counters when the text may have 2^32 - 1 positions or more (n unknown after pfp_bwt_load without a hint)
-    static const bool force_wide = getenv("PFP_FORCE_WIDE_ROWS") != nullptr;
+    const bool force_wide = c->tun.force_wide_rows != 0;
     const bool wide = force_wide || c->n == 0 || c->n + 2 >= 0xFFFFFFFFULL;
     int rc = wide ? emit_stage<uint64_t>(c, ea, want_sa, want_rssa, slice, nslices) : emit_stage<uint32_t>(c, ea, want_sa, want_rssa, slice, nslices);
     if (rc != PFP_OK) return rc;

@@ -427,10 +427,8 @@ template <typename K> inline int radix_sort_pairs(pfp_ctx *c, K *k0, uint32_t *v
     }
     const size_t mk = c->arena.mark_hi();
     const uint32_t ntiles = nblocks(n, RS_TILE);
-    static int seg_grid = 0;   // workgroups per pass (segments); default 3 per CU of a 256-CU device
-    if (!seg_grid) { const char *e = getenv("PFP_SEG_GRID"); seg_grid = (e && atoi(e) > 0 && atoi(e) <= SEG_MAX_GRID) ? atoi(e) : 768; }
-    static int seg_stage = -1;
-    if (seg_stage < 0) { const char *e = getenv("PFP_SEG_STAGE"); seg_stage = e ? atoi(e) : 1; }
+    const int seg_grid = (c->tun.seg_grid > 0 && c->tun.seg_grid <= SEG_MAX_GRID) ? c->tun.seg_grid : 768;   // workgroups per pass (segments)
+    const int seg_stage = c->tun.seg_stage;
     const uint32_t tps = (ntiles + (uint32_t)seg_grid - 1) / (uint32_t)seg_grid;   // tiles per segment
     const uint32_t G = (ntiles + tps - 1) / tps;
     uint32_t *seg; unsigned long long *total;

@@ -612,8 +612,8 @@ template <bool DICT> inline int suffix_sort_doubling(pfp_ctx *c, uint64_t N, uin
     uint32_t na = 0; PFP_TRY(d2h_u32(c, b.d_cnt, &na));
     int rounds = 1;
     const int rbits = bits_for(N);
-    static const bool verbose = getenv("PFP_VERBOSE") != nullptr;
-    static const int force_k = getenv("PFP_SORT_K") ? atoi(getenv("PFP_SORT_K")) : 0;      // tests / A-B runs: 1 = plain doubling in every round, 3 = three ranks in every round but the run round
+    const bool verbose = c->tun.verbose != 0;
+    const int force_k = c->tun.sort_k;      // tests / A-B runs: 1 = plain doubling in every round, 3 = three ranks in every round but the run round
     if (na > 0) {
         // active lists (two sets, swapped every round) and the per-round outputs; every later list is shorter than the first
         for (int t = 0; t < 2; ++t) { PFP_ALLOC_HI(c, b.aslot[t], uint32_t, na); PFP_ALLOC_HI(c, b.arnk[t], uint32_t, na); if (DICT) PFP_ALLOC_HI(c, b.ajmp[t], uint32_t, na); }
@@ -630,10 +630,10 @@ template <bool DICT> inline int suffix_sort_doubling(pfp_ctx *c, uint64_t N, uin
         }
         // k0 / v0 / k1 / v1 are free from here on: scratch of the large-class route
         b.k0 = k0; b.k1 = k1; b.v0 = v0; b.v1 = v1;
-        static const bool no_table = getenv("PFP_SORT_NO_TABLE") != nullptr;                   // tests: the K = 3 rounds follow the chains themselves
+        const bool no_table = c->tun.sort_no_table != 0;                   // tests: the K = 3 rounds follow the chains themselves
         if (force_k != 1 && !no_table && (uint64_t)na * 8 > N && c->arena.hi - c->arena.lo > 16 * (size_t)N + 40 * (size_t)na + ((size_t)1 << 20))
             PFP_ALLOC_HI(c, b.T, uint4, N);          // optional: without room for it the K = 3 rounds follow the chains themselves
-        static const uint32_t max_range_env = getenv("PFP_CLASS_SORT_MAXRANGE") ? (uint32_t)atoi(getenv("PFP_CLASS_SORT_MAXRANGE")) : 0u;   // tests: smaller, to reach the large-class route
+        const uint32_t max_range_env = c->tun.class_sort_maxrange;   // tests: smaller, to reach the large-class route
         int cur = 0; uint64_t h = h0;
         uint32_t na_before = 0;                 // length of the list the previous round started from (0: no previous round)
         while (na > 0) {

@@ -92,6 +92,7 @@ def load_library(path=None):
     L.pfp_profile_select.argtypes = [vp, C.c_char_p]
     L.pfp_profile_get.argtypes = [vp, i32, C.POINTER(C.c_char_p), C.POINTER(u64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.pfp_stage_ms.argtypes = [vp, C.POINTER(C.c_double)]
+    L.pfp_debug_set.argtypes = [vp, C.c_char_p, C.c_longlong]
     _libs[path] = L
     return L
 
@@ -115,6 +116,11 @@ class PfpContext:
             raise PfpError(st.value, self.L.pfp_strerror(st.value).decode())
         self.sizes = None
         self.bsizes = None
+
+    def debug_set(self, **switches):
+        """route / tuning switches of this context (include/pfbwt_hip_dev.h: pfp_debug_set), e.g. force_wide_rows=1"""
+        for k, v in switches.items():
+            self._check(self.L.pfp_debug_set(self.h, k.encode(), int(v)))
 
     def close(self):
         if getattr(self, "h", None):

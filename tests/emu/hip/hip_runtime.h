@@ -214,6 +214,13 @@ template <typename T> static inline T atomicCAS(T *p, T c, T v) { T o = *p; if (
 template <typename T> static inline T __hip_atomic_load(const T *p, int, int) { return *p; }
 template <typename T, typename V> static inline void __hip_atomic_store(T *p, V v, int, int) { *p = (T)v; }
 static inline void __builtin_amdgcn_s_sleep(int) {}
+// v_perm_b32 with selectors 0..7: byte i of the result = byte (sel.byte[i] & 7) of the 64-bit value {hi, lo}
+static inline unsigned __builtin_amdgcn_perm(unsigned hi, unsigned lo, unsigned sel)
+{
+    const unsigned long long tbl = ((unsigned long long)hi << 32) | lo; unsigned r = 0;
+    for (int i = 0; i < 4; ++i) r |= (unsigned)((tbl >> (8 * ((sel >> (8 * i)) & 7))) & 0xff) << (8 * i);
+    return r;
+}
 
 // ---- host runtime ---------------------------------------------------------------------------
 static inline hipError_t hipMalloc(void **p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }

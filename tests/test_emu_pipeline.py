@@ -173,7 +173,7 @@ def test_emu_wide_rows_and_chunked_emission(emu_factory, env):
     doubling rounds, forced on small inputs: every output combination must still equal the oracle."""
     import sys
     from pfp_testlib import ROOT
-    e = dict(os.environ); e.update(env)
+    e = dict(os.environ); e.update(env); e["PFP_TEST_HOOKS"] = "1"
     pr = subprocess.run([sys.executable, "-c", VARIANT_CODE, ROOT], env=e, capture_output=True, text=True, timeout=900)
     assert pr.returncode == 0 and "variant ok" in pr.stdout, pr.stdout[-1500:] + pr.stderr[-3000:]
 

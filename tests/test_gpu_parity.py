@@ -188,7 +188,7 @@ def test_doubling_round_sort_routes(env):
     plain doubling), classes too large for a tile collected and radix-sorted (forced by a smaller range limit: some of
     the pairs, nearly all of them) -- every route must give the oracle's arrays"""
     import subprocess, sys
-    e = dict(os.environ); e.update(env); e["PFP_VERBOSE"] = "1"
+    e = dict(os.environ); e.update(env); e["PFP_VERBOSE"] = "1"; e["PFP_TEST_HOOKS"] = "1"
     pr = subprocess.run([sys.executable, "-c", CLASS_SORT_CODE, ROOT], env=e, capture_output=True, text=True, timeout=900)
     assert pr.returncode == 0 and "class sort variant ok" in pr.stdout, pr.stdout[-1500:] + pr.stderr[-3000:]
     lines = [l for l in pr.stderr.splitlines() if "class sort:" in l]

@@ -64,6 +64,6 @@ ENVS = [
 
 @pytest.mark.parametrize("env", ENVS, ids=lambda e: ",".join("%s=%s" % (k.replace("PFP_", ""), v) for k, v in e.items()))
 def test_forced_emission_routes_gpu(env):
-    e = dict(os.environ); e.update(env)
+    e = dict(os.environ); e.update(env); e["PFP_TEST_HOOKS"] = "1"      # the engine reads PFP_* switches only under PFP_TEST_HOOKS=1
     pr = subprocess.run([sys.executable, "-c", ROUTE_CODE, ROOT], env=e, capture_output=True, text=True, timeout=1500)
     assert pr.returncode == 0 and "routes ok" in pr.stdout, pr.stdout[-1500:] + pr.stderr[-3000:]

@@ -20,6 +20,36 @@ int main(int argc, char **argv)
     double t0 = now_ms();
     CK(hipSetDevice(0)); CK(hipFree(0));
     printf("runtime init %.1f ms\n", now_ms() - t0);
+    if (argc >= 3 && !strcmp(argv[1], "fresh")) {      // a fresh process takes <GB> at once (hipMalloc) or in 2 GiB VMM chunks ("freshvmm"), holds it <hold> s, exits
+        const size_t g = (size_t)atoll(argv[2]);
+        void *p = nullptr; t0 = now_ms(); hipError_t e = hipMalloc(&p, g * GB);
+        printf("fresh process: hipMalloc %zu GB: %s %.1f ms\n", g, hipGetErrorString(e), now_ms() - t0); fflush(stdout);
+        if (argc >= 4 && e == hipSuccess) { t0 = now_ms(); CK(hipFree(p)); printf("  hipFree %.1f ms\n", now_ms() - t0); void *q = nullptr; t0 = now_ms(); e = hipMalloc(&q, (size_t)atoll(argv[3]) * GB); printf("  then hipMalloc %s GB: %s %.1f ms\n", argv[3], hipGetErrorString(e), now_ms() - t0); }
+        return 0;
+    }
+    if (argc >= 3 && !strcmp(argv[1], "freshvmm")) {
+        const size_t g = (size_t)atoll(argv[2]);
+        hipMemAllocationProp prop; memset(&prop, 0, sizeof prop);
+        prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = 0;
+        void *va = nullptr; CK(hipMemAddressReserve(&va, 512 * GB, 0, nullptr, 0));
+        hipMemAccessDesc ad; memset(&ad, 0, sizeof ad); ad.location = prop.location; ad.flags = hipMemAccessFlagsProtReadWrite;
+        double tall = now_ms(), worst = 0; std::vector<hipMemGenericAllocationHandle_t> hs;
+        for (size_t i = 0; i < g / 2; ++i) {
+            hipMemGenericAllocationHandle_t h; t0 = now_ms();
+            if (hipMemCreate(&h, 2 * GB, &prop, 0) != hipSuccess) { printf("create failed at chunk %zu\n", i); break; }
+            CK(hipMemMap((char *)va + i * 2 * GB, 2 * GB, 0, h, 0)); CK(hipMemSetAccess((char *)va + i * 2 * GB, 2 * GB, &ad, 1));
+            const double t = now_ms() - t0; if (t > worst) worst = t; if (t > 50) printf("  chunk %zu: %.1f ms\n", i, t);
+            hs.push_back(h);
+        }
+        printf("fresh process: %zu VMM chunks of 2 GB: %.1f ms total, worst chunk %.1f ms\n", hs.size(), now_ms() - tall, worst); fflush(stdout);
+        hipStream_t s; CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        t0 = now_ms(); k_touch<<<4096, 256, 0, s>>>((uint4 *)va, hs.size() * 2 * GB / 16); CK(hipStreamSynchronize(s)); printf("  touch all: %.1f ms\n", now_ms() - t0);
+        // move the physical chunk of slot 0 to the first unmapped slot (what a two-ended arena does instead of freeing)
+        t0 = now_ms(); CK(hipMemUnmap(va, 2 * GB)); CK(hipMemMap((char *)va + hs.size() * 2 * GB, 2 * GB, 0, hs[0], 0)); CK(hipMemSetAccess((char *)va + hs.size() * 2 * GB, 2 * GB, &ad, 1));
+        printf("  remap of one chunk: %.2f ms\n", now_ms() - t0);
+        t0 = now_ms(); k_touch<<<4096, 256, 0, s>>>((uint4 *)((char *)va + hs.size() * 2 * GB), 2 * GB / 16); CK(hipStreamSynchronize(s)); printf("  touch remapped: %.1f ms\n", now_ms() - t0);
+        return 0;
+    }
     size_t fr = 0, tot = 0; CK(hipMemGetInfo(&fr, &tot)); printf("free %.1f GB of %.1f GB\n", fr / 1e9, tot / 1e9);
     hipStream_t s; CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     // 1. hipMalloc by size, cold then again

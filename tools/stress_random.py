@@ -15,7 +15,7 @@ ap.add_argument("--medium", type=int, default=0, help="instead of the small case
 a = ap.parse_args()
 if a.envs and not a.child:
     for e in ENVS:
-        env = dict(os.environ); env.update(e)
+        env = dict(os.environ); env.update(e); env["PFP_TEST_HOOKS"] = "1"
         t0 = time.time()
         pr = subprocess.run([sys.executable, os.path.abspath(__file__), "--seeds", str(a.seeds[0]), str(a.seeds[1]), "--count", str(a.count), "--medium", str(a.medium), "--child"] + (["--emu"] if a.emu else []), env=env, capture_output=True, text=True)
         print("%s: rc=%d %.0fs %s" % (e or "default", pr.returncode, time.time() - t0, pr.stdout.strip().splitlines()[-1] if pr.stdout.strip() else pr.stderr[-800:]), flush=True)
