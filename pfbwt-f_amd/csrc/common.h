@@ -8,6 +8,7 @@
 #include <chrono>
 #include <vector>
 #include "../../include/pfbwt_hip.h"
+#include "devmem.h"
 #include "../../include/pfbwt_hip_dev.h"
 
 namespace pfp {
@@ -36,24 +37,28 @@ static const char *const kernel_names[K_COUNT_] = {
 
 struct ProfRec { uint64_t launches = 0; double ms = 0, bytes = 0; };
 
-// Two-ended bump allocator over one hipMalloc'd slab: results of a stage live at the low end,
-// scratch at the high end (released with mark/release).
+// Two-ended bump allocator over one address range (devmem.h: physical memory is committed as the two ends advance): results
+// of a stage live at the low end, scratch at the high end (released with mark/release).
 struct Arena {
+    VmRegion vm;
     char *base = nullptr;
     size_t cap = 0, lo = 0, hi = 0, want = 0;
+    size_t peak_lo = 0, peak_hi_bytes = 0;      // high-water marks (PFP_VERBOSE)
     bool failed = false;
     void reset() { lo = 0; hi = cap; failed = false; }
     void *alloc_lo(size_t bytes)
     {
         size_t a = (lo + 255) & ~(size_t)255;
-        if (a + bytes > hi) { failed = true; want += bytes; return nullptr; }
-        lo = a + bytes; return base + a;
+        if (a + bytes > hi || !vm.commit(a, a + bytes)) { failed = true; want += bytes; return nullptr; }
+        lo = a + bytes; if (lo > peak_lo) peak_lo = lo;
+        return base + a;
     }
     void *alloc_hi(size_t bytes)
     {
         size_t b = (bytes + 255) & ~(size_t)255;
-        if (b > hi || hi - b < lo) { failed = true; want += bytes; return nullptr; }
-        hi -= b; return base + hi;
+        if (b > hi || hi - b < lo || !vm.commit(hi - b, hi)) { failed = true; want += bytes; return nullptr; }
+        hi -= b; if (cap - hi > peak_hi_bytes) peak_hi_bytes = cap - hi;
+        return base + hi;
     }
     size_t mark_hi() const { return hi; }
     void release_hi(size_t m) { hi = m; }
@@ -91,7 +96,8 @@ struct pfp_ctx {
     // error detail
     uint64_t err_pos = 0; int err_ch = 0;
     // --- text staging (device): tb = 16 guard bytes (tb[15] = Dollar) + X + w Dollars + slack
-    uint8_t *tb = nullptr; size_t tb_cap = 0; uint64_t n = 0; bool text_in_arena = false;
+    pfp::VmRegion text;          // address range of tb; committed as the text grows (never re-allocated, never copied)
+    uint8_t *tb = nullptr; size_t tb_cap = 0; uint64_t n = 0; uint64_t text_hint = 0;
     uint64_t left_ctx = 0;       // bytes of left context fed in front of this shard's text (pfp_parse_feed_left_context)
     uint64_t tb_n = 0;           // bytes of tb that hold the text of the current parse (0: none -- merged or loaded state)
     // --- parse results (device, arena low end)

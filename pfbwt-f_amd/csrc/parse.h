@@ -50,6 +50,15 @@ __global__ __launch_bounds__(BLOCK) void k_feed_batch(const uint8_t *src, uint64
     if (j == per_row - 1) for (int k = 0; k < w; ++k) dst[row * (len + (uint64_t)w) + len + k] = 'A';
 }
 
+// the w 'A's behind each of `count` records of `len` bytes that were copied in by the runtime (rows `pitch` apart)
+__global__ __launch_bounds__(BLOCK) void k_pad_rows(uint8_t *dst, uint64_t count, uint64_t len, uint64_t pitch, int w)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= count * (uint64_t)w) return;
+    const uint64_t row = i / (uint64_t)w, k = i - row * (uint64_t)w;
+    dst[row * pitch + len + k] = 'A';
+}
+
 // seq_nt4_ntoa_table, src/utils.c:139-161 (after toupper): A,N->0 C->1 G->2 T,'-'->3 else 5
 __device__ __forceinline__ uint32_t ntoa_code(uint32_t c)
 {

@@ -16,44 +16,52 @@ using namespace pfp;
 #endif
 
 // -------------------------------------------------------------------------------------------------
+// The workspace is an ADDRESS range of `want` bytes (what the stages of a text of n_hint bytes could ask for, at most 15/16 of
+// the card); HBM is committed only where the two ends of the arena really get to (csrc/devmem.h).
 static int ensure_arena(pfp_ctx *c, uint64_t n_hint)
 {
     size_t want = c->arena_request ? c->arena_request : (size_t)(96ULL * n_hint + (64ULL << 20));
     if (!c->arena_request) {   // never ask for more than the device can give (large inputs run with what there is)
         size_t fr = 0, tot = 0;
         if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
-            const size_t avail = fr + (c->arena.base ? c->arena.cap : 0);
+            const size_t avail = fr + c->arena.vm.committed;
             const size_t cap = avail - avail / 16;
             if (want > cap) want = cap;
         }
     }
     want &= ~(size_t)4095;     // both ends of the arena hand out 256-byte aligned blocks
     if (c->arena.base && c->arena.cap >= want) return PFP_OK;
-    if (c->arena.base) { PFP_HIP(c, hipStreamSynchronize(c->stream)); PFP_HIP(c, hipFree(c->arena.base)); c->arena.base = nullptr; c->arena.cap = 0; }
-    void *p = nullptr;
-    hipError_t e = hipMalloc(&p, want);
-    if (e != hipSuccess) { c->arena.want = want; (void)hipGetLastError(); return PFP_E_NOMEM; }
-    c->arena.base = (char *)p; c->arena.cap = want; c->arena.reset();
+    if (c->arena.base) { PFP_HIP(c, hipStreamSynchronize(c->stream)); c->arena.vm.destroy(); c->arena.base = nullptr; c->arena.cap = 0; }
+    if (c->arena.vm.reserve(want, c->device) != hipSuccess) { c->arena.want = want; return PFP_E_NOMEM; }
+    c->arena.base = c->arena.vm.base; c->arena.cap = want; c->arena.reset();
     return PFP_OK;
 }
 
+// The text buffer: 16 guard bytes + text + w Dollars + slack for whole trigger-scan tiles.  Its address range is reserved once
+// (text_hint bytes if the caller announced a size with pfp_parse_reserve, else what the card could hold) and committed as the
+// text grows: feeding record by record neither re-allocates nor copies.
 static int ensure_text(pfp_ctx *c, uint64_t need_n)
 {
-    // capacity: 16 guard bytes + text rounded up to whole trigger-scan tiles + w Dollars + slack
-    size_t need = 16 + (((size_t)need_n + 4095) / 4096) * 4096 + 4096 + 64;
+    const size_t need = 16 + (((size_t)need_n + 4095) / 4096) * 4096 + 4096 + 64;
     if (c->tb && c->tb_cap >= need) return PFP_OK;
-    size_t cap = c->tb_cap ? c->tb_cap : (size_t)1 << 20;
-    while (cap < need) cap *= 2;
-    if (!c->tb && need > ((size_t)1 << 30)) cap = (need + ((size_t)1 << 20)) & ~(((size_t)1 << 20) - 1);   // a large first request (batched feed) is taken as is
-    uint8_t *nb = nullptr;
-    hipError_t e = hipMalloc((void **)&nb, cap);
-    if (e != hipSuccess) { (void)hipGetLastError(); return PFP_E_NOMEM; }
-    if (c->tb) {
-        PFP_HIP(c, hipMemcpyAsync(nb, c->tb, 16 + (size_t)c->n, hipMemcpyDeviceToDevice, c->stream));
-        PFP_HIP(c, hipStreamSynchronize(c->stream));
-        PFP_HIP(c, hipFree(c->tb));
+    if (!c->text.live() || need > c->text.va_bytes) {
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); tot = (size_t)1 << 38; }
+        size_t va = c->text_hint ? (size_t)c->text_hint + (size_t)c->text_hint / 8 + ((size_t)64 << 20) : tot;
+        if (va < need) va = need + need / 4;
+        VmRegion nr;
+        if (nr.reserve(va, c->device) != hipSuccess) return PFP_E_NOMEM;
+        if (c->tb) {      // the announced size was too small: move to a larger range (the one case in which text is copied)
+            if (!nr.commit(0, 16 + (size_t)c->n)) { nr.destroy(); return PFP_E_NOMEM; }
+            PFP_HIP(c, hipMemcpyAsync(nr.base, c->tb, 16 + (size_t)c->n, hipMemcpyDeviceToDevice, c->stream));
+            PFP_HIP(c, hipStreamSynchronize(c->stream));
+            c->text.destroy();
+        }
+        c->text = nr; nr.base = nullptr;
+        c->tb = (uint8_t *)c->text.base; c->tb_cap = 0;
     }
-    c->tb = nb; c->tb_cap = cap;
+    if (!c->text.commit(0, need)) return PFP_E_NOMEM;
+    c->tb_cap = c->text.vmm ? (c->text.lo_edge < c->text.va_bytes ? c->text.lo_edge : c->text.va_bytes) : c->text.va_bytes;
     return PFP_OK;
 }
 
@@ -155,10 +163,10 @@ void pfp_destroy(pfp_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     prof_collect(c);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
-    if (c->tb) (void)hipFree(c->tb);
+    c->text.destroy();
     if (c->d_trigtab) (void)hipFree(c->d_trigtab);
     for (int k = 0; k < 2; ++k) { if (c->hstage[k]) (void)hipHostFree(c->hstage[k]); if (c->hstage_ev[k]) (void)hipEventDestroy(c->hstage_ev[k]); }
-    if (c->arena.base) (void)hipFree(c->arena.base);
+    c->arena.vm.destroy();
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -323,9 +331,10 @@ int pfp_parse_feed_batch(pfp_ctx *c, const uint8_t *bases, uint64_t count, uint6
     if (c->n + add + (uint64_t)c->w + 64 >= ((c->flags & PFP_FLAG_U64) ? (1ULL << 40) : 0xFFFFFFFFULL)) return PFP_E_TOO_LARGE;
     PFP_TRY(ensure_text(c, c->n + add + (uint64_t)c->w));
     uint8_t *dst = c->tb + 16 + c->n;
-    // pinned host memory: ONE strided DMA transfer for the whole collection, the pads of pfparser.hpp:335-337 by a strided fill
-    PFP_HIP(c, hipMemcpy2DAsync(dst, (size_t)pitch, bases, (size_t)stride, (size_t)len, (size_t)count, hipMemcpyHostToDevice, c->stream));
-    PFP_HIP(c, hipMemset2DAsync(dst + len, (size_t)pitch, 'A', (size_t)c->w, (size_t)count, c->stream));
+    // pinned host memory: one DMA transfer per record, queued back to back (the runtime's 2-D copy rejects a destination that
+    // spans several pieces of the on-demand committed text, csrc/devmem.h), the pads of pfparser.hpp:335-337 by one small kernel
+    for (uint64_t k = 0; k < count; ++k) PFP_HIP(c, hipMemcpyAsync(dst + k * pitch, bases + k * stride, (size_t)len, hipMemcpyHostToDevice, c->stream));
+    PFP_LAUNCH(c, K_MISC, count * (uint64_t)c->w, k_pad_rows, nblocks(count * (uint64_t)c->w, BLOCK), dst, count, len, pitch, c->w);
     PFP_HIP(c, hipStreamSynchronize(c->stream));      // the caller may reuse its buffer
     c->n += add; c->tb_n = c->n;
     return PFP_OK;

@@ -14,6 +14,7 @@
  */
 #ifndef PFBWT_EMU_HIP_RUNTIME_H
 #define PFBWT_EMU_HIP_RUNTIME_H
+#include <sys/mman.h>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -237,6 +238,32 @@ static inline hipError_t hipMemcpy2DAsync(void *d, size_t dp, const void *s, siz
 { for (size_t r = 0; r < h; ++r) memmove((char *)d + r * dp, (const char *)s + r * sp, w); return hipSuccess; }
 static inline hipError_t hipMemset2DAsync(void *d, size_t dp, int v, size_t w, size_t h, hipStream_t = 0)
 { for (size_t r = 0; r < h; ++r) memset((char *)d + r * dp, v, w); return hipSuccess; }
+// virtual memory management (csrc/devmem.h): a reservation is an inaccessible anonymous mapping, mapping a handle makes its
+// range readable and writable -- a touch outside what the engine committed faults here, as it would on the card
+typedef struct emu_memhandle_s { size_t bytes; } *hipMemGenericAllocationHandle_t;
+enum hipMemAllocationType { hipMemAllocationTypePinned = 1 };
+enum hipMemLocationType { hipMemLocationTypeDevice = 1 };
+enum hipMemAccessFlags { hipMemAccessFlagsProtReadWrite = 3 };
+struct hipMemLocation { hipMemLocationType type; int id; };
+struct hipMemAllocationProp { hipMemAllocationType type; int requestedHandleTypes; hipMemLocation location; void *win32HandleMetaData; unsigned char allocFlags[8]; };
+struct hipMemAccessDesc { hipMemLocation location; hipMemAccessFlags flags; };
+static inline hipError_t hipMemAddressReserve(void **p, size_t size, size_t align, void *, unsigned long long)
+{
+    if (!align) align = 4096;
+    char *q = (char *)mmap(nullptr, size + align, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (q == (char *)MAP_FAILED) return hipErrorOutOfMemory;
+    char *a = (char *)(((uintptr_t)q + align - 1) / align * align);
+    if (a > q) munmap(q, (size_t)(a - q));
+    if (a + size < q + size + align) munmap(a + size, (size_t)(q + size + align - (a + size)));
+    *p = a; return hipSuccess;
+}
+static inline hipError_t hipMemAddressFree(void *p, size_t size) { munmap(p, size); return hipSuccess; }
+static inline hipError_t hipMemCreate(hipMemGenericAllocationHandle_t *h, size_t size, const hipMemAllocationProp *, unsigned long long) { *h = new emu_memhandle_s{size}; return hipSuccess; }
+static inline hipError_t hipMemRelease(hipMemGenericAllocationHandle_t h) { delete h; return hipSuccess; }
+static inline hipError_t hipMemMap(void *p, size_t size, size_t, hipMemGenericAllocationHandle_t, unsigned long long) { return mprotect(p, size, PROT_READ | PROT_WRITE) == 0 ? hipSuccess : hipErrorInvalidValue; }
+static inline hipError_t hipMemUnmap(void *p, size_t size)
+{ return mmap(p, size, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE | MAP_FIXED, -1, 0) == p ? hipSuccess : hipErrorInvalidValue; }
+static inline hipError_t hipMemSetAccess(void *, size_t, const hipMemAccessDesc *, size_t) { return hipSuccess; }
 static inline hipError_t hipStreamCreate(hipStream_t *s) { *s = 0; return hipSuccess; }
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = 0; return hipSuccess; }
 static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }

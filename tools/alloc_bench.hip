@@ -27,6 +27,58 @@ int main(int argc, char **argv)
         if (argc >= 4 && e == hipSuccess) { t0 = now_ms(); CK(hipFree(p)); printf("  hipFree %.1f ms\n", now_ms() - t0); void *q = nullptr; t0 = now_ms(); e = hipMalloc(&q, (size_t)atoll(argv[3]) * GB); printf("  then hipMalloc %s GB: %s %.1f ms\n", argv[3], hipGetErrorString(e), now_ms() - t0); }
         return 0;
     }
+    if (argc >= 2 && !strcmp(argv[1], "vmmcopy")) {      // do runtime copies / fills work across the boundary of separately created + mapped handles?
+#define MUST(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("ABORT %s: %s\n", #x, hipGetErrorString(e_)); fflush(stdout); return 1; } } while (0)
+        const size_t CH = (size_t)64 << 20;
+        hipMemAllocationProp prop; memset(&prop, 0, sizeof prop);
+        prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = 0;
+        void *va = nullptr; MUST(hipMemAddressReserve(&va, 64 * GB, (size_t)2 << 30, nullptr, 0));
+        printf("reserve 64 GiB asking for 2 GiB alignment: va=%p (%s)\n", va, ((uintptr_t)va & (((size_t)2 << 30) - 1)) ? "NOT aligned" : "aligned");
+        hipMemAccessDesc ad; memset(&ad, 0, sizeof ad); ad.location = prop.location; ad.flags = hipMemAccessFlagsProtReadWrite;
+        // which (offset, size) combinations does hipMemSetAccess take?  (nothing touches these ranges)
+        struct { size_t off, sz; } probe[] = {{1 * GB, 256 << 20}, {1 * GB + (256 << 20), 128 << 20}, {2 * GB + (128 << 20), 256 << 20}, {3 * GB, 192 << 20}, {4 * GB + (64 << 20), 2 * GB}};
+        for (auto &pr : probe) {
+            hipMemGenericAllocationHandle_t hh; MUST(hipMemCreate(&hh, pr.sz, &prop, 0));
+            hipError_t em = hipMemMap((char *)va + pr.off, pr.sz, 0, hh, 0);
+            hipError_t ea = em == hipSuccess ? hipMemSetAccess((char *)va + pr.off, pr.sz, &ad, 1) : em;
+            printf("piece of %4zu MiB at offset %5zu MiB: map %s, access %s\n", pr.sz >> 20, pr.off >> 20, hipGetErrorString(em), hipGetErrorString(ea)); (void)hipGetLastError();
+            if (em == hipSuccess) (void)hipMemUnmap((char *)va + pr.off, pr.sz);
+            (void)hipMemRelease(hh);
+        }
+        // eight uniform 64 MiB pieces at multiples of their size
+        char *reg = (char *)va + 16 * GB;
+        for (int i = 0; i < 8; ++i) { hipMemGenericAllocationHandle_t hh; MUST(hipMemCreate(&hh, CH, &prop, 0)); MUST(hipMemMap(reg + i * CH, CH, 0, hh, 0)); MUST(hipMemSetAccess(reg + i * CH, CH, &ad, 1)); }
+        hipStream_t s; MUST(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        const size_t nb = 3 * CH; uint8_t *hp = nullptr, *hq = nullptr; MUST(hipHostMalloc((void **)&hp, nb, 0)); MUST(hipHostMalloc((void **)&hq, nb, 0));
+        for (size_t i = 0; i < nb; ++i) hp[i] = (uint8_t)(i * 7 + (i >> 20));
+        char *d = reg + CH / 2;                       // [d, d + nb) spans four pieces, all mapped and accessible
+        hipError_t e;
+        e = hipMemcpyAsync(d, hp, nb, hipMemcpyHostToDevice, s); printf("H2D across pieces: %s", hipGetErrorString(e)); if (e != hipSuccess) return 1; e = hipStreamSynchronize(s); printf(" / sync %s\n", hipGetErrorString(e)); if (e != hipSuccess) return 1;
+        memset(hq, 0, nb); e = hipMemcpyAsync(hq, d, nb, hipMemcpyDeviceToHost, s); printf("D2H across pieces: %s", hipGetErrorString(e)); if (e != hipSuccess) return 1; e = hipStreamSynchronize(s); printf(" / sync %s  data %s\n", hipGetErrorString(e), memcmp(hp, hq, nb) ? "DIFFER" : "equal"); if (e != hipSuccess) return 1;
+        void *plain = nullptr; MUST(hipMalloc(&plain, nb));
+        e = hipMemcpyAsync(plain, d, nb, hipMemcpyDeviceToDevice, s); printf("D2D vmm(across) -> hipMalloc: %s", hipGetErrorString(e)); if (e != hipSuccess) return 1; e = hipStreamSynchronize(s); printf(" / sync %s\n", hipGetErrorString(e)); if (e != hipSuccess) return 1;
+        memset(hq, 0, nb); MUST(hipMemcpy(hq, plain, nb, hipMemcpyDeviceToHost)); printf("   data %s\n", memcmp(hp, hq, nb) ? "DIFFER" : "equal");
+        e = hipMemsetAsync(d, 0x5A, nb, s); printf("memset across pieces: %s", hipGetErrorString(e)); if (e != hipSuccess) return 1; e = hipStreamSynchronize(s); printf(" / sync %s\n", hipGetErrorString(e)); if (e != hipSuccess) return 1;
+        MUST(hipMemcpy(hq, d, nb, hipMemcpyDeviceToHost)); size_t bad = 0; for (size_t i = 0; i < nb; ++i) bad += hq[i] != 0x5A; printf("   memset bytes wrong: %zu\n", bad);
+        e = hipMemcpyAsync(d, plain, nb, hipMemcpyDeviceToDevice, s); printf("D2D hipMalloc -> vmm(across): %s", hipGetErrorString(e)); if (e != hipSuccess) return 1; e = hipStreamSynchronize(s); printf(" / sync %s\n", hipGetErrorString(e)); if (e != hipSuccess) return 1;
+        MUST(hipMemcpy(hq, d, nb, hipMemcpyDeviceToHost)); printf("   data %s\n", memcmp(hp, hq, nb) ? "DIFFER" : "equal");
+        e = hipMemcpyAsync(reg + 5 * CH - 1000, d, 2000 + CH, hipMemcpyDeviceToDevice, s); printf("D2D vmm -> vmm, both across: %s", hipGetErrorString(e)); if (e != hipSuccess) return 1; e = hipStreamSynchronize(s); printf(" / sync %s\n", hipGetErrorString(e)); if (e != hipSuccess) return 1;
+        e = hipMemcpy2DAsync(d + 5, 1000 + 10, hp, 1000, 1000, (nb - CH) / 1010, hipMemcpyHostToDevice, s); printf("2D H2D across pieces: %s", hipGetErrorString(e)); if (e != hipSuccess) return 1; e = hipStreamSynchronize(s); printf(" / sync %s\n", hipGetErrorString(e)); if (e != hipSuccess) return 1;
+        e = hipMemset2DAsync(d + 5, 1010, 'A', 10, (nb - CH) / 1010, s); printf("2D memset across pieces: %s", hipGetErrorString(e)); if (e != hipSuccess) return 1; e = hipStreamSynchronize(s); printf(" / sync %s\n", hipGetErrorString(e)); if (e != hipSuccess) return 1;
+        hipPointerAttribute_t at; e = hipPointerGetAttributes(&at, d); printf("hipPointerGetAttributes(vmm): %s type %d\n", hipGetErrorString(e), e == hipSuccess ? (int)at.type : -1); (void)hipGetLastError();
+        // cost of many small pieces
+        char *reg2 = (char *)va + 32 * GB;
+        t0 = now_ms(); int nsm = 0; for (int i = 0; i < 256; ++i) { hipMemGenericAllocationHandle_t hh; MUST(hipMemCreate(&hh, CH, &prop, 0)); MUST(hipMemMap(reg2 + i * CH, CH, 0, hh, 0)); MUST(hipMemSetAccess(reg2 + i * CH, CH, &ad, 1)); ++nsm; }
+        printf("%d pieces of 64 MiB created+mapped: %.2f ms each\n", nsm, (now_ms() - t0) / (nsm ? nsm : 1));
+        t0 = now_ms(); k_touch<<<4096, 256, 0, s>>>((uint4 *)reg2, (size_t)nsm * CH / 16); MUST(hipStreamSynchronize(s)); printf("touch 16 GiB of 64 MiB pieces: %.1f ms\n", now_ms() - t0);
+        t0 = now_ms(); k_touch<<<4096, 256, 0, s>>>((uint4 *)reg2, (size_t)nsm * CH / 16); MUST(hipStreamSynchronize(s)); printf("again: %.1f ms\n", now_ms() - t0);
+        char *reg3 = (char *)va + 48 * GB;
+        t0 = now_ms(); nsm = 0; for (int i = 0; i < 512; ++i) { hipMemGenericAllocationHandle_t hh; MUST(hipMemCreate(&hh, (size_t)2 << 20, &prop, 0)); MUST(hipMemMap(reg3 + (size_t)i * (2 << 20), (size_t)2 << 20, 0, hh, 0)); MUST(hipMemSetAccess(reg3 + (size_t)i * (2 << 20), (size_t)2 << 20, &ad, 1)); ++nsm; }
+        printf("%d pieces of 2 MiB created+mapped: %.3f ms each\n", nsm, (now_ms() - t0) / (nsm ? nsm : 1));
+        t0 = now_ms(); k_touch<<<4096, 256, 0, s>>>((uint4 *)reg3, (size_t)nsm * (2 << 20) / 16); MUST(hipStreamSynchronize(s)); printf("touch 1 GiB of 2 MiB pieces: %.2f ms\n", now_ms() - t0);
+        t0 = now_ms(); k_touch<<<4096, 256, 0, s>>>((uint4 *)reg3, (size_t)nsm * (2 << 20) / 16); MUST(hipStreamSynchronize(s)); printf("again: %.2f ms\n", now_ms() - t0);
+        return 0;
+    }
     if (argc >= 3 && !strcmp(argv[1], "freshvmm")) {
         const size_t g = (size_t)atoll(argv[2]);
         hipMemAllocationProp prop; memset(&prop, 0, sizeof prop);
