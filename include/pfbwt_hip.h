@@ -34,7 +34,8 @@ typedef enum pfp_status {
     PFP_E_HIP = -5,          /* HIP runtime error; pfp_error_detail gives the hipError_t */
     PFP_E_ONE_WORD = -6,     /* pfparser.hpp:390-392 "only one dict word total" */
     PFP_E_STATE = -7,        /* call order violated (e.g. pfp_parse_bwt before pfp_parse_finalize) */
-    PFP_E_CORRUPT = -8       /* loaded parse files are inconsistent (pfbwt.hpp:139 "something went wrong!") */
+    PFP_E_CORRUPT = -8,      /* loaded parse files are inconsistent (pfbwt.hpp:139 "something went wrong!") */
+    PFP_E_IO = -9            /* pfp_parse_feed_fasta_file: the file cannot be opened or read (pfparser.hpp:302-304 "failed to open file!") */
 } pfp_status;
 
 /* pfp_create flags */
@@ -88,6 +89,37 @@ int pfp_parse_feed_device(pfp_ctx *ctx, const void *d_bases, uint64_t len, int e
 /* `count` records of `len` bytes each, record k at d_bases + k*stride (device memory): the same as `count` calls of
  * pfp_parse_feed_device(.., len, 1), done as one strided copy (a collection of equal-length haplotypes) */
 int pfp_parse_feed_device_batch(pfp_ctx *ctx, const void *d_bases, uint64_t count, uint64_t len, uint64_t stride);
+/* FASTA ingest on the device: RAW file bytes -- header lines, newlines and all -- in any chunking (host memory;
+ * page-locked memory is read by DMA in place).  Stands in for kseq_read as PfParser::add_fasta drives it, include/kseq.h:178-228,
+ * include/pfparser.hpp:300-337: bytes in front of the first '>' / '@' are skipped, a line that starts with '>' or '@' is a header
+ * line, the other lines are concatenated without their line ends ('\r' dropped), every record -- empty ones too -- is followed
+ * by the w 'A's.  flags: PFP_FASTA_FINAL closes the stream (the last record's pad; the next call starts a new file),
+ * PFP_FASTA_RECORDS collects, for the records that START in this call, the offset of their header's first byte in `raw` and the
+ * text position (get_n() coordinates) of their first base -- the (name, start) pairs of --print-docs, pfparser.hpp:321-325 -- to be
+ * fetched with pfp_parse_fasta_records; *nrec (nullable) = their number.  The raw bytes cross PCIe in chunks of up to 256 MiB;
+ * stripping chunk k overlaps the upload of chunk k + 1; returns when the caller's buffer may be reused.
+ * PFP_E_ARG with pfp_error_detail ch == '+': a line starts with '+' (a FASTQ quality section, kseq.h:209-221) -- not handled on
+ * the device, the context must be reset and the input read by a host-side reader (pfp_parse_feed per record). */
+#define PFP_FASTA_FINAL   1u
+#define PFP_FASTA_RECORDS 2u
+int pfp_parse_feed_fasta(pfp_ctx *ctx, const uint8_t *raw, uint64_t len, unsigned flags, uint64_t *nrec);
+int pfp_parse_fasta_records(pfp_ctx *ctx, uint64_t *raw_off, uint64_t *text_pos);
+/* The reading side of PfParser::add_fasta, pfparser.hpp:300-307 (gzopen + kseq_init + the kseq_read loop, include/kseq.h:178-228):
+ * `path` ("-" = stdin; gzip or plain, detected by content) is read in 64 MiB blocks into page-locked buffers -- a plain regular
+ * file by several threads at independent offsets, a gzip stream or a pipe by one -- and the blocks go through
+ * pfp_parse_feed_fasta while the next ones are being read.  FASTQ (the first record starts with '@') is read record by record
+ * on the host with kseq's rules (quality lines skipped).  flags: PFP_FASTA_RECORDS collects (name, start) of every record for
+ * pfp_parse_docs / pfp_parse_doc_get (--print-docs); the stream is always closed (PFP_FASTA_FINAL implied).  info (nullable):
+ * raw bytes read, records, text length behind the file, time the consumer waited for the readers, wall time, and which
+ * reader ran (1 parallel pread, 2 single zlib / pipe reader, 3 host record reader). */
+typedef struct pfp_ingest_info { uint64_t raw_bytes, records, n; double read_wait_ms, total_ms; int mode; } pfp_ingest_info;
+int pfp_parse_feed_fasta_file(pfp_ctx *ctx, const char *path, unsigned flags, pfp_ingest_info *info);
+int pfp_parse_docs(pfp_ctx *ctx, uint64_t *count);
+int pfp_parse_doc_get(pfp_ctx *ctx, uint64_t i, const char **name, uint64_t *start);   /* valid until the next pfp_parse_feed_fasta_file */
+/* Announce the size of the text that is going to be fed (e.g. the size of the FASTA file): sizes the ADDRESS range of the text
+ * buffer -- HBM itself is committed as the text grows (never re-allocated or copied).  Optional; without it the range is as
+ * large as the card, which limits a process to a few hundred live contexts. */
+int pfp_parse_reserve(pfp_ctx *ctx, uint64_t text_bytes);
 /* Back to feeding with the text kept: after pfp_parse_finalize the (normalised) text is still on the device, more
  * records can be appended and pfp_parse_finalize run again -- what PfParser::operator+= (pfparser.hpp:194-263) needs
  * when the right-hand parse is appended as text (pfp_text_view of its context + pfp_parse_feed_device) instead of being

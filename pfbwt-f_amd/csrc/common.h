@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <chrono>
+#include <string>
 #include <vector>
 #include "../../include/pfbwt_hip.h"
 #include "devmem.h"
@@ -26,14 +27,14 @@ enum KernelId {
     K_TRIGGER_SCAN, K_PHRASE_ENDS, K_PHRASE_HASH, K_PHRASE_HASH_LONG, K_DEDUP_HEADS, K_DEDUP_LONG,
     K_DICT_BUILD, K_RADIX_HIST, K_RADIX_SCATTER, K_SCAN_REDUCE, K_SCAN_SPINE, K_SCAN_APPLY,
     K_SS_INIT_KEYS, K_SS_HEADS, K_SS_MAKE_KEYS, K_SS_WRITE_RANK, K_SS_FLAG_ACTIVE, K_COMPACT,
-    K_WORD_RANK, K_PARSE_RANKS, K_DICT_SORTED, K_PBWT_ROWS, K_EMIT_COUNT, K_EMIT, K_RUNS, K_SAMPLES, K_MISC, K_EMIT_BIG, K_FILL, K_CLASS_SORT,
+    K_WORD_RANK, K_PARSE_RANKS, K_DICT_SORTED, K_PBWT_ROWS, K_EMIT_COUNT, K_EMIT, K_RUNS, K_SAMPLES, K_MISC, K_EMIT_BIG, K_FILL, K_CLASS_SORT, K_FASTA,
     K_COUNT_
 };
 static const char *const kernel_names[K_COUNT_] = {
     "trigger_scan", "phrase_ends", "phrase_hash", "phrase_hash_long", "dedup_heads", "dedup_long",
     "dict_build", "radix_hist", "radix_scatter", "scan_reduce", "scan_spine", "scan_apply",
     "ss_init_keys", "ss_heads", "ss_make_keys", "ss_write_rank", "ss_flag_active", "compact",
-    "word_rank", "parse_ranks", "dict_sorted", "pbwt_rows", "emit_count", "emit", "runs", "samples", "misc", "emit_big", "fill", "class_sort"};
+    "word_rank", "parse_ranks", "dict_sorted", "pbwt_rows", "emit_count", "emit", "runs", "samples", "misc", "emit_big", "fill", "class_sort", "fasta_strip"};
 
 struct ProfRec { uint64_t launches = 0; double ms = 0, bytes = 0; };
 
@@ -84,6 +85,7 @@ struct Tunables {
     int no_runaware = 0;               // -r with every row enumerated, as with a full SA
     long big_group_members = -2;       // -2: BIG_GROUP_MEMBERS (emit.h); < 0 otherwise: never take the sort route
     int force_wide_rows = 0;           // 64-bit row counters on small texts
+    uint64_t fasta_chunk_bytes = 0;    // size of the raw-FASTA device buffers (0: 1 MiB ... 256 MiB by the size of the first call)
 };
 
 } // namespace pfp
@@ -137,6 +139,18 @@ struct pfp_ctx {
     //     k + 1 overlaps the DMA of chunk k (pinned sources are copied directly)
     uint8_t *hstage[2] = {nullptr, nullptr}; hipEvent_t hstage_ev[2] = {nullptr, nullptr}; bool hstage_used[2] = {false, false};
     pfp::Tunables tun;
+    // --- raw FASTA ingest (csrc/fasta.h): two device buffers for raw chunks (the upload of one overlaps the stripping of the other)
+    struct FastaIngest {
+        uint8_t *raw[2] = {nullptr, nullptr}; size_t rawcap = 0; bool used[2] = {false, false};
+        hipStream_t copy = nullptr; hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
+        uint8_t *tiles = nullptr; size_t tiles_cap = 0;                 // per-tile summaries of one chunk
+        unsigned long long *d_tot = nullptr, *h_tot = nullptr;          // device / page-locked host: kept bytes, header starts, end state, flags
+        uint32_t state = 2; bool started = false; uint64_t records = 0; // the stream's state machine (2 = at a line start)
+        std::vector<uint64_t> rec_raw, rec_pos;                         // records that started in the last pfp_parse_feed_fasta call
+    } fa;
+    uint8_t *ing_buf[8] = {};                                           // page-locked blocks of the file reader (csrc/ingest.h)
+    uint64_t ing_next_off = 0;
+    std::vector<std::string> doc_names; std::vector<uint64_t> doc_starts;   // records of the last pfp_parse_feed_fasta_file(PFP_FASTA_RECORDS)
     uint64_t hash_seed = 0x9E3779B97F4A7C15ULL;
     uint32_t *d_trigtab = nullptr;      // w <= 10: one bit per k-mer, "wang_hash(kmer) % p == 0" (128 KiB for w = 10; lives in LDS during the trigger scan)
 };

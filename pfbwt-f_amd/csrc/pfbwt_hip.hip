@@ -4,6 +4,7 @@
 #include "common.h"
 #include "prims.h"
 #include "parse.h"
+#include "fasta.h"
 #include "sufsort.h"
 #include "emit.h"
 #include "markers.h"
@@ -74,11 +75,12 @@ static void reset_results(pfp_ctx *c)
     c->d_ye = nullptr; c->d_pid = nullptr; c->d_parse = nullptr; c->d_last = nullptr; c->d_dict = nullptr; c->d_ws = nullptr; c->d_wordid = nullptr;
     c->d_occ = nullptr; c->d_sdict = nullptr; c->d_gsa = nullptr; c->d_grank = nullptr;
     c->arena.reset();
+    c->fa.started = false; c->fa.state = 2; c->fa.records = 0; c->fa.rec_raw.clear(); c->fa.rec_pos.clear();
 }
 
 // ---- route / tuning switches (pfbwt_hip_dev.h) -----------------------------------------------------
 static const char *const tunable_names[] = {"verbose", "seg_grid", "seg_stage", "sort_k", "sort_no_table", "class_sort_maxrange", "dedup_table_log2", "no_trigger_table",
-                                            "emit_chunk_rows", "fill_subs", "sample_cap", "no_runaware", "big_group_members", "force_wide_rows"};
+                                            "emit_chunk_rows", "fill_subs", "sample_cap", "no_runaware", "big_group_members", "force_wide_rows", "fasta_chunk_bytes"};
 static int set_tunable(pfp_ctx *c, const char *key, long long v)
 {
     Tunables &t = c->tun;
@@ -96,6 +98,7 @@ static int set_tunable(pfp_ctx *c, const char *key, long long v)
     else if (!strcmp(key, "no_runaware")) t.no_runaware = (int)v;
     else if (!strcmp(key, "big_group_members")) t.big_group_members = (long)v;
     else if (!strcmp(key, "force_wide_rows")) t.force_wide_rows = (int)v;
+    else if (!strcmp(key, "fasta_chunk_bytes")) t.fasta_chunk_bytes = v > 0 ? (uint64_t)v : 0;
     else return PFP_E_ARG;
     return PFP_OK;
 }
@@ -132,6 +135,7 @@ const char *pfp_strerror(int s)
     case PFP_E_ONE_WORD: return "error: only one dict word total. Re-run with a smaller p modulus";
     case PFP_E_STATE: return "call order violated";
     case PFP_E_CORRUPT: return "something went wrong!";
+    case PFP_E_IO: return "failed to open file!";
     default: return "unknown status";
     }
 }
@@ -164,6 +168,12 @@ void pfp_destroy(pfp_ctx *c)
     prof_collect(c);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     c->text.destroy();
+    for (int k = 0; k < 2; ++k) { if (c->fa.raw[k]) (void)hipFree(c->fa.raw[k]); if (c->fa.ev_copied[k]) (void)hipEventDestroy(c->fa.ev_copied[k]); if (c->fa.ev_free[k]) (void)hipEventDestroy(c->fa.ev_free[k]); }
+    if (c->fa.tiles) (void)hipFree(c->fa.tiles);
+    if (c->fa.d_tot) (void)hipFree(c->fa.d_tot);
+    if (c->fa.h_tot) (void)hipHostFree(c->fa.h_tot);
+    if (c->fa.copy) (void)hipStreamDestroy(c->fa.copy);
+    for (auto &q : c->ing_buf) if (q) (void)hipHostFree(q);
     if (c->d_trigtab) (void)hipFree(c->d_trigtab);
     for (int k = 0; k < 2; ++k) { if (c->hstage[k]) (void)hipHostFree(c->hstage[k]); if (c->hstage_ev[k]) (void)hipEventDestroy(c->hstage_ev[k]); }
     c->arena.vm.destroy();
@@ -337,6 +347,169 @@ int pfp_parse_feed_batch(pfp_ctx *c, const uint8_t *bases, uint64_t count, uint6
     PFP_LAUNCH(c, K_MISC, count * (uint64_t)c->w, k_pad_rows, nblocks(count * (uint64_t)c->w, BLOCK), dst, count, len, pitch, c->w);
     PFP_HIP(c, hipStreamSynchronize(c->stream));      // the caller may reuse its buffer
     c->n += add; c->tb_n = c->n;
+    return PFP_OK;
+}
+
+// ---- raw FASTA bytes (csrc/fasta.h) ---------------------------------------------------------------------------------
+constexpr size_t FA_RAW_MAX = (size_t)256 << 20, FA_RAW_MIN = (size_t)1 << 20;
+int pfp_parse_reserve(pfp_ctx *c, uint64_t text_bytes)
+{
+    if (!c) return PFP_E_ARG;
+    if (!c->text.live()) c->text_hint = text_bytes;      // sizes the address range of the text; ignored once text has been fed
+    return PFP_OK;
+}
+static int fasta_buffers(pfp_ctx *c, uint64_t len)
+{
+    auto &f = c->fa;
+    size_t want = FA_RAW_MIN; while (want < FA_RAW_MAX && want < len) want <<= 1;
+    if (c->tun.fasta_chunk_bytes) want = (size_t)(c->tun.fasta_chunk_bytes < 64 ? 64 : c->tun.fasta_chunk_bytes);      // tests: many chunks on small inputs
+    if (!f.copy) {
+        PFP_HIP(c, hipStreamCreateWithFlags(&f.copy, hipStreamNonBlocking));
+        for (int k = 0; k < 2; ++k) { PFP_HIP(c, hipEventCreateWithFlags(&f.ev_copied[k], hipEventDisableTiming)); PFP_HIP(c, hipEventCreateWithFlags(&f.ev_free[k], hipEventDisableTiming)); }
+        PFP_HIP(c, hipMalloc((void **)&f.d_tot, 64));
+        PFP_HIP(c, hipHostMalloc((void **)&f.h_tot, 64, hipHostMallocDefault));
+        PFP_HIP(c, hipMemsetAsync(f.d_tot, 0, 64, c->stream));
+    }
+    if (f.rawcap >= want || (f.rawcap && want < 4 * f.rawcap)) return PFP_OK;      // (a much larger call than the first one: take larger buffers once)
+    PFP_HIP(c, hipStreamSynchronize(c->stream)); PFP_HIP(c, hipStreamSynchronize(f.copy));
+    for (int k = 0; k < 2; ++k) { if (f.raw[k]) PFP_HIP(c, hipFree(f.raw[k])); f.raw[k] = nullptr; f.used[k] = false; }
+    if (f.tiles) { PFP_HIP(c, hipFree(f.tiles)); f.tiles = nullptr; }
+    for (int k = 0; k < 2; ++k) if (hipMalloc((void **)&f.raw[k], want) != hipSuccess) { (void)hipGetLastError(); f.rawcap = 0; return PFP_E_NOMEM; }
+    const size_t T = want / FA_TILE + 1;
+    f.tiles_cap = T * (1 + 12 + 12 + 1 + 8 + 4) + 256;
+    if (hipMalloc((void **)&f.tiles, f.tiles_cap) != hipSuccess) { (void)hipGetLastError(); f.rawcap = 0; return PFP_E_NOMEM; }
+    f.rawcap = want;
+    return PFP_OK;
+}
+// kseq_read, include/kseq.h:186-190: everything in front of the first '>' or '@' of a stream is skipped.  Returns the offset
+// of the first byte that counts (len: none yet).
+static uint64_t fa_skip_preamble(pfp_ctx *c, const uint8_t *raw, uint64_t len)
+{
+    auto &f = c->fa;
+    if (f.started || !len) return 0;
+    const uint8_t *a = (const uint8_t *)memchr(raw, '>', (size_t)len), *b = (const uint8_t *)memchr(raw, '@', (size_t)len);
+    const uint8_t *q = (a && b) ? (a < b ? a : b) : (a ? a : b);
+    if (!q) return len;
+    f.started = true; f.state = FA_L; f.records = 0;
+    return (uint64_t)(q - raw);
+}
+// upload of one raw piece (at most rawcap bytes) into device buffer `slot`, once the kernels that read its previous content are done
+static int fa_issue(pfp_ctx *c, const uint8_t *src, uint64_t len, int slot)
+{
+    auto &f = c->fa;
+    if (f.used[slot]) PFP_HIP(c, hipStreamWaitEvent(f.copy, f.ev_free[slot], 0));
+    PFP_HIP(c, hipMemcpyAsync(f.raw[slot], src, (size_t)len, hipMemcpyHostToDevice, f.copy));
+    PFP_HIP(c, hipEventRecord(f.ev_copied[slot], f.copy));
+    return PFP_OK;
+}
+// strip the piece in device buffer `slot` into the text.  Returns with the upload of the piece complete (the host waits for
+// the piece's totals, which wait for the upload): the caller's buffer may be reused.  rec_base: offset of the piece in the
+// caller's coordinate system (record offsets are reported in it).
+static int fa_process(pfp_ctx *c, uint64_t len, int slot, bool want_recs, uint64_t rec_base, uint64_t *started)
+{
+    auto &f = c->fa;
+    const uint64_t w = (uint64_t)c->w;
+    const uint64_t limit = (c->flags & PFP_FLAG_U64) ? (1ULL << 40) : 0xFFFFFFFFULL;
+    PFP_HIP(c, hipStreamWaitEvent(c->stream, f.ev_copied[slot], 0));
+    FaTiles t; t.T = (len + FA_TILE - 1) / FA_TILE;
+    uint8_t *q = f.tiles;
+    t.kbase = (unsigned long long *)q; q += t.T * 8; t.kept = (uint32_t *)q; q += t.T * 12; t.hdr = (uint32_t *)q; q += t.T * 12; t.hbase = (uint32_t *)q; q += t.T * 4; t.func = q; q += t.T; t.st = q;
+    PFP_LAUNCH(c, K_FASTA, len, k_fa_scan, t.T, (const uint8_t *)f.raw[slot], len, t);
+    PFP_LAUNCH(c, K_MISC, t.T * 40, k_fa_spine, 1, t, f.state, f.d_tot);
+    PFP_HIP(c, hipMemcpyAsync(f.h_tot, f.d_tot, 24, hipMemcpyDeviceToHost, c->stream));
+    PFP_HIP(c, hipStreamSynchronize(c->stream));
+    const uint64_t kept = f.h_tot[0], hdr = f.h_tot[1], rec0 = f.records;
+    const uint64_t tbase = c->n - w * (rec0 ? rec0 - 1 : 0);
+    const uint64_t n_new = tbase + kept + w * ((rec0 + hdr) ? rec0 + hdr - 1 : 0);
+    if (n_new + 2 * w + 64 >= limit) return PFP_E_TOO_LARGE;                      // pfparser.hpp:326-331
+    PFP_TRY(ensure_text(c, n_new + 2 * w));
+    uint64_t *d_rr = nullptr, *d_rp = nullptr;
+    if (want_recs && hdr) { PFP_HIP(c, hipMalloc((void **)&d_rr, hdr * 16)); d_rp = d_rr + hdr; }
+    PFP_LAUNCH(c, K_FASTA, 2 * len, k_fa_compact, t.T, (const uint8_t *)f.raw[slot], len, t, c->tb + 16, tbase, rec0, c->w, d_rr, d_rp, (uint32_t *)(f.d_tot + 4));
+    PFP_HIP(c, hipEventRecord(f.ev_free[slot], c->stream)); f.used[slot] = true;
+    if (d_rr) {
+        const size_t b = f.rec_raw.size();
+        f.rec_raw.resize(b + hdr); f.rec_pos.resize(b + hdr);
+        PFP_HIP(c, hipMemcpy(f.rec_raw.data() + b, d_rr, hdr * 8, hipMemcpyDeviceToHost));
+        PFP_HIP(c, hipMemcpy(f.rec_pos.data() + b, d_rp, hdr * 8, hipMemcpyDeviceToHost));
+        PFP_HIP(c, hipFree(d_rr));
+        for (size_t i = b; i < b + hdr; ++i) f.rec_raw[i] += rec_base;
+    }
+    c->n = n_new; c->tb_n = c->n; f.records = rec0 + hdr; f.state = (uint32_t)f.h_tot[2];
+    if (started) *started += hdr;
+    return PFP_OK;
+}
+// end of a stream: the pad of its last record; a '+' line seen on the way makes the whole stream PFP_E_ARG
+static int fa_finish_stream(pfp_ctx *c)
+{
+    auto &f = c->fa;
+    const uint64_t w = (uint64_t)c->w;
+    if (f.started && f.records) {
+        PFP_TRY(ensure_text(c, c->n + 2 * w));
+        PFP_HIP(c, hipMemsetAsync(c->tb + 16 + c->n, 'A', (size_t)w, c->stream));
+        c->n += w; c->tb_n = c->n;
+    }
+    uint32_t fl = 0;
+    if (f.d_tot) { PFP_HIP(c, hipMemcpyAsync(&fl, f.d_tot + 4, 4, hipMemcpyDeviceToHost, c->stream)); PFP_HIP(c, hipStreamSynchronize(c->stream)); PFP_HIP(c, hipMemsetAsync(f.d_tot + 4, 0, 8, c->stream)); }
+    f.started = false; f.state = FA_L; f.records = 0;
+    if (fl & 1u) { c->err_ch = '+'; return PFP_E_ARG; }                             // a FASTQ quality section: not handled on the device
+    return PFP_OK;
+}
+static int feed_fasta_impl(pfp_ctx *c, const uint8_t *raw, uint64_t len, unsigned flags, uint64_t *nrec)
+{
+    auto &f = c->fa;
+    const bool want_recs = (flags & PFP_FASTA_RECORDS) != 0;
+    f.rec_raw.clear(); f.rec_pos.clear();
+    uint64_t started = 0;
+    const uint64_t off = fa_skip_preamble(c, raw, len);
+    if (off < len) {
+        PFP_TRY(fasta_buffers(c, len - off));
+        const uint64_t cap = f.rawcap, nsub = (len - off + cap - 1) / cap;
+        auto piece = [&](uint64_t k, uint64_t *o, uint64_t *cl) { *o = off + k * cap; *cl = (len - *o < cap) ? len - *o : cap; };
+        uint64_t o, cl;
+        piece(0, &o, &cl); PFP_TRY(fa_issue(c, raw + o, cl, 0));
+        for (uint64_t k = 0; k < nsub; ++k) {
+            if (k + 1 < nsub) { piece(k + 1, &o, &cl); PFP_TRY(fa_issue(c, raw + o, cl, (int)((k + 1) & 1))); }      // its upload overlaps the stripping of piece k
+            piece(k, &o, &cl);
+            PFP_TRY(fa_process(c, cl, (int)(k & 1), want_recs, o, &started));
+        }
+    }
+    if (flags & PFP_FASTA_FINAL) PFP_TRY(fa_finish_stream(c));
+    if (nrec) *nrec = started;
+    return PFP_OK;
+}
+int pfp_parse_feed_fasta(pfp_ctx *c, const uint8_t *raw, uint64_t len, unsigned flags, uint64_t *nrec)
+{
+    if (!c || (!raw && len)) return PFP_E_ARG;
+    PFP_HIP(c, hipSetDevice(c->device));
+    if (c->stage != 0) reset_results(c);
+    return feed_fasta_impl(c, raw, len, flags, nrec);
+}
+} // extern "C"
+#include "ingest.h"
+extern "C" {
+int pfp_parse_feed_fasta_file(pfp_ctx *c, const char *path, unsigned flags, pfp_ingest_info *info)
+{
+    if (!c || !path) return PFP_E_ARG;
+    PFP_HIP(c, hipSetDevice(c->device));
+    if (c->stage != 0) reset_results(c);
+    IngestStats st;
+    const int rc = ingest_file(c, path, flags, &st);
+    if (info) { info->raw_bytes = st.raw_bytes; info->records = st.records; info->n = c->n; info->read_wait_ms = st.read_wait_ms; info->total_ms = st.total_ms; info->mode = st.mode; }
+    return rc;
+}
+int pfp_parse_docs(pfp_ctx *c, uint64_t *count) { if (!c || !count) return PFP_E_ARG; *count = c->doc_names.size(); return PFP_OK; }
+int pfp_parse_doc_get(pfp_ctx *c, uint64_t i, const char **name, uint64_t *start)
+{
+    if (!c || i >= c->doc_names.size()) return PFP_E_ARG;
+    if (name) *name = c->doc_names[(size_t)i].c_str();
+    if (start) *start = c->doc_starts[(size_t)i];
+    return PFP_OK;
+}
+int pfp_parse_fasta_records(pfp_ctx *c, uint64_t *raw_off, uint64_t *text_pos)
+{
+    if (!c) return PFP_E_ARG;
+    for (size_t i = 0; i < c->fa.rec_raw.size(); ++i) { if (raw_off) raw_off[i] = c->fa.rec_raw[i]; if (text_pos) text_pos[i] = c->fa.rec_pos[i]; }
     return PFP_OK;
 }
 

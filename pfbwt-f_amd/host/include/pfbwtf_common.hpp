@@ -1,7 +1,7 @@
 // pfbwt-f_amd/host/include/pfbwtf_common.hpp -- shared bits of the host-side mirror of the reference
 // interface: uint_t / int_t / int_text (gsa/gsacak.h:44-64), special symbols and file extensions
-// (include/utils.h:8-31), die() (src/utils.c:13-17), and a FASTA/FASTQ record reader with the record
-// semantics of include/kseq.h:178-222 (gz or plain, "-" = stdin).
+// (include/utils.h:8-31), die() (src/utils.c:13-17).  Reading FASTA / FASTQ (include/kseq.h:178-222; gz or plain,
+// "-" = stdin) is the engine's job: pfp_parse_feed_fasta_file.
 #ifndef PFBWTF_COMMON_HPP
 #define PFBWTF_COMMON_HPP
 #include <cinttypes>
@@ -44,55 +44,6 @@ inline void engine_check(pfp_ctx *ctx, int st, const char *what)
     }
     exit(1);
 }
-
-struct FastaRecord { std::string name; std::string seq; };
-
-class FastaReader {
-  public:
-    explicit FastaReader(const std::string &fname)
-    {
-        fp_ = (fname == "-") ? gzdopen(fileno(stdin), "r") : gzopen(fname.c_str(), "r");
-        if (fp_ == NULL) die("failed to open file!\n");
-        gzbuffer(fp_, 1 << 20);
-    }
-    ~FastaReader() { if (fp_) gzclose(fp_); }
-    // next record; false at end of file.  FASTA and FASTQ ('@' headers, '+' quality) are accepted.
-    bool next(FastaRecord &r)
-    {
-        int c;
-        if (!pending_) { while ((c = getc_()) >= 0 && c != '>' && c != '@') {} if (c < 0) return false; }
-        pending_ = 0;
-        r.name.clear(); r.seq.clear();
-        // header line: name up to the first white space, rest is comment
-        bool in_name = true;
-        while ((c = getc_()) >= 0 && c != '\n') { if (in_name) { if (c == ' ' || c == '\t' || c == '\r') in_name = false; else r.name.push_back((char)c); } }
-        // sequence lines
-        bool line_start = true;
-        while ((c = getc_()) >= 0) {
-            if (line_start && (c == '>' || c == '@')) { pending_ = c; return true; }
-            if (line_start && c == '+') break;
-            if (c == '\n') { line_start = true; continue; }
-            line_start = false;
-            if (c != '\r') r.seq.push_back((char)c);
-        }
-        if (c == '+') {   // FASTQ: skip the '+' line, then as many quality characters as bases
-            while ((c = getc_()) >= 0 && c != '\n') {}
-            size_t q = 0;
-            while (q < r.seq.size() && (c = getc_()) >= 0) if (c != '\n' && c != '\r') ++q;
-        }
-        return true;
-    }
-
-  private:
-    int getc_()
-    {
-        if (pos_ == len_) { len_ = gzread(fp_, buf_, sizeof buf_); pos_ = 0; if (len_ <= 0) { len_ = 0; return -1; } }
-        return (unsigned char)buf_[pos_++];
-    }
-    gzFile fp_ = NULL;
-    char buf_[1 << 16];
-    int pos_ = 0, len_ = 0, pending_ = 0;
-};
 
 template <typename T> inline std::vector<T> read_vec(const std::string &path)
 {

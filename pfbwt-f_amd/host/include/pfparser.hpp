@@ -3,10 +3,10 @@
 //
 //   reference member                         here
 //   PfParser(PfParserParams) :82-84          pfp_create (w, p, flags)
-//   add_fasta :299-369                       host FASTA reader -> pfp_parse_feed per record (the engine stages pageable
-//                                            memory through two pinned buffers; the DMA of one record overlaps the
-//                                            reading / inflating of the next).  The text lives in HBM ONLY: the
-//                                            mirror keeps no copy (a 32 Gbase collection would not fit a host string)
+//   add_fasta :299-369                       pfp_parse_feed_fasta_file: the engine reads the file in blocks on helper threads
+//                                            into page-locked memory and strips headers / line ends on the device.  The
+//                                            text lives in HBM ONLY: the mirror keeps no copy (a 32 Gbase collection
+//                                            would not fit a host string)
 //   finalize :484-517                        pfp_parse_finalize + pfp_parse_get (dict, occ, ranks, last, sai)
 //   bwt_of_parse :379-467                    pfp_parse_bwt + pfp_parse_bwt_get, then OutFn(bwlast, ilist, bwsai)
 //   operator+= :194-263                      exact by construction: the merged parse IS the parse of the
@@ -91,24 +91,27 @@ template <typename Hasher = WangHash> struct PfParser {
     // stores parse information from a fasta file (pfparser.hpp:299-369); returns pos_
     size_t add_fasta(std::string fasta_fname)
     {
-        FastaReader rd(fasta_fname);
-        FastaRecord rec;
-#if !M64
-        uint64_t total_l = 0;
-#endif
         ensure_ctx();
         if (finalized_) { engine_check(ctx_, pfp_parse_reopen(ctx_), "pfp_parse_reopen"); finalized_ = false; }
-        while (rd.next(rec)) {
-            if (params_.store_docs) { doc_starts_.push_back((UIntType)n_fed_); doc_names_.push_back(rec.name); }
-#if !M64
-            if (total_l + rec.seq.size() > 0xFFFFFFFFull) { fprintf(stderr, "size: %lu\n", (unsigned long)(total_l + rec.seq.size())); die("input too long, please use 64-bit version"); }
-            total_l += rec.seq.size();
-#endif
-            // straight to the device; end_of_seq = 1 appends the w 'A's of :335-337 there
-            engine_check(ctx_, pfp_parse_feed(ctx_, (const uint8_t *)rec.seq.data(), rec.seq.size(), 1), "pfp_parse_feed");
-            n_fed_ += rec.seq.size() + params_.w;
-            nseqs_ += 1;
+        // the whole reading side lives in the engine (csrc/ingest.h): blocks of raw bytes are read on helper threads into
+        // page-locked memory, cross PCIe while the next ones are read, and are stripped of headers / line ends on the device;
+        // the w 'A's of :335-337 are appended there
+        pfp_ingest_info info;
+        const int st = pfp_parse_feed_fasta_file(ctx_, fasta_fname.c_str(), params_.store_docs ? PFP_FASTA_RECORDS : 0u, &info);
+        if (st == PFP_E_IO) die("failed to open file!\n");
+        engine_check(ctx_, st, "pfp_parse_feed_fasta_file");
+        if (params_.store_docs) {
+            uint64_t nd = 0; engine_check(ctx_, pfp_parse_docs(ctx_, &nd), "pfp_parse_docs");
+            for (uint64_t i = 0; i < nd; ++i) {
+                const char *nm = nullptr; uint64_t start = 0;
+                engine_check(ctx_, pfp_parse_doc_get(ctx_, i, &nm, &start), "pfp_parse_doc_get");
+                doc_starts_.push_back((UIntType)start); doc_names_.push_back(nm);
+            }
         }
+        if (params_.verbose) fprintf(stderr, "read %lu bytes, %lu records in %.3f s (reader %d, waited %.3f s for it)\n", (unsigned long)info.raw_bytes, (unsigned long)info.records,
+                                     info.total_ms * 1e-3, info.mode, info.read_wait_ms * 1e-3);
+        n_fed_ = info.n;
+        nseqs_ += info.records;
         return get_pos();
     }
 

@@ -68,11 +68,16 @@ int main(int argc, char **argv)
         } else if (pfbwtf::file_exists(prefix)) {      // parse_from_fasta, :264-270 -- a stand-alone parse of this operand
             fprintf(stderr, "generating parse for %s\n", prefix.data());
             sh.ctx = new_ctx(params);
-            pfbwtf::FastaReader rd(prefix); pfbwtf::FastaRecord rec; uint64_t fed = 0;
-            while (rd.next(rec)) {
-                if (store_docs) { doc_names.push_back(rec.name); doc_starts.push_back((parser_t::UIntType)(n_so_far + fed)); }
-                pfbwtf::engine_check(sh.ctx, pfp_parse_feed(sh.ctx, (const uint8_t *)rec.seq.data(), rec.seq.size(), 1), "pfp_parse_feed");
-                fed += rec.seq.size() + (uint64_t)w;
+            const int st = pfp_parse_feed_fasta_file(sh.ctx, prefix.c_str(), store_docs ? PFP_FASTA_RECORDS : 0u, nullptr);
+            if (st == PFP_E_IO) die("failed to open file!\n");
+            pfbwtf::engine_check(sh.ctx, st, "pfp_parse_feed_fasta_file");
+            if (store_docs) {
+                uint64_t nd = 0; pfbwtf::engine_check(sh.ctx, pfp_parse_docs(sh.ctx, &nd), "pfp_parse_docs");
+                for (uint64_t i = 0; i < nd; ++i) {
+                    const char *nm = nullptr; uint64_t start = 0;
+                    pfbwtf::engine_check(sh.ctx, pfp_parse_doc_get(sh.ctx, i, &nm, &start), "pfp_parse_doc_get");
+                    doc_names.push_back(nm); doc_starts.push_back((parser_t::UIntType)(n_so_far + start));
+                }
             }
             pfbwtf::engine_check(sh.ctx, pfp_parse_finalize_shard(sh.ctx, nullptr), "pfp_parse_finalize_shard");
         } else {

@@ -13,6 +13,7 @@ DEFAULT_LIB = os.path.join(os.path.dirname(_HERE), "lib", "libpfbwt_hip.so")
 
 PFP_OK = 0
 FLAG_U64, FLAG_NON_ACGT_TO_A, FLAG_SAI = 1, 2, 4
+E_ARG = -1
 E_INVALID_CHAR, E_TOO_LARGE, E_NOMEM, E_HIP, E_ONE_WORD, E_STATE, E_CORRUPT = -2, -3, -4, -5, -6, -7, -8
 
 
@@ -93,6 +94,9 @@ def load_library(path=None):
     L.pfp_profile_get.argtypes = [vp, i32, C.POINTER(C.c_char_p), C.POINTER(u64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.pfp_stage_ms.argtypes = [vp, C.POINTER(C.c_double)]
     L.pfp_debug_set.argtypes = [vp, C.c_char_p, C.c_longlong]
+    L.pfp_parse_feed_fasta.argtypes = [vp, vp, u64, C.c_uint, C.POINTER(u64)]
+    L.pfp_parse_fasta_records.argtypes = [vp, vp, vp]
+    L.pfp_parse_reserve.argtypes = [vp, u64]
     _libs[path] = L
     return L
 
@@ -146,6 +150,23 @@ class PfpContext:
     def feed(self, bases, end_of_seq=True):
         a = np.frombuffer(bases, dtype=np.uint8) if isinstance(bases, (bytes, bytearray, memoryview)) else np.ascontiguousarray(bases, dtype=np.uint8)
         self._check(self.L.pfp_parse_feed(self.h, _ptr(a) if a.size else None, a.size, 1 if end_of_seq else 0))
+
+    def reserve(self, text_bytes):
+        self._check(self.L.pfp_parse_reserve(self.h, int(text_bytes)))
+
+    def feed_fasta(self, raw, final=True, records=False, ptr=None, nbytes=None):
+        """raw FASTA bytes (bytes / uint8 array, or ptr + nbytes of host memory); returns the (raw offset, text position) pairs of
+        the records that start in this call when records=True"""
+        if ptr is None:
+            a = np.frombuffer(raw, dtype=np.uint8) if isinstance(raw, (bytes, bytearray, memoryview)) else np.ascontiguousarray(raw, dtype=np.uint8)
+            ptr, nbytes = a.ctypes.data, a.size
+        nrec = C.c_uint64(0)
+        self._check(self.L.pfp_parse_feed_fasta(self.h, C.c_void_p(ptr), int(nbytes), (1 if final else 0) | (2 if records else 0), C.byref(nrec)))
+        if not records:
+            return None
+        ro = np.empty(nrec.value, np.uint64); tp = np.empty(nrec.value, np.uint64)
+        self._check(self.L.pfp_parse_fasta_records(self.h, _ptr(ro), _ptr(tp)))
+        return ro, tp
 
     def feed_host_batch(self, host_ptr, count, length, stride):
         """`count` equal-length records in host memory (pinned: one strided DMA transfer; pageable: staging ring)"""
