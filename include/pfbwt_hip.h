@@ -185,6 +185,13 @@ int pfp_bwt_load(pfp_ctx *ctx, const uint8_t *dict, uint64_t dsize, const void *
 /* PrefixFreeBWT::generate_bwt_lcp pfbwt.hpp:96-194 (sort_dict_suffixes :206-223 = gsacak included)
  * fused with the CLI's out_fn src/pfbwt-f.cpp:298-328: BWT bytes, SA (row 0 := n), run samples. */
 int pfp_bwt_build(pfp_ctx *ctx, int want_sa, int want_rssa, pfp_bwt_sizes *out);
+/* The same, with the rows on their way to host memory while the emission is still running: host_bwt (n + 1 bytes, n from
+ * pfp_parse_sizes / pfp_text_length) and, with want_sa, host_sa (n + 1 U-wide values) are filled window by window -- the DMA
+ * transfer of a window overlaps the emission of the next (page-locked destinations run at the link's rate).  The run samples
+ * are fetched afterwards with pfp_bwt_get(ctx, NULL, NULL, ssa, esa) once out->r says how large they are. */
+int pfp_bwt_build_stream(pfp_ctx *ctx, int want_sa, int want_rssa, uint8_t *host_bwt, void *host_sa, pfp_bwt_sizes *out);
+/* PfParser::get_n(): bytes of text fed so far (the w 'A's behind every record included) */
+int pfp_text_length(pfp_ctx *ctx, uint64_t *n);
 /* Multi-GPU emission: every rank holds the same parse state (after pfp_merge_shards + pfp_parse_bwt) and emits
  * only output rows [nout*slice/nslices, nout*(slice+1)/nslices).  out->r counts the runs that START in the slice
  * (the sum over slices is r); pfp_bwt_get / pfp_bwt_device_ptrs then refer to the slice (slice_rows entries).
@@ -226,6 +233,12 @@ int pfp_sacak_int_u64(const uint32_t *s, uint64_t *SA, uint64_t n, uint64_t k);
  * terminator).  The engine itself never materialises LCP (pfp_bwt_build uses class heads instead). */
 int pfp_gsacak_u32(const uint8_t *s, uint32_t *SA, int32_t *LCP, int32_t *DA, uint32_t n);
 int pfp_gsacak_u64(const uint8_t *s, uint64_t *SA, int64_t *LCP, int64_t *DA, uint64_t n);
+
+/* Page-lock / release caller-owned host memory (hipHostRegister): sources of pfp_parse_feed_fasta / pfp_parse_feed_batch and
+ * destinations of pfp_bwt_build_stream / pfp_bwt_get then move at the link's rate, and a caller of this C ABI need not link
+ * the HIP runtime itself. */
+int pfp_host_register(void *p, uint64_t bytes);
+int pfp_host_unregister(void *p);
 
 /* library build info: "hip-gfx950" for the product library */
 const char *pfp_backend(void);

@@ -25,7 +25,7 @@ int pfp_stage_ms(pfp_ctx *ctx, double out[3]);
 /* Route and tuning switches of ONE context (tests force the routes that only huge inputs take; A/B measurements):
  *   verbose, seg_grid, seg_stage, sort_k (1 | 3), sort_no_table, class_sort_maxrange, dedup_table_log2, no_trigger_table,
  *   emit_chunk_rows, fill_subs, sample_cap (< 0: none), no_runaware, big_group_members (< 0: never), force_wide_rows,
- *   fasta_chunk_bytes.
+ *   fasta_chunk_bytes, ingest_block_bytes.
  * Returns PFP_E_ARG for an unknown key.  In a process started with PFP_TEST_HOOKS=1 pfp_create presets a new context from the
  * environment variables PFP_<KEY IN UPPER CASE>; without PFP_TEST_HOOKS=1 the environment is ignored (PFP_VERBOSE excepted,
  * which only prints). */
@@ -38,6 +38,11 @@ int pfp_debug_sort(pfp_ctx *ctx, uint64_t n, int bits, int reps, double *ms_out,
  * up (mod 2^64) to the checksum of the whole: tools/big_check_slices.py compares the sliced (multi-GPU) outputs of a
  * 32 Gbase build with the single-context output this way, without moving them off the device. */
 int pfp_debug_checksum(pfp_ctx *ctx, const void *d_buf, uint64_t bytes, uint64_t global_offset, uint64_t out[2]);
+
+/* sum of the 64-bit little-endian words of a device buffer (out[0]) and of word * (word index + 1) (out[1]), modulo 2^64; a
+ * trailing partial word is zero-padded.  bench.py checks the outputs that were streamed to host memory against the
+ * device-resident ones with it. */
+int pfp_debug_wordsum(pfp_ctx *ctx, const void *d_buf, uint64_t bytes, uint64_t out[2]);
 
 #ifdef __cplusplus
 }

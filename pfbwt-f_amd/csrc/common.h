@@ -61,6 +61,17 @@ struct Arena {
         hi -= b; if (cap - hi > peak_hi_bytes) peak_hi_bytes = cap - hi;
         return base + hi;
     }
+    // address space only: the caller commits what it is going to touch (commit_range) -- arrays sized for the worst case of
+    // which a fraction is used (run samples: r is not known in advance)
+    void *reserve_lo(size_t bytes)
+    {
+        size_t a = (lo + 255) & ~(size_t)255;
+        if (a + bytes > hi) { failed = true; want += bytes; return nullptr; }
+        lo = a + bytes;
+        return base + a;
+    }
+    bool commit_range(const void *p, size_t bytes) { const size_t o = (size_t)((const char *)p - base); return vm.commit(o, o + bytes); }
+    size_t offset_of(const void *p) const { return (size_t)((const char *)p - base); }
     size_t mark_hi() const { return hi; }
     void release_hi(size_t m) { hi = m; }
     size_t mark_lo() const { return lo; }
@@ -85,6 +96,7 @@ struct Tunables {
     int no_runaware = 0;               // -r with every row enumerated, as with a full SA
     long big_group_members = -2;       // -2: BIG_GROUP_MEMBERS (emit.h); < 0 otherwise: never take the sort route
     int force_wide_rows = 0;           // 64-bit row counters on small texts
+    uint64_t ingest_block_bytes = 0;   // block size of the file reader (0: 64 MiB)
     uint64_t fasta_chunk_bytes = 0;    // size of the raw-FASTA device buffers (0: 1 MiB ... 256 MiB by the size of the first call)
 };
 
@@ -148,6 +160,7 @@ struct pfp_ctx {
         uint32_t state = 2; bool started = false; uint64_t records = 0; // the stream's state machine (2 = at a line start)
         std::vector<uint64_t> rec_raw, rec_pos;                         // records that started in the last pfp_parse_feed_fasta call
     } fa;
+    uint8_t *h_bwt = nullptr; void *h_sa = nullptr;                      // pfp_bwt_build_stream: host destinations, filled window by window during the emission
     uint8_t *ing_buf[8] = {};                                           // page-locked blocks of the file reader (csrc/ingest.h)
     uint64_t ing_next_off = 0;
     std::vector<std::string> doc_names; std::vector<uint64_t> doc_starts;   // records of the last pfp_parse_feed_fasta_file(PFP_FASTA_RECORDS)

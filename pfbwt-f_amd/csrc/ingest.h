@@ -100,6 +100,7 @@ static int ingest_records(pfp_ctx *c, HostRecordReader &rd, bool want_docs, Inge
 static int ingest_file(pfp_ctx *c, const char *path, unsigned flags, IngestStats *st)
 {
     HostTimer timer;
+    const size_t BLK = (c->tun.ingest_block_bytes && c->tun.ingest_block_bytes < ING_BLOCK) ? (size_t)c->tun.ingest_block_bytes : ING_BLOCK;      // tests: many blocks on small files
     const bool want_docs = (flags & PFP_FASTA_RECORDS) != 0;
     const bool is_stdin = !strcmp(path, "-");
     c->doc_names.clear(); c->doc_starts.clear();
@@ -117,14 +118,14 @@ static int ingest_file(pfp_ctx *c, const char *path, unsigned flags, IngestStats
     for (int k = 0; k < ING_RING; ++k) if (!c->ing_buf[k]) PFP_HIP(c, hipHostMalloc((void **)&c->ing_buf[k], ING_BLOCK, hipHostMallocDefault));
     BlockRing ring;
     for (int k = 0; k < ING_RING; ++k) ring.buf[k] = c->ing_buf[k];
-    if (parallel) ring.nblocks = ((uint64_t)sb.st_size + ING_BLOCK - 1) / ING_BLOCK;
+    if (parallel) ring.nblocks = ((uint64_t)sb.st_size + BLK - 1) / BLK;
     auto fill = [&](uint64_t b, int slot) -> bool {      // reader side: block b into its slot; false at a read error
         size_t got = 0;
         if (parallel) {
-            const uint64_t o = b * ING_BLOCK, want = (uint64_t)sb.st_size - o < ING_BLOCK ? (uint64_t)sb.st_size - o : ING_BLOCK;
+            const uint64_t o = b * BLK, want = (uint64_t)sb.st_size - o < BLK ? (uint64_t)sb.st_size - o : BLK;
             while (got < want) { const ssize_t r = pread(fd, ring.buf[slot] + got, (size_t)(want - got), (off_t)(o + got)); if (r < 0) return false; if (r == 0) break; got += (size_t)r; }
         } else {
-            while (got < ING_BLOCK) { const int r = gzread(gzf, ring.buf[slot] + got, (unsigned)(ING_BLOCK - got < ((size_t)1 << 30) ? ING_BLOCK - got : ((size_t)1 << 30))); if (r < 0) return false; if (r == 0) break; got += (size_t)r; }
+            while (got < BLK) { const int r = gzread(gzf, ring.buf[slot] + got, (unsigned)(BLK - got < ((size_t)1 << 30) ? BLK - got : ((size_t)1 << 30))); if (r < 0) return false; if (r == 0) break; got += (size_t)r; }
         }
         ring.len[slot] = got;
         return true;
@@ -141,7 +142,7 @@ static int ingest_file(pfp_ctx *c, const char *path, unsigned flags, IngestStats
             const bool ok = fill(b, slot);
             std::lock_guard<std::mutex> lk(ring.mu);
             if (!ok) ring.fail = true;
-            else { ring.filled[slot] = b + 1; if (!parallel && ring.len[slot] < ING_BLOCK) ring.nblocks = b + 1; }      // a short block ends a stream
+            else { ring.filled[slot] = b + 1; if (!parallel && ring.len[slot] < BLK) ring.nblocks = b + 1; }      // a short block ends a stream
             ring.cv.notify_all();
             if (!ok) return;
         }
@@ -174,7 +175,7 @@ static int ingest_file(pfp_ctx *c, const char *path, unsigned flags, IngestStats
             off = fa_skip_preamble(c, p, l);
             if (first && off < l && p[off] == '@') { fastq = true; break; }     // FASTQ: on the host, record by record
             if (off < l) first = false;
-            if (off < l) { rc = fasta_buffers(c, ING_BLOCK); if (rc == PFP_OK) rc = fa_issue(c, p + off, l - off, (int)(b & 1)); if (rc != PFP_OK) break; }
+            if (off < l) { rc = fasta_buffers(c, BLK); if (rc == PFP_OK && f.rawcap < BLK) rc = PFP_E_ARG; if (rc == PFP_OK) rc = fa_issue(c, p + off, l - off, (int)(b & 1)); if (rc != PFP_OK) break; }
         }
         const uint64_t my_off = issued_next ? c->ing_next_off : off;
         issued_next = false;
@@ -185,10 +186,10 @@ static int ingest_file(pfp_ctx *c, const char *path, unsigned flags, IngestStats
                 if (l2) { rc = fa_issue(c, p2, l2, (int)((b + 1) & 1)); if (rc != PFP_OK) break; issued_next = true; c->ing_next_off = 0; }
             }
             f.rec_raw.clear(); f.rec_pos.clear();
-            rc = fa_process(c, l - my_off, (int)(b & 1), want_docs, b * ING_BLOCK + my_off, &st->records);
+            rc = fa_process(c, l - my_off, (int)(b & 1), want_docs, b * BLK + my_off, &st->records);
             if (rc != PFP_OK) break;
-            if (want_docs) ingest_names(c, p, l, b * ING_BLOCK, &name_open);
-        } else if (want_docs && name_open) ingest_names(c, p, l, b * ING_BLOCK, &name_open);
+            if (want_docs) ingest_names(c, p, l, b * BLK, &name_open);
+        } else if (want_docs && name_open) ingest_names(c, p, l, b * BLK, &name_open);
         { std::lock_guard<std::mutex> lk(ring.mu); ring.consumed = b + 1; }
         ring.cv.notify_all();
         ++b;
@@ -202,7 +203,7 @@ static int ingest_file(pfp_ctx *c, const char *path, unsigned flags, IngestStats
         if (parallel) { rd.fp = gzopen(path, "r"); if (!rd.fp) rc = PFP_E_IO; }
         else {      // the blocks the reader thread got to before it was stopped, in order; the stream goes on behind the last one if that was a full block
             bool more = true;
-            for (uint64_t blk = b;; ++blk) { const int slot = (int)(blk % ING_RING); if (ring.filled[slot] != blk + 1) break; head.insert(head.end(), ring.buf[slot], ring.buf[slot] + ring.len[slot]); more = ring.len[slot] == ING_BLOCK; }
+            for (uint64_t blk = b;; ++blk) { const int slot = (int)(blk % ING_RING); if (ring.filled[slot] != blk + 1) break; head.insert(head.end(), ring.buf[slot], ring.buf[slot] + ring.len[slot]); more = ring.len[slot] == BLK; }
             rd.pre = head.data(); rd.pre_len = head.size(); rd.fp = more ? gzf : nullptr;
         }
         c->fa.started = false; c->fa.state = 2; c->fa.records = 0;

@@ -80,7 +80,7 @@ static void reset_results(pfp_ctx *c)
 
 // ---- route / tuning switches (pfbwt_hip_dev.h) -----------------------------------------------------
 static const char *const tunable_names[] = {"verbose", "seg_grid", "seg_stage", "sort_k", "sort_no_table", "class_sort_maxrange", "dedup_table_log2", "no_trigger_table",
-                                            "emit_chunk_rows", "fill_subs", "sample_cap", "no_runaware", "big_group_members", "force_wide_rows", "fasta_chunk_bytes"};
+                                            "emit_chunk_rows", "fill_subs", "sample_cap", "no_runaware", "big_group_members", "force_wide_rows", "fasta_chunk_bytes", "ingest_block_bytes"};
 static int set_tunable(pfp_ctx *c, const char *key, long long v)
 {
     Tunables &t = c->tun;
@@ -99,6 +99,7 @@ static int set_tunable(pfp_ctx *c, const char *key, long long v)
     else if (!strcmp(key, "big_group_members")) t.big_group_members = (long)v;
     else if (!strcmp(key, "force_wide_rows")) t.force_wide_rows = (int)v;
     else if (!strcmp(key, "fasta_chunk_bytes")) t.fasta_chunk_bytes = v > 0 ? (uint64_t)v : 0;
+    else if (!strcmp(key, "ingest_block_bytes")) t.ingest_block_bytes = v > 0 ? (uint64_t)v : 0;
     else return PFP_E_ARG;
     return PFP_OK;
 }
@@ -358,18 +359,23 @@ int pfp_parse_reserve(pfp_ctx *c, uint64_t text_bytes)
     if (!c->text.live()) c->text_hint = text_bytes;      // sizes the address range of the text; ignored once text has been fed
     return PFP_OK;
 }
+static int ensure_copy_stream(pfp_ctx *c)
+{
+    auto &f = c->fa;
+    if (f.copy) return PFP_OK;
+    PFP_HIP(c, hipStreamCreateWithFlags(&f.copy, hipStreamNonBlocking));
+    for (int k = 0; k < 2; ++k) { PFP_HIP(c, hipEventCreateWithFlags(&f.ev_copied[k], hipEventDisableTiming)); PFP_HIP(c, hipEventCreateWithFlags(&f.ev_free[k], hipEventDisableTiming)); }
+    PFP_HIP(c, hipMalloc((void **)&f.d_tot, 64));
+    PFP_HIP(c, hipHostMalloc((void **)&f.h_tot, 64, hipHostMallocDefault));
+    PFP_HIP(c, hipMemsetAsync(f.d_tot, 0, 64, c->stream));
+    return PFP_OK;
+}
 static int fasta_buffers(pfp_ctx *c, uint64_t len)
 {
     auto &f = c->fa;
     size_t want = FA_RAW_MIN; while (want < FA_RAW_MAX && want < len) want <<= 1;
     if (c->tun.fasta_chunk_bytes) want = (size_t)(c->tun.fasta_chunk_bytes < 64 ? 64 : c->tun.fasta_chunk_bytes);      // tests: many chunks on small inputs
-    if (!f.copy) {
-        PFP_HIP(c, hipStreamCreateWithFlags(&f.copy, hipStreamNonBlocking));
-        for (int k = 0; k < 2; ++k) { PFP_HIP(c, hipEventCreateWithFlags(&f.ev_copied[k], hipEventDisableTiming)); PFP_HIP(c, hipEventCreateWithFlags(&f.ev_free[k], hipEventDisableTiming)); }
-        PFP_HIP(c, hipMalloc((void **)&f.d_tot, 64));
-        PFP_HIP(c, hipHostMalloc((void **)&f.h_tot, 64, hipHostMallocDefault));
-        PFP_HIP(c, hipMemsetAsync(f.d_tot, 0, 64, c->stream));
-    }
+    PFP_TRY(ensure_copy_stream(c));
     if (f.rawcap >= want || (f.rawcap && want < 4 * f.rawcap)) return PFP_OK;      // (a much larger call than the first one: take larger buffers once)
     PFP_HIP(c, hipStreamSynchronize(c->stream)); PFP_HIP(c, hipStreamSynchronize(f.copy));
     for (int k = 0; k < 2; ++k) { if (f.raw[k]) PFP_HIP(c, hipFree(f.raw[k])); f.raw[k] = nullptr; f.used[k] = false; }
@@ -1372,6 +1378,19 @@ template <typename SAT, typename EBT> static int emit_and_sample(pfp_ctx *c, Emi
         return PFP_OK;
     };
     auto bwt_of = [&](const Win &wn) -> uint8_t * { return bwtbuf + (wn.cs - wn.cl - (s0 - lead)); };   // position cs - cl
+    // pfp_bwt_build_stream: the rows of a finished window start their way to the host while the next window is emitted
+    std::vector<hipEvent_t> wev;
+    auto stream_out = [&](const Win &wn) -> int {
+        if (!c->h_bwt && !c->h_sa) return PFP_OK;
+        hipEvent_t e; PFP_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); wev.push_back(e);
+        PFP_HIP(c, hipEventRecord(e, c->stream));
+        PFP_HIP(c, hipStreamWaitEvent(c->fa.copy, e, 0));
+        const uint64_t rows = wn.ce - wn.cs;
+        if (c->h_bwt) PFP_HIP(c, hipMemcpyAsync(c->h_bwt + (wn.cs - s0), bwt_of(wn) + wn.cl, (size_t)rows, hipMemcpyDeviceToHost, c->fa.copy));
+        if (c->h_sa && sabuf) PFP_HIP(c, hipMemcpyAsync((char *)c->h_sa + (wn.cs - s0) * sizeof(SAT), sabuf + (wn.cs - (s0 - lead)), (size_t)rows * sizeof(SAT), hipMemcpyDeviceToHost, c->fa.copy));
+        return PFP_OK;
+    };
+    struct EvGuard { std::vector<hipEvent_t> &v; ~EvGuard() { for (auto e : v) (void)hipEventDestroy(e); } } evguard{wev};
     const uint64_t qcap = runaware ? maxq + 1 : maxrows + 1;     // parse rows kept per window
     bool bwt_done = false;
     if (want_rssa && !keep_sa) {
@@ -1390,7 +1409,7 @@ template <typename SAT, typename EBT> static int emit_and_sample(pfp_ctx *c, Emi
         if (cap > nrows) cap = nrows;
         if (c->tun.sample_cap < cap) cap = c->tun.sample_cap;   // tests: force the fallback
         SAT *samp = nullptr;
-        if (cap) PFP_ALLOC_LO(c, samp, SAT, 4 * cap + 4);
+        if (cap) { samp = (SAT *)c->arena.reserve_lo(sizeof(SAT) * (4 * cap + 4)); if (!samp) return PFP_E_NOMEM; }      // address space for the worst case; committed window by window
         SAT *ssa = samp, *esa = samp ? samp + 2 * cap : nullptr;
         SAT *esa_w = esa ? esa + 2 * lead : nullptr;      // slices > 0: the first run start of the slice closes a run of the previous slice
         uint64_t run_base = 0; bool overflow = cap == 0;
@@ -1400,11 +1419,13 @@ template <typename SAT, typename EBT> static int emit_and_sample(pfp_ctx *c, Emi
             const uint64_t rows = wn.ce - wn.cs;
             uint8_t *bw = bwt_of(wn) + wn.cl;                                // first row of the window
             PFP_TRY(emit_window(wn, bw - wn.cl, (SAT *)nullptr, qtmp, true));
+            PFP_TRY(stream_out(wn));
             const uint64_t ntiles = nblocks(rows, RUN_TILE);
             PFP_LAUNCH(c, K_RUNS, rows, k_run_tile_count, ntiles, (const uint8_t *)bw, rows, (int)wn.cl, tilecnt, rmask);
             PFP_TRY((device_scan<uint32_t, 0>(c, tilecnt, tilebase, ntiles, d_cnt)));
             uint32_t rc = 0; PFP_TRY(d2h_u32(c, d_cnt, &rc));
             if (!overflow && run_base + rc > cap) overflow = true;
+            if (!overflow && !(c->arena.commit_range(ssa + 2 * run_base, sizeof(SAT) * (2 * (size_t)rc + 4)) && c->arena.commit_range(esa + 2 * run_base, sizeof(SAT) * (2 * (size_t)rc + 8)))) overflow = true;
             if (!overflow) {
                 const bool last = wn.ce == total;
                 PFP_LAUNCH(c, K_SAMPLES, rows / 8 + (uint64_t)rc * 4 * sizeof(SAT), (k_sample_rows<SAT>), nblocks(ntiles, SR_TILES), (const uint16_t *)rmask, rows, (uint64_t)ntiles, (const uint32_t *)tilebase, wn.cs, run_base, total,
@@ -1416,7 +1437,11 @@ template <typename SAT, typename EBT> static int emit_and_sample(pfp_ctx *c, Emi
         }
         c->runs = run_base; c->esa_pairs = run_base - (s0 == 0 ? 1 : 0) + (s1 == total ? 1 : 0);
         c->arena.release_hi(hi_mark);
-        if (!overflow) { c->d_ssa = ssa; c->d_esa = esa; return PFP_OK; }
+        if (!overflow) {
+            c->d_ssa = ssa; c->d_esa = esa;
+            c->arena.release_lo(c->arena.offset_of(esa) + sizeof(SAT) * (2 * (size_t)run_base + 8));      // what lies behind the run ends that were written is free again
+            return PFP_OK;
+        }
         c->arena.release_lo(lo_mark);      // fall through: BWT bytes are complete, samples are redone with exact sizes
         bwt_done = true;
     } else {
@@ -1424,6 +1449,7 @@ template <typename SAT, typename EBT> static int emit_and_sample(pfp_ctx *c, Emi
     for (uint64_t ch = 0; ch < nchunks; ++ch) {
         const Win &wn = wins[(size_t)ch];
         PFP_TRY(emit_window(wn, bwt_of(wn), sabuf ? sabuf + (wn.cs - wn.cl - (s0 - lead)) : (SAT *)nullptr, (uint32_t *)nullptr, true));
+        PFP_TRY(stream_out(wn));
     }
     bwt_done = true;
     // runs (src/pfbwt-f.cpp:304-305): runs that start in this slice
@@ -1615,6 +1641,19 @@ static int bwt_build_body(pfp_ctx *c, int want_sa, int want_rssa, int slice, int
 }
 
 int pfp_bwt_build(pfp_ctx *c, int want_sa, int want_rssa, pfp_bwt_sizes *out) { return bwt_build_impl(c, want_sa, want_rssa, 0, 1, out); }
+int pfp_bwt_build_stream(pfp_ctx *c, int want_sa, int want_rssa, uint8_t *host_bwt, void *host_sa, pfp_bwt_sizes *out)
+{
+    if (!c || !host_bwt || (want_sa && !host_sa)) return PFP_E_ARG;
+    PFP_HIP(c, hipSetDevice(c->device));
+    PFP_TRY(ensure_copy_stream(c));
+    c->h_bwt = host_bwt; c->h_sa = want_sa ? host_sa : nullptr;
+    const int rc = bwt_build_impl(c, want_sa, want_rssa, 0, 1, out);
+    c->h_bwt = nullptr; c->h_sa = nullptr;
+    const hipError_t e = hipStreamSynchronize(c->fa.copy);               // the last windows' rows have arrived
+    if (rc == PFP_OK && e != hipSuccess) { c->hip_err = (int)e; return PFP_E_HIP; }
+    return rc;
+}
+int pfp_text_length(pfp_ctx *c, uint64_t *n) { if (!c || !n) return PFP_E_ARG; *n = c->n; return PFP_OK; }
 int pfp_bwt_build_slice(pfp_ctx *c, int want_sa, int want_rssa, int slice, int nslices, pfp_bwt_sizes *out, uint64_t *slice_begin, uint64_t *slice_rows, uint64_t *esa_pairs)
 {
     int rc = bwt_build_impl(c, want_sa, want_rssa, slice, nslices, out);
@@ -1777,6 +1816,40 @@ int pfp_debug_checksum(pfp_ctx *c, const void *d_buf, uint64_t bytes, uint64_t g
     out[0] = h[0]; out[1] = h[1];
     return PFP_OK;
 }
+
+// sum of the 64-bit words of a device buffer and sum of word * (index + 1), modulo 2^64 (bench.py compares the outputs that
+// reached host memory with the device-resident ones this way; bytes behind the last whole word count as a zero-padded word)
+__global__ __launch_bounds__(BLOCK) void k_wordsum(const uint8_t *p, uint64_t bytes, unsigned long long *out)
+{
+    __shared__ unsigned long long red[4];
+    const uint64_t nw = (bytes + 7) / 8;
+    unsigned long long a = 0, b = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < nw; i += (uint64_t)gridDim.x * BLOCK) {
+        unsigned long long v = 0;
+        if (8 * i + 8 <= bytes) v = ld8(p + 8 * i); else for (uint64_t k = 0; 8 * i + k < bytes; ++k) v |= (unsigned long long)p[8 * i + k] << (8 * k);
+        a += v; b += v * (i + 1);
+    }
+    unsigned long long ta, tb;
+    (void)block_excl_sum(a, red, &ta); (void)block_excl_sum(b, red, &tb);
+    if (threadIdx.x == 0) { atomicAdd(&out[0], ta); atomicAdd(&out[1], tb); }
+}
+int pfp_debug_wordsum(pfp_ctx *c, const void *d_buf, uint64_t bytes, uint64_t out[2])
+{
+    if (!c || (!d_buf && bytes) || !out) return PFP_E_ARG;
+    PFP_HIP(c, hipSetDevice(c->device));
+    unsigned long long *d_out; PFP_HIP(c, hipMalloc((void **)&d_out, 16));
+    PFP_HIP(c, hipMemsetAsync(d_out, 0, 16, c->stream));
+    if (bytes) PFP_LAUNCH(c, K_MISC, bytes, k_wordsum, 4096, (const uint8_t *)d_buf, bytes, d_out);
+    unsigned long long h[2];
+    PFP_HIP(c, hipMemcpyAsync(h, d_out, 16, hipMemcpyDeviceToHost, c->stream));
+    PFP_HIP(c, hipStreamSynchronize(c->stream));
+    PFP_HIP(c, hipFree(d_out));
+    out[0] = h[0]; out[1] = h[1];
+    return PFP_OK;
+}
+// page-locked host memory for the callers of pfp_bwt_build_stream / pfp_parse_feed_fasta (they need not link the HIP runtime)
+int pfp_host_register(void *p, uint64_t bytes) { if (!p || !bytes) return PFP_E_ARG; if (hipHostRegister(p, (size_t)bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return PFP_E_HIP; } return PFP_OK; }
+int pfp_host_unregister(void *p) { if (!p) return PFP_E_ARG; if (hipHostUnregister(p) != hipSuccess) { (void)hipGetLastError(); return PFP_E_HIP; } return PFP_OK; }
 
 // ---- development aid: time the pair sort on pseudo-random keys (no product path calls this) ----------
 __global__ __launch_bounds__(BLOCK) void k_debug_fill(uint64_t *keys, uint32_t *vals, uint64_t n, int bits, uint64_t seed)

@@ -44,6 +44,10 @@ class ShardView(C.Structure):
 _libs = {}
 
 
+class IngestInfo(C.Structure):
+    _fields_ = [("raw_bytes", C.c_uint64), ("records", C.c_uint64), ("n", C.c_uint64), ("read_wait_ms", C.c_double), ("total_ms", C.c_double), ("mode", C.c_int)]
+
+
 def load_library(path=None):
     path = os.path.abspath(path or os.environ.get("PFBWT_HIP_LIB") or DEFAULT_LIB)   # PFBWT_HIP_LIB: another build of the same library
     if path in _libs:
@@ -97,6 +101,14 @@ def load_library(path=None):
     L.pfp_parse_feed_fasta.argtypes = [vp, vp, u64, C.c_uint, C.POINTER(u64)]
     L.pfp_parse_fasta_records.argtypes = [vp, vp, vp]
     L.pfp_parse_reserve.argtypes = [vp, u64]
+    L.pfp_parse_feed_fasta_file.argtypes = [vp, C.c_char_p, C.c_uint, C.POINTER(IngestInfo)]
+    L.pfp_bwt_build_stream.argtypes = [vp, i32, i32, vp, vp, C.POINTER(BwtSizes)]
+    L.pfp_text_length.argtypes = [vp, C.POINTER(u64)]
+    L.pfp_host_register.argtypes = [vp, u64]
+    L.pfp_host_unregister.argtypes = [vp]
+    L.pfp_debug_wordsum.argtypes = [vp, vp, u64, C.POINTER(u64)]
+    L.pfp_parse_docs.argtypes = [vp, C.POINTER(u64)]
+    L.pfp_parse_doc_get.argtypes = [vp, u64, C.POINTER(C.c_char_p), C.POINTER(u64)]
     _libs[path] = L
     return L
 
@@ -167,6 +179,28 @@ class PfpContext:
         ro = np.empty(nrec.value, np.uint64); tp = np.empty(nrec.value, np.uint64)
         self._check(self.L.pfp_parse_fasta_records(self.h, _ptr(ro), _ptr(tp)))
         return ro, tp
+
+    def feed_fasta_file(self, path, records=False):
+        info = IngestInfo()
+        self._check(self.L.pfp_parse_feed_fasta_file(self.h, os.fsencode(path), 2 if records else 0, C.byref(info)))
+        return info
+
+    def text_length(self):
+        n = C.c_uint64(0); self._check(self.L.pfp_text_length(self.h, C.byref(n))); return n.value
+
+    def bwt_build_stream(self, host_bwt_ptr, host_sa_ptr=None, rssa=False):
+        """emission with the rows streamed to host memory (n + 1 bytes at host_bwt_ptr, n + 1 U-wide values at host_sa_ptr)"""
+        b = BwtSizes()
+        self._check(self.L.pfp_bwt_build_stream(self.h, 1 if host_sa_ptr else 0, 1 if rssa else 0, C.c_void_p(host_bwt_ptr), C.c_void_p(host_sa_ptr) if host_sa_ptr else None, C.byref(b)))
+        self.bsizes, self._want, self._rows, self.esa_pairs = b, (bool(host_sa_ptr), bool(rssa)), b.nout, b.r
+        return b
+
+    def samples_get(self, out=None):
+        """the run samples of the last build: (ssa, esa) as 2*r U-wide arrays (into out["ssa"] / out["esa"] if given)"""
+        b = self.bsizes
+        ssa = out["ssa"] if out else np.empty(2 * b.r, self.udt); esa = out["esa"] if out else np.empty(2 * b.r, self.udt)
+        self._check(self.L.pfp_bwt_get(self.h, None, None, _ptr(ssa), _ptr(esa)))
+        return ssa, esa
 
     def feed_host_batch(self, host_ptr, count, length, stride):
         """`count` equal-length records in host memory (pinned: one strided DMA transfer; pageable: staging ring)"""

@@ -230,6 +230,9 @@ static inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
 static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned = 0) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 template <typename T> static inline hipError_t hipHostMalloc(T **p, size_t n, unsigned f = 0) { return hipHostMalloc((void **)p, n, f); }
 static inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
+#define hipHostRegisterDefault 0
+static inline hipError_t hipHostRegister(void *, size_t, unsigned) { return hipSuccess; }
+static inline hipError_t hipHostUnregister(void *) { return hipSuccess; }
 static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t = 0) { memmove(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemset(void *d, int v, size_t n) { memset(d, v, n); return hipSuccess; }

@@ -3,6 +3,7 @@ kseq_read + PfParser::add_fasta (include/kseq.h:178-228, include/pfparser.hpp:30
 The check is end to end: every array of the build over the raw bytes == the oracle's over the records a plain Python
 restatement of kseq's record rules extracts (the BWT determines the text), plus the (header offset, record start) pairs.
 * CPU: through tests/emu.  * GPU: the product library."""
+import ctypes as C
 import os
 import subprocess
 import numpy as np
@@ -114,6 +115,58 @@ def test_fasta_ingest_emu(emu_factory):
     run_cases(emu_factory, 1)
 
 
+def check_file_ingest(factory, tmp, block_bytes):
+    """pfp_parse_feed_fasta_file: plain (parallel pread), gzip and FASTQ inputs, two files in a row, docs"""
+    import gzip
+    rng = np.random.default_rng(7)
+    raw1 = random_fasta(rng, 9, 5000, crlf=True)
+    raw2 = random_fasta(rng, 5, 3000, preamble=False, trailing_newline=False)
+    fq = b"".join(b"@q%d desc\n%s\n+\n%s\n" % (i, bytes(rng.choice(list(b"ACGT"), 80 + 13 * i).astype(np.uint8)), b"I" * (80 + 13 * i)) for i in range(12))
+    files = {"a.fa": raw1, "b.fa.gz": gzip.compress(raw2), "c.fq": fq, "d.fq.gz": gzip.compress(fq)}
+    for nm, data in files.items():
+        open(os.path.join(tmp, nm), "wb").write(data)
+    fq_recs = [(0, b"q%d" % i, fq.split(b"\n")[4 * i + 1]) for i in range(12)]
+    for order in (("a.fa", "b.fa.gz"), ("b.fa.gz", "a.fa"), ("c.fq", "a.fa"), ("d.fq.gz",)):
+        recs = []
+        for nm in order:
+            recs += fq_recs if nm.startswith(("c.", "d.")) else kseq_model(raw1 if nm == "a.fa" else raw2)
+        seqs = [s for _, _, s in recs]
+        c = factory(w=6, p=11, u64=True, sai=True)
+        c.debug_set(ingest_block_bytes=block_bytes, fasta_chunk_bytes=max(64, block_bytes))
+        names, starts, nrec = [], [], 0
+        for nm in order:
+            info = c.feed_fasta_file(os.path.join(tmp, nm), records=True)
+            nrec += info.records
+            cnt = C.c_uint64(0); c._check(c.L.pfp_parse_docs(c.h, C.byref(cnt)))
+            for i in range(cnt.value):
+                pn, ps = C.c_char_p(), C.c_uint64(0)
+                c._check(c.L.pfp_parse_doc_get(c.h, i, C.byref(pn), C.byref(ps)))
+                names.append(pn.value); starts.append(ps.value)
+        assert nrec == len(recs) and names == [n for _, n, _ in recs], (order, names[:4])
+        acc, want = 0, []
+        for s_ in seqs:
+            want.append(acc); acc += len(s_) + 6
+        assert starts == want and c.text_length() == acc
+        sz = c.finalize(); c.parse_bwt()
+        hb = np.zeros(sz.n + 1, np.uint8)
+        b = c.bwt_build_stream(hb.ctypes.data, None, rssa=True)
+        ssa, esa = c.samples_get()
+        ref = oracle_run(seqs, w=6, p=11, U=8)
+        assert compare({"bwt": hb, "ssa": ssa, "esa": esa, "r": b.r, "n": sz.n}, ref, 8, names=("bwt", "ssa", "esa")) == [], order
+        c.close()
+    import pfbwt_hip
+    c = factory(w=6, p=11, u64=True, sai=True)
+    with pytest.raises(pfbwt_hip.PfpError) as e:
+        c.feed_fasta_file(os.path.join(tmp, "does-not-exist.fa"))
+    assert e.value.status == -9
+    c.close()
+
+
+def test_file_ingest_emu(emu_factory, tmp_path):
+    for blk in (4096, 70000):
+        check_file_ingest(emu_factory, str(tmp_path), blk)
+
+
 def fastq_like_is_rejected(factory):
     import pfbwt_hip
     c = factory(w=10, p=100, u64=True, sai=True)
@@ -134,6 +187,12 @@ def test_fastq_like_input_is_rejected_emu(emu_factory):
 def test_fasta_ingest_gpu(gpu_ctx_factory):
     run_cases(gpu_ctx_factory, 8)
     fastq_like_is_rejected(gpu_ctx_factory)
+
+
+@pytest.mark.gpu
+def test_file_ingest_gpu(gpu_ctx_factory, tmp_path):
+    for blk in (4096, 1 << 20, 0):
+        check_file_ingest(gpu_ctx_factory, str(tmp_path), blk)
 
 
 @pytest.mark.gpu
