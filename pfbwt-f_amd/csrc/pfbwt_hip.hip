@@ -436,8 +436,9 @@ static int fa_process(pfp_ctx *c, uint64_t len, int slot, bool want_recs, uint64
     if (d_rr) {
         const size_t b = f.rec_raw.size();
         f.rec_raw.resize(b + hdr); f.rec_pos.resize(b + hdr);
-        PFP_HIP(c, hipMemcpy(f.rec_raw.data() + b, d_rr, hdr * 8, hipMemcpyDeviceToHost));
-        PFP_HIP(c, hipMemcpy(f.rec_pos.data() + b, d_rp, hdr * 8, hipMemcpyDeviceToHost));
+        PFP_HIP(c, hipMemcpyAsync(f.rec_raw.data() + b, d_rr, hdr * 8, hipMemcpyDeviceToHost, c->stream));      // (the context's stream does not synchronise with the null stream)
+        PFP_HIP(c, hipMemcpyAsync(f.rec_pos.data() + b, d_rp, hdr * 8, hipMemcpyDeviceToHost, c->stream));
+        PFP_HIP(c, hipStreamSynchronize(c->stream));
         PFP_HIP(c, hipFree(d_rr));
         for (size_t i = b; i < b + hdr; ++i) f.rec_raw[i] += rec_base;
     }
