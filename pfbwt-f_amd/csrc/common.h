@@ -87,6 +87,7 @@ struct Tunables {
     int seg_stage = 1;                 // global radix scatter staged through LDS
     int sort_k = 0;                    // 1: plain doubling in every refinement round, 3: three ranks in every round but the run round
     int sort_no_table = 0;             // the K = 3 rounds follow the chains themselves
+    int sort_no_group = 0;             // the refinement rounds sort full keys, never group equal keys first
     uint32_t class_sort_maxrange = 0;  // smaller LDS class-sort ranges (reaches the large-class route on small inputs)
     int dedup_table_log2 = 0;          // a first phrase table that overflows
     int no_trigger_table = 0;          // trigger test by hashing every window

@@ -132,7 +132,7 @@ def check_file_ingest(factory, tmp, block_bytes):
             recs += fq_recs if nm.startswith(("c.", "d.")) else kseq_model(raw1 if nm == "a.fa" else raw2)
         seqs = [s for _, _, s in recs]
         c = factory(w=6, p=11, u64=True, sai=True)
-        c.debug_set(ingest_block_bytes=block_bytes, fasta_chunk_bytes=max(64, block_bytes))
+        c.debug_set(ingest_block_bytes=block_bytes, fasta_chunk_bytes=block_bytes)
         names, starts, nrec = [], [], 0
         for nm in order:
             info = c.feed_fasta_file(os.path.join(tmp, nm), records=True)
