@@ -39,6 +39,12 @@ int pfp_debug_sort(pfp_ctx *ctx, uint64_t n, int bits, int reps, double *ms_out,
  * 32 Gbase build with the single-context output this way, without moving them off the device. */
 int pfp_debug_checksum(pfp_ctx *ctx, const void *d_buf, uint64_t bytes, uint64_t global_offset, uint64_t out[2]);
 
+/* Order check of the run samples against the resident text, at any size: .esa[k] and .ssa[k + 1] are adjacent BWT rows, so
+ * T[esa[k].sa ..] < T[ssa[k + 1].sa ..] must hold for all r - 1 pairs (the suffixes are compared byte by byte on the device; the
+ * engine's own sort results are not consulted).  Needs the state left by pfp_bwt_build(want_rssa = 1) of a context that still
+ * holds its text.  out[0] pairs checked, out[1] order violations, out[2] pairs whose rows are not adjacent, out[3] longest and
+ * out[4] sum of the common prefixes. */
+int pfp_debug_check_sample_order(pfp_ctx *ctx, uint64_t out[5]);
 /* sum of the 64-bit little-endian words of a device buffer (out[0]) and of word * (word index + 1) (out[1]), modulo 2^64; a
  * trailing partial word is zero-padded.  bench.py checks the outputs that were streamed to host memory against the
  * device-resident ones with it. */

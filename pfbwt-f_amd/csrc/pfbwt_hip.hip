@@ -1849,6 +1849,55 @@ int pfp_debug_wordsum(pfp_ctx *c, const void *d_buf, uint64_t bytes, uint64_t ou
     out[0] = h[0]; out[1] = h[1];
     return PFP_OK;
 }
+// Full-size order check that does not lean on the engine's own sorting: .esa[k] and .ssa[k + 1] are ADJACENT
+// rows of the BWT matrix (a run ends, the next one starts), so the suffix at esa[k].sa must be lexicographically smaller than the
+// suffix at ssa[k + 1].sa -- compared directly on the text that is still resident (its w Dollars stand for the terminator, which is
+// smaller than every base).  One thread per pair, eight bytes per step.  out: pairs checked, order violations, pairs whose rows
+// are not adjacent, longest common prefix seen, sum of the common prefixes.
+extern "C++" {
+template <typename SAT> __global__ __launch_bounds__(BLOCK) void k_check_sample_order(const uint8_t *X, uint64_t n, const SAT *ssa, const SAT *esa, uint64_t r, unsigned long long *out)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (k + 1 >= r) return;
+    const uint64_t ra = esa[2 * k], a = esa[2 * k + 1], rb = ssa[2 * k + 2], b = ssa[2 * k + 3];
+    if (ra + 1 != rb) atomicAdd(&out[2], 1ULL);
+    uint64_t h = 0; bool ok = false;
+    for (;;) {
+        const uint64_t pa = a + h, pb = b + h;
+        if (pa > n || pb > n) break;                                        // (cannot happen: the Dollar at n ends every comparison)
+        const uint64_t va = ld8(X + pa), vb = ld8(X + pb);                  // the buffer holds w Dollars and slack behind the text
+        if (va != vb) {
+            const int sh = (__ffsll((long long)(va ^ vb)) - 1) & ~7;
+            const uint64_t q = (uint64_t)sh >> 3;
+            if (pa + q > n || pb + q > n) break;                            // the difference lies behind the terminator of one of them: not an order
+            ok = ((va >> sh) & 0xFF) < ((vb >> sh) & 0xFF); h += q;
+            break;
+        }
+        h += 8;
+    }
+    if (!ok) atomicAdd(&out[1], 1ULL);
+    atomicAdd(&out[0], 1ULL); atomicMax(&out[3], (unsigned long long)h); atomicAdd(&out[4], (unsigned long long)h);
+}
+}
+int pfp_debug_check_sample_order(pfp_ctx *c, uint64_t out[5])
+{
+    if (!c || !out) return PFP_E_ARG;
+    if (c->stage < 3 || !c->d_ssa || !c->d_esa || !c->tb || c->tb_n != c->n || c->slice_rows != c->nout) return PFP_E_STATE;      // needs the text and the whole output's samples
+    PFP_HIP(c, hipSetDevice(c->device));
+    unsigned long long *d_out; PFP_HIP(c, hipMalloc((void **)&d_out, 40));
+    PFP_HIP(c, hipMemsetAsync(d_out, 0, 40, c->stream));
+    const uint64_t r = c->runs;
+    if (r > 1) {
+        if (c->flags & PFP_FLAG_U64) PFP_LAUNCH(c, K_MISC, r * 64, (k_check_sample_order<uint64_t>), nblocks(r, BLOCK), (const uint8_t *)c->tb + 16, c->n, (const uint64_t *)c->d_ssa, (const uint64_t *)c->d_esa, r, d_out);
+        else PFP_LAUNCH(c, K_MISC, r * 64, (k_check_sample_order<uint32_t>), nblocks(r, BLOCK), (const uint8_t *)c->tb + 16, c->n, (const uint32_t *)c->d_ssa, (const uint32_t *)c->d_esa, r, d_out);
+    }
+    unsigned long long h[5];
+    PFP_HIP(c, hipMemcpyAsync(h, d_out, 40, hipMemcpyDeviceToHost, c->stream));
+    PFP_HIP(c, hipStreamSynchronize(c->stream));
+    PFP_HIP(c, hipFree(d_out));
+    for (int i = 0; i < 5; ++i) out[i] = h[i];
+    return PFP_OK;
+}
 // page-locked host memory for the callers of pfp_bwt_build_stream / pfp_parse_feed_fasta (they need not link the HIP runtime)
 int pfp_host_register(void *p, uint64_t bytes) { if (!p || !bytes) return PFP_E_ARG; if (hipHostRegister(p, (size_t)bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return PFP_E_HIP; } return PFP_OK; }
 int pfp_host_unregister(void *p) { if (!p) return PFP_E_ARG; if (hipHostUnregister(p) != hipSuccess) { (void)hipGetLastError(); return PFP_E_HIP; } return PFP_OK; }

@@ -107,6 +107,7 @@ def load_library(path=None):
     L.pfp_host_register.argtypes = [vp, u64]
     L.pfp_host_unregister.argtypes = [vp]
     L.pfp_debug_wordsum.argtypes = [vp, vp, u64, C.POINTER(u64)]
+    L.pfp_debug_check_sample_order.argtypes = [vp, C.POINTER(u64)]
     L.pfp_parse_docs.argtypes = [vp, C.POINTER(u64)]
     L.pfp_parse_doc_get.argtypes = [vp, u64, C.POINTER(C.c_char_p), C.POINTER(u64)]
     _libs[path] = L
@@ -194,6 +195,12 @@ class PfpContext:
         self._check(self.L.pfp_bwt_build_stream(self.h, 1 if host_sa_ptr else 0, 1 if rssa else 0, C.c_void_p(host_bwt_ptr), C.c_void_p(host_sa_ptr) if host_sa_ptr else None, C.byref(b)))
         self.bsizes, self._want, self._rows, self.esa_pairs = b, (bool(host_sa_ptr), bool(rssa)), b.nout, b.r
         return b
+
+    def check_sample_order(self):
+        """adjacent-row order check of the run samples on the device (include/pfbwt_hip_dev.h)"""
+        o = (C.c_uint64 * 5)()
+        self._check(self.L.pfp_debug_check_sample_order(self.h, o))
+        return {"pairs": int(o[0]), "order_violations": int(o[1]), "rows_not_adjacent": int(o[2]), "max_lcp": int(o[3]), "mean_lcp": (int(o[4]) / int(o[0])) if o[0] else 0.0}
 
     def samples_get(self, out=None):
         """the run samples of the last build: (ssa, esa) as 2*r U-wide arrays (into out["ssa"] / out["esa"] if given)"""
