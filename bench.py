@@ -48,9 +48,26 @@ WORKLOADS = {
     # the north-star shape: 1000 haplotypes x 32 Mbase = 32 Gbase on ONE GPU, -r (BWT + run-length sampled SA, a full
     # .sa of 32 G x 8 B does not fit), pfbwt-f64 path.
     "S-32G": (32_000_000, 1000, 1000, (0, 0, 0, 0), 10, 100, True),
+    # configs[3] size on one GPU: 1000 haplotypes of chr22 length, -r
+    "S-50G": (50_818_468, 1000, 1000, (0, 0, 0, 0), 10, 100, True),
+    # configs[2] stand-in: one GRCh38-sized sequence (3.1 Gbase, 35 Mbp of N in two runs), -s -r, pfbwt-f64 path
+    "S-3G": (3_100_000_000, 1, 38, (500_000_000, 30_000_000, 2_000_000_000, 5_000_000), 10, 100, True),
 }
-SAMPLES_ONLY = {"S-32G"}          # workloads run with -r instead of -s
-CPU_SAMPLE_HAPLOTYPES = 10        # S-32G: the CPU baseline / oracle parity run covers the first 10 haplotypes
+OUTPUTS = {"S-32G": (False, True), "S-50G": (False, True), "S-3G": (True, True)}      # (-s, -r); default: -s only
+CPU_SAMPLE_HAPLOTYPES = 10        # large collections: the CPU baseline / oracle parity run covers the first 10 haplotypes
+CPU_SAMPLE_BASES = 100_000_000    # one huge sequence: its first 100 Mbase (~20 s of CPU work)
+
+
+def outputs_of(workload):
+    return OUTPUTS.get(workload, (True, False))
+
+
+def out_names(want_sa, want_rssa):
+    return ("bwt",) + (("sa",) if want_sa else ()) + (("ssa", "esa") if want_rssa else ())
+
+
+def oracle_mode(want_sa, want_rssa):
+    return ["-s"] * want_sa + ["-r"] * want_rssa
 PARITY_ENV = {"PFP_TEST_HOOKS": "1", "PFP_FORCE_WIDE_ROWS": "1", "PFP_EMIT_CHUNK_ROWS": str(1 << 25)}     # S-32G parity child: k_*<u64, u64>, ~10 windows
 
 KERNEL_SYMBOL = {"emit": "pfp::k_emit<", "fill": "pfp::k_fill<", "radix_scatter": "pfp::k_seg_scatter<unsigned long", "radix_hist": "pfp::k_seg_hist<unsigned long",
@@ -86,7 +103,7 @@ def sha_file(path):
     return h.hexdigest()
 
 
-def cpu_baseline(seqs, w, p, u64, mode="-s"):
+def cpu_baseline(seqs, w, p, u64, mode=("-s",)):
     """Time oracle/pfbwt_oracle (CPU restatement, one thread, pinned to one core) on the input; returns (dict, digests)."""
     exe = os.path.join(ROOT, "oracle", "pfbwt_oracle")
     if not os.path.exists(exe):
@@ -99,7 +116,8 @@ def cpu_baseline(seqs, w, p, u64, mode="-s"):
             for k in range(0, s.size, 60000):
                 f.write(s[k:k + 60000].tobytes()); f.write(b"\n")
     n = sum(int(s.size) + w for s in seqs)
-    cmd = [exe, mode, "--u64" if u64 else "--u32", "-w", str(w), "-p", str(p), "-o", os.path.join(tmp, "out"), fa]
+    mode = list(mode)
+    cmd = [exe] + mode + ["--u64" if u64 else "--u32", "-w", str(w), "-p", str(p), "-o", os.path.join(tmp, "out"), fa]
     core = None
     try:        # the reference is single-threaded: one host core of the GPU box
         core = sorted(os.sched_getaffinity(0))[-1]
@@ -120,7 +138,36 @@ def cpu_baseline(seqs, w, p, u64, mode="-s"):
             _, name, sec = line.split("\t")
             stages[name] = float(sec.rstrip("s"))
     compute = sum(v for k, v in stages.items() if k != "reading input")
-    dig = {ext: sha_file(os.path.join(tmp, "out." + ext)) for ext in (("bwt", "sa") if mode == "-s" else ("bwt", "ssa", "esa"))}
+    # the pieces of the REFERENCE that build here from its own sources (oracle/Makefile ref; src/pfbwt-f.cpp itself needs sdsl-lite):
+    # merge_pfp64 --parse-bwt = PfParser::add_fasta + finalize + bwt_of_parse (src/merge_pfp.cpp:115-170), gsacak = the dictionary
+    # suffix sort + LCP of pfbwt.hpp:211 -- timed on the same sample, pinned to the same core, beside the port's stages
+    ref_pieces = None
+    mp = os.path.join(ROOT, "oracle", "_ref", "merge_pfp64"); gs = os.path.join(ROOT, "oracle", "_ref", "libgsacak64.so")
+    if os.path.exists(mp) and os.path.exists(gs):
+        try:
+            pin = ["taskset", "-c", str(core)] if core is not None else []
+            t0 = time.time()
+            pr2 = subprocess.run(pin + [mp, "-w", str(w), "-p", str(p), "-s", "--parse-bwt", "-o", os.path.join(tmp, "ref"), fa], capture_output=True, text=True)
+            t_parse = time.time() - t0
+            if pr2.returncode != 0:
+                raise RuntimeError(pr2.stderr[-300:])
+            code = ("import ctypes,sys,time,numpy as np\n"
+                    "L=ctypes.CDLL(sys.argv[1]); d=np.fromfile(sys.argv[2],np.uint8); n=d.size\n"
+                    "SA=np.empty(n,np.uint64); LCP=np.empty(n,np.int64)\n"
+                    "L.gsacak.argtypes=[ctypes.c_void_p]*4+[ctypes.c_uint64]; t=time.time()\n"
+                    "L.gsacak(d.ctypes.data,SA.ctypes.data,LCP.ctypes.data,None,n); print(n, time.time()-t)\n")
+            pr3 = subprocess.run(pin + [sys.executable, "-c", code, gs, os.path.join(tmp, "ref.dict")], capture_output=True, text=True)
+            if pr3.returncode != 0:
+                raise RuntimeError(pr3.stderr[-300:])
+            dn, t_gsa = pr3.stdout.split()
+            port_parse = sum(v for k, v in stages.items() if k.startswith(("parsing", "writing dict", "ranking")))
+            ref_pieces = {"merge_pfp64 --parse-bwt (reference parse + parse-BWT, FASTA read and file writes included) s": round(t_parse, 2),
+                          "port, same stages s": round(port_parse + stages.get("reading input", 0.0), 2),
+                          "gsacak (reference dictionary gSA + LCP) s": round(float(t_gsa), 2), "dictionary bytes": int(dn),
+                          "parse Mbases/s reference": round(n / t_parse / 1e6, 1), "gsacak Mchars/s": round(int(dn) / float(t_gsa) / 1e6, 2)}
+        except Exception as e:
+            ref_pieces = {"error": repr(e)}
+    dig = {ext: sha_file(os.path.join(tmp, "out." + ext)) for ext in out_names("-s" in mode, "-r" in mode)}
     for fn in os.listdir(tmp):
         os.remove(os.path.join(tmp, fn))
     os.rmdir(tmp)
@@ -131,25 +178,24 @@ def cpu_baseline(seqs, w, p, u64, mode="-s"):
                 cpu_model = line.split(":", 1)[1].strip(); break
     except OSError:
         pass
-    return ({"value": n / compute / 1e9, "unit": "Gbases/s", "cores": 1, "kind": "port",
+    return ({"value": n / compute / 1e9, "unit": "Gbases/s", "cores": 1, "kind": "port", "reference_pieces_same_sample": ref_pieces,
              "sample": "n=%d bases through oracle/pfbwt_oracle %s, one thread%s; stage seconds %s; wall incl. FASTA read + file writes %.1f s; host has %d cores (%s)"
-                       % (n, mode, (" pinned with taskset -c %d" % core) if core is not None else "", json.dumps(stages), wall, os.cpu_count(), cpu_model)}, dig)
+                       % (n, " ".join(mode), (" pinned with taskset -c %d" % core) if core is not None else "", json.dumps(stages), wall, os.cpu_count(), cpu_model)}, dig)
 
 
 def parity_child(a):
-    """child process of the parity leg: the engine on the first `--parity-child` haplotypes of the workload, under the
-    environment the parent chose; prints the sha256 of its output files as one JSON line"""
+    """child process of the parity leg: the engine on the CPU sample of the workload (its first `--parity-child` haplotypes, cut to
+    `--parity-bases` bases each), under the environment the parent chose; prints the sha256 of its output files as one JSON line"""
     import pfbwt_hip
     L, H, seed, nruns, w, p, u64 = WORKLOADS[a.workload]
-    samples_only = a.workload in SAMPLES_ONLY
-    sub = synth_seqs(L, a.parity_child, seed, nruns)
+    want_sa, want_rssa = outputs_of(a.workload)
+    sub = [t[:a.parity_bases] if a.parity_bases else t for t in synth_seqs(L, a.parity_child, seed, nruns)]
     c = pfbwt_hip.PfpContext(w=w, p=p, u64=u64, sai=True, device=0)
     for t in sub:
         c.feed(t, True)
-    c.finalize(); c.parse_bwt(); c.bwt_build(sa=not samples_only, rssa=samples_only)
+    c.finalize(); c.parse_bwt(); c.bwt_build(sa=want_sa, rssa=want_rssa)
     o = c.bwt_get(); c.close()
-    names = ("bwt", "ssa", "esa") if samples_only else ("bwt", "sa")
-    print(json.dumps({k: hashlib.sha256(o[k].tobytes()).hexdigest() for k in names}), flush=True)
+    print(json.dumps({k: hashlib.sha256(o[k].tobytes()).hexdigest() for k in out_names(want_sa, want_rssa)}), flush=True)
 
 
 def write_fasta_image(path, rows, line=60000):
@@ -212,7 +258,7 @@ def e2e_child(a):
     import pfbwt_hip
     L, H, seed, nruns, w, p, u64 = WORKLOADS[a.workload]
     U = 8 if u64 else 4
-    samples_only = a.workload in SAMPLES_ONLY
+    want_sa, want_rssa = outputs_of(a.workload)
     lib = pfbwt_hip.load_library()
     fsize = os.path.getsize(a.e2e_child)
     outs = {}
@@ -221,8 +267,10 @@ def e2e_child(a):
         from concurrent.futures import ThreadPoolExecutor
         t0 = time.perf_counter()
         bufs = {"bwt": np.empty(fsize + 64, np.uint8)}
-        if not samples_only:
+        if want_sa:
             bufs["sa"] = np.empty((fsize + 64) * U, np.uint8)
+        if want_rssa:      # r is not known in advance: room for n / 6 runs (4 * U bytes each), pageable arrays if there are more
+            bufs["samples"] = np.empty((fsize // 6 + 64) * 4 * U, np.uint8)
         step = 1 << 28
         with ThreadPoolExecutor(max_workers=16) as ex:
             for b in bufs.values():
@@ -245,11 +293,15 @@ def e2e_child(a):
         t2 = time.perf_counter()
         th.join()
         t3 = time.perf_counter()
-        b = ctx.bwt_build_stream(outs["bwt"].ctypes.data, outs["sa"].ctypes.data if not samples_only else None, rssa=samples_only)
+        b = ctx.bwt_build_stream(outs["bwt"].ctypes.data, outs["sa"].ctypes.data if want_sa else None, rssa=want_rssa)
         t4 = time.perf_counter()
         ssa = esa = None
-        if samples_only:
-            ssa, esa = ctx.samples_get()
+        if want_rssa:
+            if 4 * U * b.r <= outs["samples"].size:
+                sv = outs["samples"].view(np.uint64 if u64 else np.uint32)
+                ssa, esa = ctx.samples_get(out={"ssa": sv[:2 * b.r], "esa": sv[2 * b.r:4 * b.r]})
+            else:
+                ssa, esa = ctx.samples_get()
         t5 = time.perf_counter()
         n = sz.n
         runs.append({"ms": 1e3 * (t5 - t0), "startup_ms": 1e3 * (t_in0 - t0), "ingest_ms": 1e3 * (t1 - t_in0), "reader_GBps": info.raw_bytes / (t1 - t_in0) / 1e9,
@@ -260,9 +312,9 @@ def e2e_child(a):
     # what reached host memory: word sums of .bwt (and .sa), compared by the parent with the device-resident outputs of the timed steps
     n = runs[1]["n"]
     res["sums"] = {"bwt": host_wordsum(outs["bwt"][:n + 1])}
-    if samples_only:
+    if want_rssa:
         res["sums"]["ssa"] = host_wordsum(ssa.view(np.uint8)); res["sums"]["esa"] = host_wordsum(esa.view(np.uint8))
-    else:
+    if want_sa:
         res["sums"]["sa"] = host_wordsum(outs["sa"][:(n + 1) * U])
     t6 = time.perf_counter()
     ctx.close()
@@ -294,6 +346,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--parity-child", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--parity-bases", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--e2e-child", default="", help=argparse.SUPPRESS)
     a = ap.parse_args()
     if a.parity_child:
@@ -328,8 +381,9 @@ def main():
 
     L, H, seed, nruns, w, p, u64 = WORKLOADS[a.workload]
     U = 8 if u64 else 4
-    samples_only = a.workload in SAMPLES_ONLY
-    strong = a.workload == "S-32G"      # the north-star collection is FIXED (1000 haplotypes); N GPUs share it
+    want_sa, want_rssa = outputs_of(a.workload)
+    big = n_is_big = H * (L + w) > (1 << 31)      # the CPU leg and the oracle parity run cover a sample of such workloads
+    strong = a.workload in ("S-32G", "S-50G")      # the north-star collection is FIXED (1000 haplotypes); N GPUs share it
     if strong:
         if H % world:
             raise SystemExit("%s: %d haplotypes do not split evenly over %d ranks" % (a.workload, H, world))
@@ -352,9 +406,9 @@ def main():
         if world == 1 and not forced:
             feed_local(ctx)
             ctx.finalize(); ctx.parse_bwt()
-            return ctx.bwt_build(sa=not samples_only, rssa=samples_only)
+            return ctx.bwt_build(sa=want_sa, rssa=want_rssa)
         import pfbwt_dist
-        return pfbwt_dist.sharded_build(ctx, feed_local, w, dev, sa=not samples_only, rssa=samples_only)[1]
+        return pfbwt_dist.sharded_build(ctx, feed_local, w, dev, sa=want_sa, rssa=want_rssa)[1]
 
     def sync():
         torch.cuda.synchronize()
@@ -406,25 +460,25 @@ def main():
                 traffic = sum(r["launches"] * r["hbm_bytes_per_launch_corrected"] for r in cand) / sum(r["launches"] for r in cand)
         except (OSError, ValueError, KeyError):
             pass
-        out_names = ".bwt, .ssa, .esa" if samples_only else ".bwt, .sa"
+        out_list = ", ".join("." + k for k in out_names(want_sa, want_rssa))
         res = {
             "metric": "Gbases/s end-to-end BWT+SA build; bit-exact .bwt/.sa vs reference", "value": value,
             "value_is": "device-resident build (text already in HBM, outputs left in HBM), as the bench contract prescribes; the FASTA-bytes -> host-memory figures of the metric's wording are the end_to_end_fasta block (cold / warm), host rows -> host is end_to_end", "unit": "Gbases/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "u8 text / u32 indices / u64 hash", "data": "synthetic",
-            "config": {"workload": a.workload, "L": L, "H": H * world, "seed": seed, "n_runs": list(nruns), "w": w, "p": p, "flags": "-r" if samples_only else "-s", "uint_t": 64 if u64 else 32,
-                       "n": n, "r": r_total, "input": "text resident in HBM, outputs (%s) left in HBM" % out_names,
+            "config": {"workload": a.workload, "L": L, "H": H * world, "seed": seed, "n_runs": list(nruns), "w": w, "p": p, "flags": " ".join(oracle_mode(want_sa, want_rssa)), "uint_t": 64 if u64 else 32,
+                       "n": n, "r": r_total, "input": "text resident in HBM, outputs (%s) left in HBM" % out_list,
                        "per_rank": ("%d haplotype(s) of the collection per rank; parse sharded, one RCCL all-gather of dictionaries + parses, "
                                     "merge + dictionary/parse suffix sorts on every rank, emission (and run samples) sliced over the ranks" % H) if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": traffic,
                          "launches_per_step": pr["launches"] / a.steps, "avg_launch_us": 1e3 * pr["ms"] / pr["launches"],
                          "alg_bytes_per_launch": pr["bytes"] / pr["launches"],
                          "share_of_kernel_time": max(r["ms"] for r in warm_rows if r["kernel"] != "misc") / total_ms,
-                         "end_to_end_alg_GBps": ((2 * n + 4 * U * r_total) if samples_only else (2 + U) * n) / (dt / a.steps) / 1e9},
+                         "end_to_end_alg_GBps": (2 * n + (4 * U * r_total if want_rssa else 0) + (U * n if want_sa else 0)) / (dt / a.steps) / 1e9},
             "stage_ms": ctx.stage_ms(),
         }
         dev_sums = None
-        if world == 1 and not forced and samples_only:
+        if world == 1 and not forced and want_rssa:
             # full-size ordering proof on the outputs of the last timed step: all r - 1 pairs of adjacent rows (.esa[k], .ssa[k + 1])
             # compared suffix against suffix on the resident text (pfp_debug_check_sample_order)
             res["full_size_order_check"] = ctx.check_sample_order()
@@ -438,16 +492,16 @@ def main():
             def dsum(ptr, nbytes):
                 o = (ctypes.c_uint64 * 2)(); ctx._check(ctx.L.pfp_debug_wordsum(ctx.h, ctypes.c_void_p(ptr), int(nbytes), o)); return [int(o[0]), int(o[1])]
             dev_sums = {"bwt": dsum(dp["bwt"], n + 1)}
-            if samples_only:
+            if want_rssa:
                 dev_sums["ssa"] = dsum(dp["ssa"], 2 * r_total * U); dev_sums["esa"] = dsum(dp["esa"], 2 * r_total * U)
-            else:
+            if want_sa:
                 dev_sums["sa"] = dsum(dp["sa"], (n + 1) * U)
             # host -> host, rows: the text sits in pinned host memory as headerless rows, the outputs end in pinned host memory
             ob = {"bwt": torch.empty(n + 1, dtype=torch.uint8, pin_memory=True).numpy()}
-            if samples_only:
+            if want_rssa:
                 ob["ssa"] = torch.empty(2 * r_total * U, dtype=torch.uint8, pin_memory=True).numpy().view(np.uint64 if u64 else np.uint32)
                 ob["esa"] = torch.empty(2 * r_total * U, dtype=torch.uint8, pin_memory=True).numpy().view(np.uint64 if u64 else np.uint32)
-            else:
+            if want_sa:
                 ob["sa"] = torch.empty((n + 1) * U, dtype=torch.uint8, pin_memory=True).numpy().view(np.uint64 if u64 else np.uint32)
             best = None
             for _ in range(2):
@@ -456,14 +510,14 @@ def main():
                 e1 = time.perf_counter()
                 ctx.finalize(); ctx.parse_bwt()
                 e2 = time.perf_counter()
-                ctx.bwt_build_stream(ob["bwt"].ctypes.data, ob["sa"].ctypes.data if not samples_only else None, rssa=samples_only)
-                if samples_only:
+                ctx.bwt_build_stream(ob["bwt"].ctypes.data, ob["sa"].ctypes.data if want_sa else None, rssa=want_rssa)
+                if want_rssa:
                     ctx.samples_get(out=ob)
                 e3 = time.perf_counter()
                 cur = {"ms": 1e3 * (e3 - e0), "h2d_ms": 1e3 * (e1 - e0), "parse_ms": 1e3 * (e2 - e1), "emit_and_d2h_ms": 1e3 * (e3 - e2)}
                 if best is None or cur["ms"] < best["ms"]:
                     best = cur
-            in_b = n_local; out_b = (n + 1) + ((4 * U * r_total) if samples_only else U * (n + 1))
+            in_b = n_local; out_b = (n + 1) + (4 * U * r_total if want_rssa else 0) + (U * (n + 1) if want_sa else 0)
             best.update({"value": n / (best["ms"] * 1e-3) / 1e9, "unit": "Gbases/s", "h2d_GBps": in_b / best["h2d_ms"] / 1e6, "d2h_GBps": out_b / best["emit_and_d2h_ms"] / 1e6,
                          "what": "headerless rows in page-locked host memory -> one DMA transfer per row -> parse -> emission with every finished window of rows "
                                  "on its way to page-locked host memory while the next one is emitted (pfp_bwt_build_stream) -> run samples",
@@ -488,9 +542,8 @@ def main():
                 t0 = time.perf_counter()
                 fbytes = write_fasta_image(img, seqs)
                 t_img = time.perf_counter() - t0
-                cpu_rows = [np.array(s) for s in seqs[:CPU_SAMPLE_HAPLOTYPES]] if samples_only else None      # the CPU leg's sample outlives the page-locked rows
-                if cpu_rows is not None:
-                    seqs = cpu_rows + [None] * (len(seqs) - len(cpu_rows))
+                if big:      # the CPU leg's sample outlives the page-locked rows
+                    seqs = [np.array(s[:CPU_SAMPLE_BASES]) for s in seqs[:CPU_SAMPLE_HAPLOTYPES]]
                 del h_all
                 # this process has just released its HBM: the driver wipes freed VRAM in the background (~40 GB/s) and a large
                 # allocation waits for a pending wipe (profiles/r03a_alloc_fresh.log) -- "cold" means a fresh process on an idle card
@@ -516,13 +569,15 @@ def main():
                 res["end_to_end_fasta"] = {"error": repr(e)}
         if not a.no_cpu_baseline and world == 1:
             # bounded CPU sample + parity: the oracle on the sample, the engine on the same sample in a child process
-            nh = min(CPU_SAMPLE_HAPLOTYPES, H) if samples_only else H
-            sub = seqs[:nh]
+            nh = min(CPU_SAMPLE_HAPLOTYPES, H) if big else H
+            nbases = min(CPU_SAMPLE_BASES, L) if big else L
+            sub = [s[:nbases] for s in seqs[:nh]]
             env = dict(os.environ)
-            if samples_only:
+            if big:
                 env.update(PARITY_ENV)
-            pc = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", a.workload, "--parity-child", str(nh)], env=env, capture_output=True, text=True)
-            cb, dig = cpu_baseline(sub, w, p, u64, mode="-r" if samples_only else "-s")
+            pc = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", a.workload, "--parity-child", str(nh)] + (["--parity-bases", str(nbases)] if nbases < L else []),
+                                env=env, capture_output=True, text=True)
+            cb, dig = cpu_baseline(sub, w, p, u64, mode=oracle_mode(want_sa, want_rssa))
             res["cpu_baseline"] = cb
             try:
                 got = json.loads(pc.stdout.strip().splitlines()[-1]) if pc.returncode == 0 else {}
@@ -530,8 +585,9 @@ def main():
                 got = {}
             ok = bool(got) and all(got.get(k) == v for k, v in dig.items())
             what = "sha256(%s) of the engine == oracle/pfbwt_oracle (the repo's CPU restatement, pinned to the reference's goldens)" % ", ".join("." + k for k in dig)
-            scope = ("on the first %d haplotypes (%d bases), engine run with %s so that the 64-bit-row / windowed kernels timed above are the ones checked; "
-                     "full-size outputs: tools/big_check_rssa.py, tools/big_check_slices.py (profiles/)" % (nh, nh * (L + w), " ".join("%s=%s" % kv for kv in PARITY_ENV.items()))) if samples_only else "on the whole input"
+            scope = ("on a sample: the first %d sequence(s), %d bases each (%d bases), engine run with %s so that the 64-bit-row / windowed kernels timed above are the ones "
+                     "checked; the full-size outputs are covered by full_size_order_check (all adjacent run-boundary rows, suffix against suffix) and by the word sums of the "
+                     "end-to-end legs" % (nh, nbases, nh * (nbases + w), " ".join("%s=%s" % kv for kv in PARITY_ENV.items()))) if big else "on the whole input"
             res["parity"] = ("bit-exact: " if ok else "MISMATCH: ") + what + " " + scope
             if not ok:
                 res["parity_detail"] = {"engine": got, "oracle": dig, "child_rc": pc.returncode, "child_stderr": pc.stderr[-500:]}

@@ -23,7 +23,7 @@ int pfp_profile_get(pfp_ctx *ctx, int idx, const char **name, uint64_t *launches
  * [0] parse_finalize [1] parse_bwt [2] bwt_build */
 int pfp_stage_ms(pfp_ctx *ctx, double out[3]);
 /* Route and tuning switches of ONE context (tests force the routes that only huge inputs take; A/B measurements):
- *   verbose, seg_grid, seg_stage, sort_k (1 | 3), sort_no_table, sort_no_group, class_sort_maxrange, dedup_table_log2, no_trigger_table,
+ *   verbose, seg_grid, seg_stage, sort_k (1 | 3), sort_no_table, class_sort_maxrange, dedup_table_log2, no_trigger_table,
  *   emit_chunk_rows, fill_subs, sample_cap (< 0: none), no_runaware, big_group_members (< 0: never), force_wide_rows,
  *   fasta_chunk_bytes, ingest_block_bytes.
  * Returns PFP_E_ARG for an unknown key.  In a process started with PFP_TEST_HOOKS=1 pfp_create presets a new context from the

@@ -54,8 +54,16 @@ static int nt4_code(int c)
 }
 
 /* ------------------------------------------------------------------------------------------- */
-/* SA-IS over an int32 text with a unique smallest sentinel T[n-1]==0.                          */
+/* SA-IS over an integer text with a unique smallest sentinel T[n-1]==0.  Index type: int32 (texts and dictionaries below
+ * 2^31 symbols: everything the test suite runs) or, built with -DORACLE_IDX64 (`make -C oracle big`: pfbwt_oracle64), int64 --
+ * three times the memory, for the one-off full-size checks of texts / dictionaries beyond 2^31 (S-3G, prefixes of S-32G). */
+#ifdef ORACLE_IDX64
+typedef int64_t sidx;
+#define SIDX_LIMIT 0x7fffffffffffffffULL
+#else
 typedef int32_t sidx;
+#define SIDX_LIMIT 0x7fffffffULL
+#endif
 #define TGET(i) ((tb[(i) >> 3] >> ((i) & 7)) & 1)
 #define TSET(i, b) (tb[(i) >> 3] = (uint8_t)((b) ? (tb[(i) >> 3] | (1u << ((i) & 7))) : (tb[(i) >> 3] & ~(1u << ((i) & 7)))))
 #define ISLMS(i) ((i) > 0 && TGET(i) && !TGET((i) - 1))
@@ -131,12 +139,22 @@ static int sais_rec(const sidx *T, sidx *SA, sidx n, sidx K)
 
 static int sais32(const sidx *T, sidx *SA, uint64_t n, uint64_t K)
 {
-    if (n >= 0x7fffffffULL || K >= 0x7fffffffULL) return -1;
+    if (n >= SIDX_LIMIT || K >= SIDX_LIMIT) return -1;
     return sais_rec(T, SA, (sidx)n, (sidx)K);
 }
 
 int orc_sais_int(const uint32_t *s, uint64_t *SA, uint64_t n, uint64_t k)
 {
+#ifdef ORACLE_IDX64
+    /* sidx is as wide as the caller's SA: sort in place, the text widened once */
+    sidx *t = (sidx *)malloc(sizeof(sidx) * (size_t)(n ? n : 1));
+    uint64_t i; int r;
+    if (!t) return -1;
+    for (i = 0; i < n; ++i) t[i] = (sidx)s[i];
+    r = sais32(t, (sidx *)SA, n, k);
+    free(t);
+    return r;
+#else
     sidx *sa = (sidx *)malloc(sizeof(sidx) * (size_t)(n ? n : 1));
     uint64_t i; int r;
     if (!sa) return -1;
@@ -144,19 +162,25 @@ int orc_sais_int(const uint32_t *s, uint64_t *SA, uint64_t n, uint64_t k)
     if (r == 0) for (i = 0; i < n; ++i) SA[i] = (uint64_t)sa[i];
     free(sa);
     return r;
+#endif
 }
 
 int orc_sais_bytes(const uint8_t *s, uint64_t *SA, uint64_t n)
 {
     sidx *t = (sidx *)malloc(sizeof(sidx) * (size_t)(n ? n : 1));
-    sidx *sa = (sidx *)malloc(sizeof(sidx) * (size_t)(n ? n : 1));
     uint64_t i; int r = -1;
+#ifdef ORACLE_IDX64
+    if (t) { for (i = 0; i < n; ++i) t[i] = s[i]; r = sais32(t, (sidx *)SA, n, 256); }
+    free(t);
+#else
+    sidx *sa = (sidx *)malloc(sizeof(sidx) * (size_t)(n ? n : 1));
     if (t && sa) {
         for (i = 0; i < n; ++i) t[i] = s[i];
         r = sais32(t, sa, n, 256);
         if (r == 0) for (i = 0; i < n; ++i) SA[i] = (uint64_t)sa[i];
     }
     free(t); free(sa);
+#endif
     return r;
 }
 
@@ -378,7 +402,7 @@ static int64_t orc_bwt_impl(const uint8_t *dict, uint64_t dsize, const uint64_t 
     suff_t *suffs = NULL; uint64_t suffs_cap = 0;
     uint8_t *chars = NULL; uint64_t *words = NULL; uint64_t cw_cap = 0;
     (void)nrows;
-    if (dsize < 1 || dsize >= 0x7fffffffULL) return -1;
+    if (dsize < 1 || dsize >= SIDX_LIMIT) return -1;
     T = (sidx *)malloc(sizeof(sidx) * (size_t)dsize);
     gsa = (sidx *)malloc(sizeof(sidx) * (size_t)dsize);
     rank = (sidx *)malloc(sizeof(sidx) * (size_t)dsize);

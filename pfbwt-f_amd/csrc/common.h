@@ -87,7 +87,6 @@ struct Tunables {
     int seg_stage = 1;                 // global radix scatter staged through LDS
     int sort_k = 0;                    // 1: plain doubling in every refinement round, 3: three ranks in every round but the run round
     int sort_no_table = 0;             // the K = 3 rounds follow the chains themselves
-    int sort_no_group = 0;             // the refinement rounds sort full keys, never group equal keys first
     uint32_t class_sort_maxrange = 0;  // smaller LDS class-sort ranges (reaches the large-class route on small inputs)
     int dedup_table_log2 = 0;          // a first phrase table that overflows
     int no_trigger_table = 0;          // trigger test by hashing every window
@@ -162,7 +161,7 @@ struct pfp_ctx {
         std::vector<uint64_t> rec_raw, rec_pos;                         // records that started in the last pfp_parse_feed_fasta call
     } fa;
     uint8_t *h_bwt = nullptr; void *h_sa = nullptr;                      // pfp_bwt_build_stream: host destinations, filled window by window during the emission
-    uint8_t *ing_buf[8] = {};                                           // page-locked blocks of the file reader (csrc/ingest.h)
+    uint8_t *ing_buf[16] = {};                                           // page-locked blocks of the file reader (csrc/ingest.h)
     uint64_t ing_next_off = 0;
     std::vector<std::string> doc_names; std::vector<uint64_t> doc_starts;   // records of the last pfp_parse_feed_fasta_file(PFP_FASTA_RECORDS)
     uint64_t hash_seed = 0x9E3779B97F4A7C15ULL;

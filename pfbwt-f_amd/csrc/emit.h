@@ -597,7 +597,12 @@ template <typename EBT> __global__ __launch_bounds__(BLOCK) void k_slice_bounds(
     uint32_t s = slot_of_row<EBT>(a, hi - 1);
     const uint32_t g = a.posinfo[a.SA[s]].y;
     while (s < a.dsize && a.posinfo[a.SA[s]].y == g) ++s;
-    while (s < a.dsize && (uint64_t)EB[s] < hi) ++s;       // slots that produce no rows keep EB unchanged
+    {   // first slot at or behind s whose rows start at or behind hi: EB never decreases (slots that produce no rows -- dictionary
+        // suffixes of length <= w come in clusters of millions -- repeat the next one's value), so this is a bisection, not a walk
+        uint64_t lo_ = s, hi_ = a.dsize;
+        while (lo_ < hi_) { const uint64_t mid = lo_ + ((hi_ - lo_) >> 1); if ((uint64_t)EB[mid] < hi) lo_ = mid + 1; else hi_ = mid; }
+        s = (uint32_t)lo_;
+    }
     out[1] = s < a.dsize ? (uint64_t)EB[s] : a.nout;
     out[3] = a.special ? (unsigned long long)ENB[s < a.dsize ? a.cpos[s] : a.ecount] : 0ULL;
 }

@@ -20,7 +20,8 @@
 namespace pfp {
 
 constexpr size_t ING_BLOCK = (size_t)64 << 20;
-constexpr int ING_RING = 6, ING_READERS = 4;
+constexpr int ING_RING = 16, ING_READERS = 8;      // the ring is a multiple of the readers: a slot is always filled by the same thread
+static_assert(ING_RING % ING_READERS == 0, "ring slots per reader");
 
 struct IngestStats { uint64_t raw_bytes = 0, records = 0; double read_wait_ms = 0, total_ms = 0; int mode = 0; };
 
@@ -114,13 +115,18 @@ static int ingest_file(pfp_ctx *c, const char *path, unsigned flags, IngestStats
     if (!parallel) { gzf = gzdopen(fd, "r"); if (!gzf) { if (!is_stdin) close(fd); return PFP_E_IO; } gzbuffer(gzf, 1 << 20); }
     if (regular && !gz && !c->text.live() && !c->text_hint) c->text_hint = (uint64_t)sb.st_size;
     auto &f = c->fa;
-    // page-locked ring (kept by the context: a second file re-uses it)
-    for (int k = 0; k < ING_RING; ++k) if (!c->ing_buf[k]) PFP_HIP(c, hipHostMalloc((void **)&c->ing_buf[k], ING_BLOCK, hipHostMallocDefault));
+    // page-locked ring (kept by the context: a second file re-uses it); a slot's buffer is allocated by the reader that first fills
+    // it -- the readers allocate in parallel, a cold process does not wait for 1 GiB of page-locked memory before the first pread
     BlockRing ring;
     for (int k = 0; k < ING_RING; ++k) ring.buf[k] = c->ing_buf[k];
     if (parallel) ring.nblocks = ((uint64_t)sb.st_size + BLK - 1) / BLK;
     auto fill = [&](uint64_t b, int slot) -> bool {      // reader side: block b into its slot; false at a read error
         size_t got = 0;
+        if (!ring.buf[slot]) {
+            (void)hipSetDevice(c->device);
+            if (hipHostMalloc((void **)&c->ing_buf[slot], ING_BLOCK, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return false; }
+            ring.buf[slot] = c->ing_buf[slot];
+        }
         if (parallel) {
             const uint64_t o = b * BLK, want = (uint64_t)sb.st_size - o < BLK ? (uint64_t)sb.st_size - o : BLK;
             while (got < want) { const ssize_t r = pread(fd, ring.buf[slot] + got, (size_t)(want - got), (off_t)(o + got)); if (r < 0) return false; if (r == 0) break; got += (size_t)r; }

@@ -79,7 +79,7 @@ static void reset_results(pfp_ctx *c)
 }
 
 // ---- route / tuning switches (pfbwt_hip_dev.h) -----------------------------------------------------
-static const char *const tunable_names[] = {"verbose", "seg_grid", "seg_stage", "sort_k", "sort_no_table", "sort_no_group", "class_sort_maxrange", "dedup_table_log2", "no_trigger_table",
+static const char *const tunable_names[] = {"verbose", "seg_grid", "seg_stage", "sort_k", "sort_no_table", "class_sort_maxrange", "dedup_table_log2", "no_trigger_table",
                                             "emit_chunk_rows", "fill_subs", "sample_cap", "no_runaware", "big_group_members", "force_wide_rows", "fasta_chunk_bytes", "ingest_block_bytes"};
 static int set_tunable(pfp_ctx *c, const char *key, long long v)
 {
@@ -89,7 +89,6 @@ static int set_tunable(pfp_ctx *c, const char *key, long long v)
     else if (!strcmp(key, "seg_stage")) t.seg_stage = (int)v;
     else if (!strcmp(key, "sort_k")) t.sort_k = (int)v;
     else if (!strcmp(key, "sort_no_table")) t.sort_no_table = (int)v;
-    else if (!strcmp(key, "sort_no_group")) t.sort_no_group = (int)v;
     else if (!strcmp(key, "class_sort_maxrange")) t.class_sort_maxrange = (uint32_t)v;
     else if (!strcmp(key, "dedup_table_log2")) t.dedup_table_log2 = (int)v;
     else if (!strcmp(key, "no_trigger_table")) t.no_trigger_table = (int)v;

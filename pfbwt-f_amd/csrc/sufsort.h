@@ -162,11 +162,9 @@ template <bool DICT> __global__ __launch_bounds__(BLOCK) void k_round_table(cons
 template <bool DICT, int K> __global__ __launch_bounds__(BLOCK) void k_round(const uint32_t *aslot, const uint32_t *arnk, const uint32_t *ajmp, uint64_t na, uint64_t N,
                                                                              uint32_t *SA, const uint32_t *rank, const uint2 *rj, const uint4 *T /*K = 3; null: follow the chain*/, uint32_t h, const uint8_t *D,
                                                                              const uint32_t *M /*run round (K = 1)*/, int lowbits, uint32_t max_range, uint32_t *newr,
-                                                                             uint32_t *xout /*the sorted suffixes, in list order*/, uint32_t *tnj, uint32_t *newj, uint8_t *flags, uint32_t *stripe_keep, unsigned long long *ndone,
-                                                                             uint32_t group_max /*0: never group equal keys before the sort*/)
+                                                                             uint32_t *xout /*the sorted suffixes, in list order*/, uint32_t *tnj, uint32_t *newj, uint8_t *flags, uint32_t *stripe_keep, unsigned long long *ndone)
 {
     constexpr int ITEMS = RoundCfg<K>::ITEMS, TILE = RoundCfg<K>::TILE;
-    constexpr uint32_t GROUP_MAX = 512;
     constexpr uint32_t STEP = RoundCfg<K>::STEP;
     __shared__ uint32_t wh[BLOCK / WAVE][RS_RADIX];
     __shared__ uint64_t skeys[TILE];
@@ -184,6 +182,7 @@ template <bool DICT, int K> __global__ __launch_bounds__(BLOCK) void k_round(con
     const uint32_t n = (uint32_t)(e - s);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t nit = (n + BLOCK - 1) / BLOCK;
+    const uint32_t base = (uint32_t)wave * (nit * WAVE) + lane;   // wave w owns the contiguous pairs [w * nit * 64, (w + 1) * nit * 64)
     const uint32_t hmin = arnk[s];
     // ---- keys.  Dependent gathers per pair (list entry -> SA[slot] -> ranks of the target): all of a thread's pairs go
     //      through each stage together, so that a tile pays the memory latencies once, not once per pair
@@ -265,138 +264,53 @@ template <bool DICT, int K> __global__ __launch_bounds__(BLOCK) void k_round(con
     const int nb = K == 3 ? (2 * lowbits + 7) / 8 : 0;
     const int nlo = (lowbits + 7) / 8;
     int nhi = 0; while (nhi < 8 && (hspan >> (8 * nhi))) ++nhi;
-    // stable LSD radix sort of skeys / skeyb / sidx [0, cnt) (cnt padded to whole waves with all-ones keys by the caller): pb passes
-    // over the two ranks of B, pl over the low part of A (lb bits), ph over what lies above it.  Wave w owns the contiguous
-    // entries [w * cnit * 64, (w + 1) * cnit * 64).
-    auto lds_sort = [&](uint32_t cnit, int pb, int pl, int ph, int lb) {
-        const uint32_t cbase = (uint32_t)wave * (cnit * WAVE) + lane;
-        for (int p = 0; p < pb + pl + ph; ++p) {
-            const bool use_b = p < pb;
-            const int q = p - pb;
-            const int sh = use_b ? 8 * p : q < pl ? 8 * q : lb + 8 * (q - pl);
-            const uint32_t dmask = (!use_b && q < pl && lb - 8 * q < 8) ? ((1u << (lb - 8 * q)) - 1u) : 255u;      // the top digit of the low part stops where the class part starts
-            uint64_t k[ITEMS], kb[K == 3 ? ITEMS : 1]; uint16_t v[ITEMS]; unsigned dg[ITEMS];
+    for (int p = 0; p < nb + nlo + nhi; ++p) {
+        const bool use_b = p < nb;
+        const int q = p - nb;
+        const int sh = use_b ? 8 * p : q < nlo ? 8 * q : lowbits + 8 * (q - nlo);
+        const uint32_t dmask = (!use_b && q < nlo && lowbits - 8 * q < 8) ? ((1u << (lowbits - 8 * q)) - 1u) : 255u;      // the top digit of the low part stops where the class part starts
+        uint64_t k[ITEMS], kb[K == 3 ? ITEMS : 1]; uint16_t v[ITEMS]; unsigned dg[ITEMS];
 #pragma unroll
-            for (int w = 0; w < BLOCK / WAVE; ++w) wh[w][threadIdx.x] = 0;
-            __syncthreads();
-#pragma unroll
-            for (int it = 0; it < ITEMS; ++it) {
-                if ((uint32_t)it < cnit) {                                  // uniform; no break: the loop must unroll (register arrays)
-                const uint32_t i = cbase + (uint32_t)it * WAVE;
-                k[it] = skeys[i]; v[it] = sidx[i];
-                if (K == 3) kb[it] = skeyb[i];
-                const uint32_t d = (uint32_t)(((K == 3 && use_b) ? kb[K == 3 ? it : 0] : k[it]) >> sh) & dmask;
-                uint32_t plo = 0xFFFFFFFFu, phi = 0xFFFFFFFFu;            // lanes with the same digit
-                same_digit_lanes(d, plo, phi);
-                const int leader = plo ? __builtin_ctz(plo) : 32 + __builtin_ctz(phi);       // never empty: the lane itself
-                uint32_t old = 0;
-                if (lane == leader) { old = wh[wave][d]; wh[wave][d] = old + (uint32_t)__builtin_popcount(plo) + (uint32_t)__builtin_popcount(phi); }
-                old = __shfl(old, leader);
-                dg[it] = d | ((old + __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u))) << 8);        // digit and rank inside the wave
-                }
-            }
-            __syncthreads();
-            {
-                const unsigned d = threadIdx.x;
-                uint32_t cw[BLOCK / WAVE]; uint32_t total = 0;
-#pragma unroll
-                for (int w = 0; w < BLOCK / WAVE; ++w) { cw[w] = wh[w][d]; total += cw[w]; }
-                uint32_t tt;
-                uint32_t run = block_excl_sum(total, reinterpret_cast<uint32_t *>(red), &tt);
-#pragma unroll
-                for (int w = 0; w < BLOCK / WAVE; ++w) { wh[w][d] = run; run += cw[w]; }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int it = 0; it < ITEMS; ++it) {
-                if ((uint32_t)it < cnit) {
-                    const uint32_t li = wh[wave][dg[it] & 255u] + (dg[it] >> 8);
-                    skeys[li] = k[it]; sidx[li] = v[it];
-                    if (K == 3) skeyb[li] = kb[K == 3 ? it : 0];
-                }
-            }
-            __syncthreads();
-        }
-    };
-    // ---- grouping.  A collection of near-identical sequences splits a class of ~1000 copies into a handful of new classes: the
-    //      keys are 99 bits wide, but a tile holds only tens to hundreds of DISTINCT ones.  The pairs are therefore first grouped
-    //      by key in a hash table in LDS (the wave counters' memory: 1024 slots; a slot names the pair that claimed it -- its key
-    //      is compared, no fingerprint is trusted), the few distinct keys are sorted (the same LSD passes, over G instead of n
-    //      entries), and ONE or two stable passes over the pairs by their group's position give the order the full sort gives
-    //      (equal keys keep their list order in both).  More than GROUP_MAX distinct keys: the full sort, as before.
-    bool grouped = false;
-    if (group_max) {
-        uint32_t *tab = &wh[0][0];                                             // 1024 slots: index of the claiming pair, or empty
-        uint16_t *slot_gid = shp, *rep = shp + 1024, *grank = shp + 1024 + GROUP_MAX;      // (shp is written behind the sort only)
-        __shared__ uint32_t gcount, govf_s;
-        volatile uint32_t &govf = govf_s;                                      // polled inside the probe loop
-#pragma unroll
-        for (int w = 0; w < BLOCK / WAVE; ++w) wh[w][threadIdx.x] = 0xFFFFFFFFu;
-        if (threadIdx.x == 0) { gcount = 0; govf_s = 0; }
+        for (int w = 0; w < BLOCK / WAVE; ++w) wh[w][threadIdx.x] = 0;
         __syncthreads();
-        uint16_t myslot[ITEMS];
 #pragma unroll
         for (int it = 0; it < ITEMS; ++it) {
-            const uint32_t j = threadIdx.x + (uint32_t)it * BLOCK;
-            myslot[it] = 0;
-            if (j < n && !govf) {
-                const uint64_t ka = skeys[j], kb2 = K == 3 ? skeyb[j] : 0ULL;
-                uint32_t x = (uint32_t)ka * 0x9E3779B1u ^ (uint32_t)(ka >> 32) * 0x85EBCA6Bu ^ (uint32_t)kb2 * 0xC2B2AE35u ^ (uint32_t)(kb2 >> 32) * 0x27D4EB2Fu;
-                x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12;
-                uint32_t sl = x & 1023u;
-                for (;;) {
-                    uint32_t r = tab[sl];
-                    if (r == 0xFFFFFFFFu) {
-                        r = atomicCAS(&tab[sl], 0xFFFFFFFFu, j);
-                        if (r == 0xFFFFFFFFu) {                                // this pair represents a new group
-                            const uint32_t g = atomicAdd(&gcount, 1u);
-                            if (g < GROUP_MAX) { slot_gid[sl] = (uint16_t)g; rep[g] = (uint16_t)j; } else govf = 1;
-                            break;
-                        }
-                    }
-                    if (skeys[r] == ka && (K != 3 || skeyb[r] == kb2)) break;
-                    sl = (sl + 1u) & 1023u;
-                    if (govf) break;                                           // (the table cannot fill up: at most GROUP_MAX + 256 claims)
-                }
-                myslot[it] = (uint16_t)sl;
+            if ((uint32_t)it < nit) {                                  // uniform; no break: the loop must unroll (register arrays)
+            const uint32_t i = base + (uint32_t)it * WAVE;
+            k[it] = skeys[i]; v[it] = sidx[i];
+            if (K == 3) kb[it] = skeyb[i];
+            const uint32_t d = (uint32_t)(((K == 3 && use_b) ? kb[K == 3 ? it : 0] : k[it]) >> sh) & dmask;
+            uint32_t plo = 0xFFFFFFFFu, phi = 0xFFFFFFFFu;            // lanes with the same digit
+            same_digit_lanes(d, plo, phi);
+            const int leader = plo ? __builtin_ctz(plo) : 32 + __builtin_ctz(phi);       // never empty: the lane itself
+            uint32_t old = 0;
+            if (lane == leader) { old = wh[wave][d]; wh[wave][d] = old + (uint32_t)__builtin_popcount(plo) + (uint32_t)__builtin_popcount(phi); }
+            old = __shfl(old, leader);
+            dg[it] = d | ((old + __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u))) << 8);        // digit and rank inside the wave
             }
         }
         __syncthreads();
-        const uint32_t G = gcount;
-        if (!govf && G <= GROUP_MAX) {
-            grouped = true;
-            // the distinct keys, compacted to the front of the key arrays (through registers: sources and targets overlap)
-            const uint32_t gnit = (G + BLOCK - 1) / BLOCK;
-            uint64_t ra[GROUP_MAX / BLOCK], rb[GROUP_MAX / BLOCK];
+        {
+            const unsigned d = threadIdx.x;
+            uint32_t cw[BLOCK / WAVE]; uint32_t total = 0;
 #pragma unroll
-            for (uint32_t q = 0; q < GROUP_MAX / BLOCK; ++q) {
-                const uint32_t g = threadIdx.x + q * BLOCK;
-                ra[q] = ~0ULL; rb[q] = ~0ULL;
-                if (g < G) { const uint32_t r = rep[g]; ra[q] = skeys[r]; if (K == 3) rb[q] = skeyb[r]; }
-            }
-            __syncthreads();
+            for (int w = 0; w < BLOCK / WAVE; ++w) { cw[w] = wh[w][d]; total += cw[w]; }
+            uint32_t tt;
+            uint32_t run = block_excl_sum(total, reinterpret_cast<uint32_t *>(red), &tt);
 #pragma unroll
-            for (uint32_t q = 0; q < GROUP_MAX / BLOCK; ++q) {
-                const uint32_t g = threadIdx.x + q * BLOCK;
-                if (q < gnit) { skeys[g] = ra[q]; sidx[g] = (uint16_t)g; if (K == 3) skeyb[g] = rb[q]; }
-            }
-            __syncthreads();
-            lds_sort(gnit, nb, nlo, nhi, lowbits);
-            for (uint32_t g = threadIdx.x; g < G; g += BLOCK) grank[sidx[g]] = (uint16_t)g;      // distinct keys: position = rank
-            __syncthreads();
-            // the pairs, keyed by the rank of their group
+            for (int w = 0; w < BLOCK / WAVE; ++w) { wh[w][d] = run; run += cw[w]; }
+        }
+        __syncthreads();
 #pragma unroll
-            for (int it = 0; it < ITEMS; ++it) {
-                const uint32_t j = threadIdx.x + (uint32_t)it * BLOCK;
-                if (j < n) { skeys[j] = (uint64_t)grank[slot_gid[myslot[it]]]; sidx[j] = (uint16_t)j; if (K == 3) skeyb[j] = 0ULL; }
-                else if (j < nit * BLOCK) { skeys[j] = ~0ULL; sidx[j] = (uint16_t)j; if (K == 3) skeyb[j] = ~0ULL; }
+        for (int it = 0; it < ITEMS; ++it) {
+            if ((uint32_t)it < nit) {
+                const uint32_t li = wh[wave][dg[it] & 255u] + (dg[it] >> 8);
+                skeys[li] = k[it]; sidx[li] = v[it];
+                if (K == 3) skeyb[li] = kb[K == 3 ? it : 0];
             }
-            __syncthreads();
-            int gbits = 1; while ((1u << gbits) < G) ++gbits;
-            lds_sort(nit, 0, G > 1 ? (gbits + 7) / 8 : 0, 0, 32);
-        } else __syncthreads();
+        }
+        __syncthreads();
     }
-    if (!grouped) lds_sort(nit, nb, nlo, nhi, lowbits);
     // ---- new classes: pair j heads a class iff its key differs from its predecessor's; head position of every pair by a
     //      max-scan (a thread scans a contiguous chunk, the chunk maxima go through the block scan)
     const uint32_t c0 = threadIdx.x * nit, c1 = (c0 + nit < n) ? c0 + nit : n;
@@ -628,7 +542,7 @@ template <bool DICT, int K> inline int suffix_sort_round(pfp_ctx *c, RoundBufs &
     // algorithmic bytes per active suffix: list entry 8 (+4 jump), SA[slot] 4 in + 4 out, the gathered
     // rank 4 (K = 3: 12; dictionary: + jump 4, + 1 terminator byte), new rank 4 (+ new jump 4 + 4 through scratch), flag 1
     PFP_LAUNCH(c, K_CLASS_SORT, (uint64_t)na * ((DICT ? 46 : 25) + (K == 3 ? 8 : 0)), (k_round<DICT, K>), gs, (const uint32_t *)b.aslot[cur], (const uint32_t *)b.arnk[cur], (const uint32_t *)b.ajmp[cur], (uint64_t)na, N, SA,
-               (const uint32_t *)rank, (const uint2 *)rj, T, hh, D, Mr, lowbits, max_range, b.newr, b.xout, b.tnj, b.newj, b.flags, b.stripe, b.d_done, c->tun.sort_no_group ? 0u : 1u);
+               (const uint32_t *)rank, (const uint2 *)rj, T, hh, D, Mr, lowbits, max_range, b.newr, b.xout, b.tnj, b.newj, b.flags, b.stripe, b.d_done);
     unsigned long long nd = 0;
     PFP_HIP(c, hipMemcpyAsync(&nd, b.d_done, 8, hipMemcpyDeviceToHost, c->stream));
     PFP_HIP(c, hipStreamSynchronize(c->stream));

@@ -60,6 +60,19 @@ def allgather_shards(ctx, device, group=None):
     return views, recv
 
 
+def allgather_docs(local_docs, n_local, group=None):
+    """--print-docs through the sharded build (pfparser.hpp:321-325): local_docs = [(name, start inside this rank's own text)],
+    n_local = bytes of text this rank fed (records + their w 'A's, WITHOUT the left context).  Returns the (name, start) list
+    of the whole collection, the same on every rank -- what `.docs` holds after a single parse."""
+    world = dist.get_world_size(group)
+    parts = [None] * world
+    dist.all_gather_object(parts, (int(n_local), [(str(nm), int(st)) for nm, st in local_docs]), group=group)
+    out, off = [], 0
+    for n_r, docs in parts:
+        out += [(nm, st + off) for nm, st in docs]; off += n_r
+    return out
+
+
 def sharded_build(ctx, feed_local, w, device, sa=True, rssa=False, group=None):
     """SPMD build over the ranks of `group`.
     1. every rank parses its own run of whole sequences (rank r > 0 with the w 'A's of the previous shard as context);
@@ -74,9 +87,8 @@ def sharded_build(ctx, feed_local, w, device, sa=True, rssa=False, group=None):
         if rank > 0:
             ctx.feed_left_context(w)
         feed_local(ctx)
-        sz_local = ctx.finalize(shard=True)        # no dictionary sort / ranks on a shard: the merge makes them for the union
-        if sz_local.m < 2 and world > 1:      # pfp_merge_shards needs the first and the last phrase of a shard to be different phrases
-            raise ValueError("shard of rank %d has a single phrase (no trigger window inside it): give it more sequence or use fewer ranks" % rank)
+        ctx.finalize(shard=True)        # no dictionary sort / ranks on a shard: the merge makes them for the union (a shard whose
+                                        # parse is ONE phrase -- a short record without a trigger window -- is folded into its seams)
     except Exception as e:      # an invalid character, a shard that is too small, ...: every rank must learn of it BEFORE the
         err = e                  # collective, or the healthy ranks would wait in the all-gather for ever
     ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=device)

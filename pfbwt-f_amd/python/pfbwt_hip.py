@@ -104,6 +104,7 @@ def load_library(path=None):
     L.pfp_parse_feed_fasta_file.argtypes = [vp, C.c_char_p, C.c_uint, C.POINTER(IngestInfo)]
     L.pfp_bwt_build_stream.argtypes = [vp, i32, i32, vp, vp, C.POINTER(BwtSizes)]
     L.pfp_text_length.argtypes = [vp, C.POINTER(u64)]
+    L.pfp_text_view.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
     L.pfp_host_register.argtypes = [vp, u64]
     L.pfp_host_unregister.argtypes = [vp]
     L.pfp_debug_wordsum.argtypes = [vp, vp, u64, C.POINTER(u64)]

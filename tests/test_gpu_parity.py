@@ -151,6 +151,51 @@ def test_full_size_properties(gpu_ctx_factory):
     assert np.array_equal(res["ssa"].reshape(-1, 2)[:, 1].astype(np.int64), sa[starts])
 
 
+def test_chr22_full_size_vs_oracle(gpu_ctx_factory):
+    """configs[1] of BASELINE.json at its full size inside the driver's own test run: S-chr22 (50.8 Mbase, two runs of N, -s, 32-bit
+    uint_t): sha256 of .bwt / .sa == oracle/pfbwt_oracle (about ten seconds of CPU); then -r on the same text: .ssa / .esa ==
+    the oracle's, and the device-side adjacent-row order check over all run samples"""
+    import hashlib, sys
+    sys.path.insert(0, ROOT)
+    import bench
+    L, H, seed, nruns, w, p, u64 = bench.WORKLOADS["S-chr22"]
+    seqs = bench.synth_seqs(L, H, seed, nruns)
+    _, dig = bench.cpu_baseline(seqs, w, p, u64, mode=("-s", "-r"))
+    c = gpu_ctx_factory(w=w, p=p, u64=u64, sai=True)
+    for s in seqs:
+        c.feed(s, True)
+    c.finalize(); c.parse_bwt(); c.bwt_build(sa=True, rssa=True)
+    o = c.bwt_get()
+    for k in ("bwt", "sa", "ssa", "esa"):
+        assert hashlib.sha256(o[k].tobytes()).hexdigest() == dig[k], k
+    chk = c.check_sample_order()
+    assert chk["pairs"] == len(o["ssa"]) // 2 - 1 and chk["order_violations"] == 0 and chk["rows_not_adjacent"] == 0, chk
+    c.close()
+
+
+def test_sample_order_check_detects_disorder(gpu_ctx_factory):
+    """the device-side order check is not vacuous: the same samples checked against a DIFFERENT text (same length) report violations"""
+    seqs = synth(77, 300_000, 3)
+    c = gpu_ctx_factory(w=10, p=100, u64=True, sai=True)
+    for s in seqs:
+        c.feed(s, True)
+    c.finalize(); c.parse_bwt(); c.bwt_build(sa=False, rssa=True)
+    good = c.check_sample_order()
+    assert good["order_violations"] == 0 and good["rows_not_adjacent"] == 0 and good["pairs"] > 1000
+    # overwrite the resident text with another one of the same length (device copy through the engine's own entry point)
+    import ctypes as C
+    other = np.frombuffer(b"".join(s + b"A" * 10 for s in synth(78, 300_000, 3)), np.uint8).copy()
+    import torch
+    d_other = torch.from_numpy(other).cuda()
+    dt, dn = C.c_void_p(0), C.c_uint64(0)
+    c._check(c.L.pfp_text_view(c.h, C.byref(dt), C.byref(dn)))
+    assert dn.value == other.size
+    c.device_copy(dt.value, d_other.data_ptr(), other.size)
+    bad = c.check_sample_order()
+    assert bad["order_violations"] > good["pairs"] // 10, bad
+    c.close()
+
+
 def test_engine_ragged_inputs(gpu_ctx_factory):
     """empty records, records shorter than w, hundreds of tiny records, one-word parses"""
     from pfp_testlib import check_ragged

@@ -193,6 +193,64 @@ def test_sharded_build_gloo_world2(emu_factory, tmp_path):
     assert pr.returncode == 0, pr.stdout[-2000:] + pr.stderr[-3000:]
 
 
+WORKER4 = r'''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.path.join(sys.argv[1], "tests")); sys.path.insert(0, os.path.join(sys.argv[1], "pfbwt-f_amd", "python"))
+from pfp_testlib import EMU_SO, compare, oracle_run
+from test_sharded import synth
+import pfbwt_hip, pfbwt_dist
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+assert world == 4
+big = synth(11, 2500, 4)
+# rank 1 holds ONE record shorter than any phrase (its parse is a single phrase), rank 2 two records one of which is empty
+shards = [[big[0], big[1][:900]], [big[2][:23]], [b"", big[3]], [big[1][900:], big[2][23:800]]]
+names = [["a0", "a1"], ["b0"], ["c0", "c1"], ["d0", "d1"]]
+seqs = [s for sh in shards for s in sh]
+mine = shards[rank]
+w, p = 6, 11
+ctx = pfbwt_hip.PfpContext(lib=EMU_SO, w=w, p=p, u64=True, sai=True)
+ok = 1
+for sa, rssa in ((True, False), (False, True)):
+    sz, b, begin, rows = pfbwt_dist.sharded_build(ctx, lambda c: [c.feed(s, True) for s in mine], w, torch.device("cpu"), sa=sa, rssa=rssa)
+    o = ctx.bwt_get()
+    parts = [None] * world
+    dist.all_gather_object(parts, (begin, rows, int(b.r), o["bwt"], o["sa"], o["ssa"], o["esa"]))
+    if rank == 0:
+        parts.sort(key=lambda t: t[0])
+        assert parts[0][0] == 0 and all(parts[i][0] + parts[i][1] == parts[i + 1][0] for i in range(world - 1))
+        res = {"n": sz.n, "m": sz.m, "dwords": sz.dwords, "dsize": sz.dsize, "r": sum(t[2] for t in parts), "bwt": np.concatenate([t[3] for t in parts])}
+        if sa: res["sa"] = np.concatenate([t[4] for t in parts])
+        if rssa: res["ssa"] = np.concatenate([t[5] for t in parts]); res["esa"] = np.concatenate([t[6] for t in parts])
+        res.update(ctx.parse_get())
+        bad = compare(res, oracle_run(seqs, w=w, p=p, U=8), 8, names=("dict", "occ", "parse", "last", "sai", "bwt") + (("sa",) if sa else ()) + (("ssa", "esa") if rssa else ()))
+        if bad: ok = 0; print("MISMATCH", sa, rssa, bad, flush=True)
+# .docs through the sharded build
+st, acc = [], 0
+for s in mine:
+    st.append(acc); acc += len(s) + w
+docs = pfbwt_dist.allgather_docs(list(zip(names[rank], st)), acc)
+want, acc = [], 0
+for nm, s in zip([n for sh in names for n in sh], seqs):
+    want.append((nm, acc)); acc += len(s) + w
+if docs != want: ok = 0; print("rank %d: docs %r != %r" % (rank, docs, want), flush=True)
+ctx.close()
+t = torch.tensor([ok]); dist.all_reduce(t, op=dist.ReduceOp.MIN)
+dist.barrier(); dist.destroy_process_group()
+sys.exit(0 if int(t) == 1 else 1)
+'''
+
+
+def test_sharded_build_gloo_world4_with_one_phrase_shard_and_docs(emu_factory, tmp_path):
+    """four ranks, one of them with a shard whose parse is a single phrase, one with an empty record; -s and -r; .docs gathered"""
+    script = tmp_path / "worker4.py"
+    script.write_text(WORKER4)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    pr = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=4", "--master-addr", "127.0.0.1", "--master-port", "29643",
+                         str(script), ROOT], capture_output=True, text=True, env=env, timeout=900)
+    assert pr.returncode == 0, pr.stdout[-2000:] + pr.stderr[-3000:]
+
+
 def sliced_emission(factory, seqs, w, p, U, nslices):
     bwt, sa, r = [], [], 0
     for sl in range(nslices):
