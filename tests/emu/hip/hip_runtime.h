@@ -38,6 +38,8 @@ struct uint2 { unsigned x, y; };
 struct uint4 { unsigned x, y, z, w; };
 static inline uint4 make_uint4(unsigned a, unsigned b, unsigned c, unsigned d) { uint4 r = {a, b, c, d}; return r; }
 static inline uint2 make_uint2(unsigned a, unsigned b) { uint2 r = {a, b}; return r; }
+struct ulonglong2 { unsigned long long x, y; };
+static inline ulonglong2 make_ulonglong2(unsigned long long a, unsigned long long b) { ulonglong2 r = {a, b}; return r; }
 
 typedef int hipError_t;
 typedef struct emu_stream_s *hipStream_t;

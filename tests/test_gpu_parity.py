@@ -185,15 +185,17 @@ def test_sample_order_check_detects_disorder(gpu_ctx_factory):
     # overwrite the resident text with another one of the same length (device copy through the engine's own entry point)
     import ctypes as C
     other = np.frombuffer(b"".join(s + b"A" * 10 for s in synth(78, 300_000, 3)), np.uint8).copy()
-    import torch
-    d_other = torch.from_numpy(other).cuda()
-    dt, dn = C.c_void_p(0), C.c_uint64(0)
+    c2 = gpu_ctx_factory(w=10, p=100, u64=True, sai=True)      # the other text reaches the device through a second context
+    for s in synth(78, 300_000, 3):
+        c2.feed(s, True)
+    dt, dn, st, sn = C.c_void_p(0), C.c_uint64(0), C.c_void_p(0), C.c_uint64(0)
     c._check(c.L.pfp_text_view(c.h, C.byref(dt), C.byref(dn)))
-    assert dn.value == other.size
-    c.device_copy(dt.value, d_other.data_ptr(), other.size)
+    c2._check(c2.L.pfp_text_view(c2.h, C.byref(st), C.byref(sn)))
+    assert dn.value == other.size == sn.value
+    c.device_copy(dt.value, st.value, other.size)
     bad = c.check_sample_order()
     assert bad["order_violations"] > good["pairs"] // 10, bad
-    c.close()
+    c.close(); c2.close()
 
 
 def test_engine_ragged_inputs(gpu_ctx_factory):
