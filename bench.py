@@ -375,7 +375,7 @@ def main():
     if world > 1 or forced:
         import torch.distributed as dist
         if forced and "RANK" not in os.environ:      # the rehearsal started plainly: a group of one rank
-            os.environ.update({"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": os.environ.get("MASTER_PORT", "29533")})
+            os.environ.update({"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": os.environ.get("MASTER_PORT", str(29000 + os.getpid() % 2000))})
         dist.init_process_group("nccl", device_id=torch.device("cuda", lrank))
     pfbwt_hip.load_library()  # raises if the gfx950 library is absent
 

@@ -71,7 +71,7 @@ static void reset_results(pfp_ctx *c)
     c->stage = 0; c->n = 0; c->tb_n = 0; c->left_ctx = 0; c->m = c->dwords = c->dsize = 0; c->nrows = 0; c->nout = c->runs = c->esa_pairs = 0;
     c->gsa_valid = false; c->d_wrank = nullptr; c->d_bwt = nullptr; c->d_sa = c->d_ssa = c->d_esa = nullptr;
     c->d_bwlast = nullptr; c->d_ilist = nullptr; c->d_bwsai = nullptr;
-    c->d_ma = nullptr; c->ma_words = 0;
+    c->d_ma = nullptr; c->ma_words = 0; c->ma_lo_mark = (size_t)-1;
     c->d_ye = nullptr; c->d_pid = nullptr; c->d_parse = nullptr; c->d_last = nullptr; c->d_dict = nullptr; c->d_ws = nullptr; c->d_wordid = nullptr;
     c->d_occ = nullptr; c->d_sdict = nullptr; c->d_gsa = nullptr; c->d_grank = nullptr;
     c->arena.reset();
@@ -1710,7 +1710,7 @@ template <typename SAT> static int marker_array_impl(pfp_ctx *c, const uint64_t 
         if (!lst.empty()) { istart.push_back(mps[i]); iend.push_back(mps[i + 1]); ilist.push_back(id); }
         i = j + 1;
     }
-    if (istart.size() >= 0xFFFFFFF0ULL || lvals.size() >= 0xFFFFFFF0ULL) return PFP_E_TOO_LARGE;
+    if (istart.size() >= 0xFFFFFFF0ULL || lvals.size() >= 0xFFFFFFF0ULL || nrows >= 0xFFFFFFF0ULL) return PFP_E_TOO_LARGE;      // run heads are counted and placed with 32-bit values
     const uint32_t nint = (uint32_t)istart.size();
     const size_t mk = c->arena.mark_hi();
     uint64_t *d_is, *d_ie, *d_lv; uint32_t *d_il, *d_lo, *rowlist, *head, *pos, *d_cnt;
@@ -1737,10 +1737,14 @@ template <typename SAT> static int marker_array_impl(pfp_ctx *c, const uint64_t 
     unsigned long long tot = 0;
     PFP_HIP(c, hipMemcpyAsync(&tot, d_tot, 8, hipMemcpyDeviceToHost, c->stream));
     PFP_HIP(c, hipStreamSynchronize(c->stream));
-    c->d_ma = nullptr; c->ma_words = tot;
+    // a result of an earlier call on the same build (several .mps streams against one suffix array) gives its space back first
+    if (c->ma_lo_mark != (size_t)-1 && c->arena.lo == c->ma_lo_end) c->arena.release_lo(c->ma_lo_mark);
+    c->d_ma = nullptr; c->ma_words = tot; c->ma_lo_mark = (size_t)-1;
     if (tot) {
+        const size_t mark = c->arena.mark_lo();
         uint64_t *d_out = (uint64_t *)c->arena.alloc_lo(tot * 8);               // result: low end, survives the release of the scratch
         if (!d_out) return PFP_E_NOMEM;
+        c->ma_lo_mark = mark; c->ma_lo_end = c->arena.mark_lo();
         PFP_LAUNCH(c, K_MISC, tot * 8, k_ma_write, nblocks(nh, BLOCK), (const uint64_t *)hrow, (const uint32_t *)hlist, (const unsigned long long *)off, (const uint32_t *)d_lo, (const uint64_t *)d_lv, (uint64_t)nh, nrows, d_out);
         PFP_HIP(c, hipStreamSynchronize(c->stream));
         c->d_ma = d_out;
@@ -1768,11 +1772,16 @@ int pfp_marker_array(pfp_ctx *c, const uint64_t *mps, uint64_t mps_words, const 
     int rc = ensure_arena(c, nrows);
     if (rc != PFP_OK) return rc;
     c->arena.reset();
-    void *d_sa = c->arena.alloc_hi(nrows * U);
-    if (!d_sa) return PFP_E_NOMEM;
-    rc = h2d_copy(c, (uint8_t *)d_sa, (const uint8_t *)sa_host, nrows * U);
-    if (rc != PFP_OK) return rc;
-    return u64 ? marker_array_impl<uint64_t>(c, mps, mps_words, (const uint64_t *)d_sa, nrows, out_words) : marker_array_impl<uint32_t>(c, mps, mps_words, (const uint32_t *)d_sa, nrows, out_words);
+    ArenaGuard g2(c);
+    auto body = [&]() -> int {
+        void *d_sa = c->arena.alloc_hi(nrows * U);
+        if (!d_sa) return PFP_E_NOMEM;
+        PFP_TRY(h2d_copy(c, (uint8_t *)d_sa, (const uint8_t *)sa_host, nrows * U));
+        return u64 ? marker_array_impl<uint64_t>(c, mps, mps_words, (const uint64_t *)d_sa, nrows, out_words) : marker_array_impl<uint32_t>(c, mps, mps_words, (const uint32_t *)d_sa, nrows, out_words);
+    };
+    rc = g2.done(body());
+    if (rc != PFP_OK) { c->d_ma = nullptr; c->ma_words = 0; c->ma_lo_mark = (size_t)-1; }
+    return rc;
 }
 int pfp_marker_array_get(pfp_ctx *c, uint64_t *dst)
 {

@@ -107,10 +107,10 @@ __global__ __launch_bounds__(BLOCK) void k_ss_runend_marks(const uint8_t *D, uin
 constexpr uint32_t RUN_MIN = DK_CHARS;
 constexpr uint8_t RF_KEEP = 1, RF_CHANGED = 2, RF_DONE = 4;
 #ifndef PFP_K3_ITEMS
-#define PFP_K3_ITEMS 8
+#define PFP_K3_ITEMS 9
 #endif
 // pairs per thread of the class-sort tile: 15 -> 3840 pairs, 49 KiB of LDS with 8-byte keys (three workgroups per CU);
-// 8 -> 2048 pairs with the 16-byte keys of K = 3 (a power of two: they are sorted by a bitonic network, 41 KiB)
+// 9 -> 2304 pairs with the 16-byte keys of K = 3 (50 KiB)
 template <int K> struct RoundCfg { static constexpr int ITEMS = K == 1 ? RS_ITEMS : PFP_K3_ITEMS, TILE = BLOCK * ITEMS; static constexpr uint32_t STEP = TILE / 2; };
 
 __global__ __launch_bounds__(BLOCK) void k_not_done(const uint8_t *done, uint64_t n, uint32_t *flag)
@@ -166,14 +166,9 @@ template <bool DICT, int K> __global__ __launch_bounds__(BLOCK) void k_round(con
 {
     constexpr int ITEMS = RoundCfg<K>::ITEMS, TILE = RoundCfg<K>::TILE;
     constexpr uint32_t STEP = RoundCfg<K>::STEP;
-    __shared__ uint32_t wh[K == 3 ? 1 : BLOCK / WAVE][K == 3 ? 1 : RS_RADIX];
-    // K = 1: 64-bit keys (class | rank) + the pair's index as payload, LSD radix passes.  K = 3: 128-bit keys { class | first rank |
-    // second rank | third rank | index of the pair } as (hi, lo) pairs, sorted by a bitonic network (see below)
-    __shared__ __attribute__((aligned(16))) uint64_t skraw[K == 3 ? 2 * TILE : TILE];
-    uint64_t *const skeys = skraw;
-    ulonglong2 *const sk2 = reinterpret_cast<ulonglong2 *>(skraw);
-    constexpr int IDXB = 11;                             // bits of a pair's index inside a K = 3 tile
-    static_assert(K != 3 || TILE == (1 << IDXB), "K = 3 tiles hold 2048 pairs");
+    __shared__ uint32_t wh[BLOCK / WAVE][RS_RADIX];
+    __shared__ uint64_t skeys[TILE];
+    __shared__ uint64_t skeyb[K == 3 ? TILE : 1];
     __shared__ uint16_t sidx[TILE];                      // payload of the LDS sort: index of the pair in the range
     __shared__ uint16_t shp[TILE + 1];                   // position (in the sorted range) of the head of every pair's new class
     __shared__ unsigned long long red[4];
@@ -252,11 +247,8 @@ template <bool DICT, int K> __global__ __launch_bounds__(BLOCK) void k_round(con
             const uint32_t j = threadIdx.x + (uint32_t)it * BLOCK;
             if (j < n) {
                 if (DICT) tnj[s + j] = njv[it];
-                const uint64_t ka = ((uint64_t)(arnk[s + j] - hmin) << lowbits) | lowv[it];
-                if constexpr (K == 3) {      // 128 bits: ka (class | first rank: at most 12 + 32 bits) | kb (second | third rank: at most 64 bits) | index (11 bits)
-                    const uint64_t kb = ((uint64_t)r2[it] << lowbits) | r3[it];
-                    sk2[j] = make_ulonglong2((ka << IDXB) | (kb >> (64 - IDXB)), (kb << IDXB) | j);
-                } else { skeys[j] = ka; sidx[j] = (uint16_t)j; }
+                skeys[j] = ((uint64_t)(arnk[s + j] - hmin) << lowbits) | lowv[it]; sidx[j] = (uint16_t)j;
+                if (K == 3) skeyb[j] = ((uint64_t)r2[it] << lowbits) | r3[it];
             }
         }
     }
@@ -267,36 +259,17 @@ template <bool DICT, int K> __global__ __launch_bounds__(BLOCK) void k_round(con
     //      the range is padded to whole waves with all-ones keys (they stay behind the real ones in a stable sort, so no
     //      item needs a validity test), the place of a pass's digit is three scalars, and the lanes that hold the same
     //      digit come from same_digit_lanes (prims.h).  Measured: 26.5 -> 24 ms for a K = 3 round over 325 M pairs.
-    if constexpr (K == 3) {
-        // ---- K = 3: bitonic sort of the 128-bit keys.  The 99 key bits cost 14 passes of the LSD radix sort above (~1300 instructions
-        //      per thread and pass: the eight ballots per item); a bitonic network over N2 <= 2048 entries has log2(N2) * (log2(N2) + 1) / 2
-        //      <= 66 compare-exchange stages of ~20 instructions per exchange and four exchanges per thread -- about a third of the
-        //      instructions --, and with the pair's index as the least significant key part all keys are distinct, so the network's
-        //      order IS the stable order.  The range is padded to a power of two with all-ones keys.
-        const uint32_t N2 = n <= 256u ? 256u : n <= 512u ? 512u : n <= 1024u ? 1024u : 2048u;
-        for (uint32_t j = n + threadIdx.x; j < N2; j += BLOCK) sk2[j] = make_ulonglong2(~0ULL, ~0ULL);
-        __syncthreads();
-        for (uint32_t k = 2; k <= N2; k <<= 1) {
-            for (uint32_t jj = k >> 1; jj > 0; jj >>= 1) {
-                for (uint32_t u = threadIdx.x; u < N2 / 2; u += BLOCK) {
-                    const uint32_t i = ((u & ~(jj - 1u)) << 1) | (u & (jj - 1u)), l = i | jj;
-                    const ulonglong2 a = sk2[i], b = sk2[l];
-                    const bool gt = a.x > b.x || (a.x == b.x && a.y > b.y);
-                    if (gt == ((i & k) == 0u)) { sk2[i] = b; sk2[l] = a; }
-                }
-                __syncthreads();
-            }
-        }
-    } else {
     const uint64_t hspan = skeys[n - 1] >> lowbits;
-    for (uint32_t j = n + threadIdx.x; j < nit * BLOCK; j += BLOCK) { skeys[j] = ~0ULL; sidx[j] = (uint16_t)j; }
+    for (uint32_t j = n + threadIdx.x; j < nit * BLOCK; j += BLOCK) { skeys[j] = ~0ULL; sidx[j] = (uint16_t)j; if (K == 3) skeyb[j] = ~0ULL; }
+    const int nb = K == 3 ? (2 * lowbits + 7) / 8 : 0;
     const int nlo = (lowbits + 7) / 8;
     int nhi = 0; while (nhi < 8 && (hspan >> (8 * nhi))) ++nhi;
-    for (int p = 0; p < nlo + nhi; ++p) {
-        const int q = p;
-        const int sh = q < nlo ? 8 * q : lowbits + 8 * (q - nlo);
-        const uint32_t dmask = (q < nlo && lowbits - 8 * q < 8) ? ((1u << (lowbits - 8 * q)) - 1u) : 255u;      // the top digit of the low part stops where the class part starts
-        uint64_t k[ITEMS]; uint16_t v[ITEMS]; unsigned dg[ITEMS];
+    for (int p = 0; p < nb + nlo + nhi; ++p) {
+        const bool use_b = p < nb;
+        const int q = p - nb;
+        const int sh = use_b ? 8 * p : q < nlo ? 8 * q : lowbits + 8 * (q - nlo);
+        const uint32_t dmask = (!use_b && q < nlo && lowbits - 8 * q < 8) ? ((1u << (lowbits - 8 * q)) - 1u) : 255u;      // the top digit of the low part stops where the class part starts
+        uint64_t k[ITEMS], kb[K == 3 ? ITEMS : 1]; uint16_t v[ITEMS]; unsigned dg[ITEMS];
 #pragma unroll
         for (int w = 0; w < BLOCK / WAVE; ++w) wh[w][threadIdx.x] = 0;
         __syncthreads();
@@ -305,7 +278,8 @@ template <bool DICT, int K> __global__ __launch_bounds__(BLOCK) void k_round(con
             if ((uint32_t)it < nit) {                                  // uniform; no break: the loop must unroll (register arrays)
             const uint32_t i = base + (uint32_t)it * WAVE;
             k[it] = skeys[i]; v[it] = sidx[i];
-            const uint32_t d = (uint32_t)(k[it] >> sh) & dmask;
+            if (K == 3) kb[it] = skeyb[i];
+            const uint32_t d = (uint32_t)(((K == 3 && use_b) ? kb[K == 3 ? it : 0] : k[it]) >> sh) & dmask;
             uint32_t plo = 0xFFFFFFFFu, phi = 0xFFFFFFFFu;            // lanes with the same digit
             same_digit_lanes(d, plo, phi);
             const int leader = plo ? __builtin_ctz(plo) : 32 + __builtin_ctz(phi);       // never empty: the lane itself
@@ -332,22 +306,17 @@ template <bool DICT, int K> __global__ __launch_bounds__(BLOCK) void k_round(con
             if ((uint32_t)it < nit) {
                 const uint32_t li = wh[wave][dg[it] & 255u] + (dg[it] >> 8);
                 skeys[li] = k[it]; sidx[li] = v[it];
+                if (K == 3) skeyb[li] = kb[K == 3 ? it : 0];
             }
         }
         __syncthreads();
-    }
     }
     // ---- new classes: pair j heads a class iff its key differs from its predecessor's; head position of every pair by a
     //      max-scan (a thread scans a contiguous chunk, the chunk maxima go through the block scan)
     const uint32_t c0 = threadIdx.x * nit, c1 = (c0 + nit < n) ? c0 + nit : n;
     uint32_t runmax = 0;
     for (uint32_t j = c0; j < c1; ++j) {
-        bool hd;
-        if constexpr (K == 3) {      // the index bits do not count; the sorted position's pair comes out of the key
-            const ulonglong2 kc = sk2[j];
-            sidx[j] = (uint16_t)(kc.y & ((1u << IDXB) - 1u));
-            hd = j == 0 || kc.x != sk2[j - 1].x || (kc.y >> IDXB) != (sk2[j - 1].y >> IDXB);
-        } else hd = j == 0 || skeys[j] != skeys[j - 1];
+        const bool hd = j == 0 || skeys[j] != skeys[j - 1] || (K == 3 && skeyb[j] != skeyb[j - 1]);
         runmax = hd ? j : runmax;
         shp[j] = (uint16_t)runmax;                       // exact only behind the first head of the chunk; fixed below
     }
