@@ -203,6 +203,11 @@ int pfp_bwt_build_slice(pfp_ctx *ctx, int want_sa, int want_rssa, int slice, int
                         uint64_t *slice_begin, uint64_t *slice_rows, uint64_t *esa_pairs);
 /* copy results to host (NULL skips): bwt nout bytes; sa nout U-wide; ssa 2*r, esa 2*r (slices: 2*esa_pairs) U-wide */
 int pfp_bwt_get(pfp_ctx *ctx, uint8_t *bwt, void *sa, void *ssa, void *esa);
+/* The results of the last build straight to file descriptors (-1 skips one): what out_fn of src/pfbwt-f.cpp:298-328 writes with two to
+ * four fwrite calls per base.  The bytes leave the device in 64 MiB blocks through page-locked buffers; the transfer of a block
+ * overlaps the write of the one before; a regular file is written by several threads (pwrite at the block's offset), a pipe --
+ * `-c bwt`: stdout -- in order by one.  PFP_E_IO: a write failed. */
+int pfp_bwt_write(pfp_ctx *ctx, int fd_bwt, int fd_sa, int fd_ssa, int fd_esa);
 /* device pointers of the same results (valid until the next pfp_* call that rebuilds them) */
 int pfp_bwt_device_ptrs(pfp_ctx *ctx, const void **d_bwt, const void **d_sa, const void **d_ssa, const void **d_esa);
 

@@ -155,7 +155,7 @@ struct pfp_ctx {
     // --- raw FASTA ingest (csrc/fasta.h): two device buffers for raw chunks (the upload of one overlaps the stripping of the other)
     struct FastaIngest {
         uint8_t *raw[2] = {nullptr, nullptr}; size_t rawcap = 0; bool used[2] = {false, false};
-        hipStream_t copy = nullptr; hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
+        hipStream_t copy = nullptr; bool copy_ready = false; hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
         uint8_t *tiles = nullptr; size_t tiles_cap = 0;                 // per-tile summaries of one chunk
         unsigned long long *d_tot = nullptr, *h_tot = nullptr;          // device / page-locked host: kept bytes, header starts, end state, flags
         uint32_t state = 2; bool started = false; uint64_t records = 0; // the stream's state machine (2 = at a line start)

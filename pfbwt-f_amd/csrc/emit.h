@@ -453,7 +453,6 @@ template <typename SAT, typename EBT> __global__ __launch_bounds__(BLOCK) void k
 {
     __shared__ uint32_t eb[EMIT_LDS_SLOTS];                  // EB[i0 + k] - EB[i0]
     __shared__ uint32_t rs[EMIT_TILE];                       // slot (relative to i0) of every row of the tile
-    __shared__ uint32_t tq[EMIT_TILE];                       // parse row of every row of the tile (run-aware emission)
     __shared__ uint32_t red[4];
     const EBT *EB = reinterpret_cast<const EBT *>(a.EB);
     const EBT *ENB = reinterpret_cast<const EBT *>(a.ENB);      // enumeration order: == EB unless only the special slots are walked
@@ -494,40 +493,19 @@ template <typename SAT, typename EBT> __global__ __launch_bounds__(BLOCK) void k
         for (int j = 0; j < EMIT_PER_THREAD; ++j) rs[threadIdx.x * EMIT_PER_THREAD + j] = loc[j] > prev ? loc[j] : prev;
         __syncthreads();
     }
-    // Run-aware emission enumerates the special slots only, and the members of a group of equal suffixes are neighbours in that
-    // enumeration: a row that has to be ranked in the OTHER members' occurrence lists (pfbwt.hpp:137-181) finds those lists among
-    // the rows of its own tile, most of the time (a group has hundreds of rows, a tile 2048).  The parse rows of the tile's rows
-    // are therefore staged in LDS once, and the bisections run there -- a tenth of the latency of a bisection in memory, which is
-    // what bounds this kernel.  Lists that stick out of the tile are bisected in memory as before.
-    const bool lds_rank = in_lds && a.special;
-    if (lds_rank) {
-        const uint32_t nrow = (uint32_t)(o1 - o0);
-        uint32_t sl[EMIT_PER_THREAD], rr[EMIT_PER_THREAD];
-#pragma unroll
-        for (int k = 0; k < EMIT_PER_THREAD; ++k) {
-            const uint32_t row = (uint32_t)k * BLOCK + threadIdx.x;
-            const uint32_t j = row < nrow ? rs[row] : 0u;
-            sl[k] = row < nrow ? a.elist[i0 + j] : 0u; rr[k] = (uint32_t)(o0 - ebase) + row - eb[j];
-        }
-#pragma unroll
-        for (int k = 0; k < EMIT_PER_THREAD; ++k) { const uint32_t row = (uint32_t)k * BLOCK + threadIdx.x; if (row < nrow) sl[k] = a.sinfo[sl[k]].x; }
-#pragma unroll
-        for (int k = 0; k < EMIT_PER_THREAD; ++k) { const uint32_t row = (uint32_t)k * BLOCK + threadIdx.x; if (row < nrow) tq[row] = a.ilist[sl[k] + rr[k]]; }
-        __syncthreads();
-    }
     // EMIT_ROWS_IN_FLIGHT rows per thread are taken through the load stages together (slot search, per-slot fields,
     // ilist, bwsai): the kernel is bound by the latency of these dependent loads, not by bandwidth.
 #pragma unroll 1
     for (int k = 0; k < EMIT_PER_THREAD; k += EMIT_ROWS_IN_FLIGHT) {
         uint64_t o[EMIT_ROWS_IN_FLIGHT]; uint32_t i[EMIT_ROWS_IN_FLIGHT], r[EMIT_ROWS_IN_FLIGHT], q[EMIT_ROWS_IN_FLIGHT];
-        uint4 S[EMIT_ROWS_IN_FLIGHT]; uint8_t fl[EMIT_ROWS_IN_FLIGHT]; bool on[EMIT_ROWS_IN_FLIGHT]; uint64_t sv[EMIT_ROWS_IN_FLIGHT]; uint32_t jl[EMIT_ROWS_IN_FLIGHT];
+        uint4 S[EMIT_ROWS_IN_FLIGHT]; uint8_t fl[EMIT_ROWS_IN_FLIGHT]; bool on[EMIT_ROWS_IN_FLIGHT]; uint64_t sv[EMIT_ROWS_IN_FLIGHT];
 #pragma unroll
         for (int u = 0; u < EMIT_ROWS_IN_FLIGHT; ++u) {
             o[u] = o0 + (uint64_t)(k + u) * BLOCK + threadIdx.x;
             on[u] = o[u] < o1;
             const uint64_t oo = on[u] ? o[u] : o0;
-            if (in_lds) { const uint32_t j = rs[(uint32_t)(oo - o0)]; i[u] = i0 + j; jl[u] = j; r[u] = (uint32_t)(oo - ebase) - eb[j]; }
-            else { i[u] = upper_bound_t<EBT>(ENB, a.ecount, (EBT)oo) - 1u; jl[u] = 0; r[u] = (uint32_t)(oo - (uint64_t)ENB[i[u]]); }
+            if (in_lds) { const uint32_t j = rs[(uint32_t)(oo - o0)]; i[u] = i0 + j; r[u] = (uint32_t)(oo - ebase) - eb[j]; }
+            else { i[u] = upper_bound_t<EBT>(ENB, a.ecount, (EBT)oo) - 1u; r[u] = (uint32_t)(oo - (uint64_t)ENB[i[u]]); }
         }
         if (a.elist) {
 #pragma unroll
@@ -536,7 +514,7 @@ template <typename SAT, typename EBT> __global__ __launch_bounds__(BLOCK) void k
 #pragma unroll
         for (int u = 0; u < EMIT_ROWS_IN_FLIGHT; ++u) { S[u] = a.sinfo[i[u]]; fl[u] = (uint8_t)(S[u].w >> 24); }
 #pragma unroll
-        for (int u = 0; u < EMIT_ROWS_IN_FLIGHT; ++u) q[u] = lds_rank ? tq[on[u] ? (uint32_t)(o[u] - o0) : 0u] : a.ilist[S[u].x + r[u]];   // parse-BWT row of this occurrence
+        for (int u = 0; u < EMIT_ROWS_IN_FLIGHT; ++u) q[u] = a.ilist[S[u].x + r[u]];                   // parse-BWT row of this occurrence
 #pragma unroll
         for (int u = 0; u < EMIT_ROWS_IN_FLIGHT; ++u) sv[u] = (sa && on[u] && !(fl[u] & SF_BIG)) ? a.bwsai[q[u]] : 0ULL;
         // rows in ordinary multi-member groups: the bisections of all rows in flight run in one loop (EMIT_RANK_W lists per
@@ -547,32 +525,6 @@ template <typename SAT, typename EBT> __global__ __launch_bounds__(BLOCK) void k
             const bool plain = on[u] && (fl[u] & SF_MULTI) && !(fl[u] & (SF_GFULL | SF_BIG));
             gk_[u] = plain ? (S[u].w & 0xFFFFFFu) : 0u; before[u] = 0;
             maxk = gk_[u] > maxk ? gk_[u] : maxk;
-        }
-        if (lds_rank) {
-            // members of the row's group by their index in the enumeration: head = jl - (slot - head slot); member mm's rows are the
-            // tile's rows [eb[head + mm], eb[head + mm + 1]) -- ranked in LDS if they all lie inside the tile, in memory otherwise
-            const uint32_t rel0 = (uint32_t)(o0 - ebase), rel1 = (uint32_t)(o1 - ebase);
-#pragma unroll
-            for (int u = 0; u < EMIT_ROWS_IN_FLIGHT; ++u) {
-                const uint32_t kk = gk_[u];
-                const int64_t jh = (int64_t)jl[u] - (int64_t)(i[u] - S[u].z);
-                for (uint32_t mm = 0; mm < kk; ++mm) {
-                    const uint32_t sm = S[u].z + mm;
-                    if (sm == i[u]) continue;
-                    const int64_t jm = jh + (int64_t)mm;
-                    bool done = false;
-                    if (jm >= 0 && (uint64_t)jm + 1u < (uint64_t)ns) {
-                        const uint32_t st = eb[(uint32_t)jm], en = eb[(uint32_t)jm + 1u];
-                        if (st >= rel0 && en <= rel1) {
-                            uint32_t lo_ = st - rel0, hi_ = en - rel0;             // first row of the member with a parse row >= q
-                            while (lo_ < hi_) { const uint32_t mid = lo_ + ((hi_ - lo_) >> 1); if (tq[mid] < q[u]) lo_ = mid + 1u; else hi_ = mid; }
-                            before[u] += lo_ - (st - rel0); done = true;
-                        }
-                    }
-                    if (!done) before[u] += rank_in_members<1>(a, &sm, q[u]);
-                }
-            }
-            maxk = 0;
         }
         for (uint32_t s0 = 0; s0 < maxk; s0 += EMIT_RANK_W) {
             uint32_t mem[EMIT_ROWS_IN_FLIGHT * EMIT_RANK_W], qq[EMIT_ROWS_IN_FLIGHT * EMIT_RANK_W], res[EMIT_ROWS_IN_FLIGHT * EMIT_RANK_W];

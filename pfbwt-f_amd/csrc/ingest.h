@@ -225,4 +225,61 @@ static int ingest_file(pfp_ctx *c, const char *path, unsigned flags, IngestStats
     return rc;
 }
 
+// ---- the way out: a device-resident result goes to a file descriptor through the same ring of page-locked blocks -- the DMA
+// transfer of block k + 1 overlaps the write of block k; a regular file is written by several threads with pwrite at the blocks'
+// own offsets, a pipe (`-c bwt`: stdout) by one thread in order.  Stands in for the per-row fwrite of out_fn,
+// src/pfbwt-f.cpp:298-328 (two to four calls per base there).
+static int write_device_to_fd(pfp_ctx *c, const void *d_src, uint64_t bytes, int fd)
+{
+    if (!bytes) return PFP_OK;
+    PFP_TRY(ensure_copy_stream(c));
+    constexpr int NB = 8;
+    const off_t base = lseek(fd, 0, SEEK_CUR);
+    const bool seekable = base != (off_t)-1;
+    const int nw = seekable ? 4 : 1;
+    for (int k = 0; k < NB; ++k) if (!c->ing_buf[k]) PFP_HIP(c, hipHostMalloc((void **)&c->ing_buf[k], ING_BLOCK, hipHostMallocDefault));
+    hipEvent_t ev[NB];
+    for (int k = 0; k < NB; ++k) PFP_HIP(c, hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
+    const uint64_t nblk = (bytes + ING_BLOCK - 1) / ING_BLOCK;
+    std::mutex mu; std::condition_variable cv;
+    uint64_t issued = 0, written[NB]; bool fail = false;          // written[s]: blocks of slot s that are on the file (a slot is re-used when its previous block is)
+    for (auto &x : written) x = 0;
+    auto writer = [&](int tid) {
+        for (uint64_t b = (uint64_t)tid; b < nblk; b += (uint64_t)nw) {
+            const int slot = (int)(b % NB);
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return fail || issued > b; }); if (fail) return; }
+            bool ok = hipEventSynchronize(ev[slot]) == hipSuccess;
+            const uint64_t off = b * ING_BLOCK, len = bytes - off < ING_BLOCK ? bytes - off : ING_BLOCK;
+            for (uint64_t done = 0; ok && done < len;) {
+                const ssize_t r = seekable ? pwrite(fd, c->ing_buf[slot] + done, (size_t)(len - done), base + (off_t)(off + done)) : write(fd, c->ing_buf[slot] + done, (size_t)(len - done));
+                if (r <= 0) ok = false; else done += (uint64_t)r;
+            }
+            std::lock_guard<std::mutex> lk(mu);
+            if (!ok) fail = true;
+            written[slot] += 1;
+            cv.notify_all();
+            if (!ok) return;
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 0; t < nw; ++t) th.emplace_back(writer, t);
+    int rc = PFP_OK;
+    for (uint64_t b = 0; b < nblk && rc == PFP_OK; ++b) {
+        const int slot = (int)(b % NB);
+        { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return fail || written[slot] >= b / NB; }); if (fail) { rc = PFP_E_IO; break; } }
+        const uint64_t off = b * ING_BLOCK, len = bytes - off < ING_BLOCK ? bytes - off : ING_BLOCK;
+        if (hipMemcpyAsync(c->ing_buf[slot], (const uint8_t *)d_src + off, (size_t)len, hipMemcpyDeviceToHost, c->fa.copy) != hipSuccess || hipEventRecord(ev[slot], c->fa.copy) != hipSuccess) { (void)hipGetLastError(); rc = PFP_E_HIP; }
+        std::lock_guard<std::mutex> lk(mu);
+        if (rc != PFP_OK) fail = true; else issued = b + 1;
+        cv.notify_all();
+    }
+    { std::lock_guard<std::mutex> lk(mu); if (rc != PFP_OK) fail = true; } cv.notify_all();
+    for (auto &t : th) t.join();
+    (void)hipStreamSynchronize(c->fa.copy);
+    for (int k = 0; k < NB; ++k) (void)hipEventDestroy(ev[k]);
+    if (rc == PFP_OK && fail) rc = PFP_E_IO;
+    if (rc == PFP_OK && seekable && lseek(fd, base + (off_t)bytes, SEEK_SET) == (off_t)-1) rc = PFP_E_IO;
+    return rc;
+}
+
 } // namespace pfp

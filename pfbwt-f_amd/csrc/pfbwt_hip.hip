@@ -173,7 +173,7 @@ void pfp_destroy(pfp_ctx *c)
     if (c->fa.tiles) (void)hipFree(c->fa.tiles);
     if (c->fa.d_tot) (void)hipFree(c->fa.d_tot);
     if (c->fa.h_tot) (void)hipHostFree(c->fa.h_tot);
-    if (c->fa.copy) (void)hipStreamDestroy(c->fa.copy);
+    if (c->fa.copy_ready) (void)hipStreamDestroy(c->fa.copy);
     for (auto &q : c->ing_buf) if (q) (void)hipHostFree(q);
     if (c->d_trigtab) (void)hipFree(c->d_trigtab);
     for (int k = 0; k < 2; ++k) { if (c->hstage[k]) (void)hipHostFree(c->hstage[k]); if (c->hstage_ev[k]) (void)hipEventDestroy(c->hstage_ev[k]); }
@@ -362,8 +362,9 @@ int pfp_parse_reserve(pfp_ctx *c, uint64_t text_bytes)
 static int ensure_copy_stream(pfp_ctx *c)
 {
     auto &f = c->fa;
-    if (f.copy) return PFP_OK;
+    if (f.copy_ready) return PFP_OK;
     PFP_HIP(c, hipStreamCreateWithFlags(&f.copy, hipStreamNonBlocking));
+    f.copy_ready = true;
     for (int k = 0; k < 2; ++k) { PFP_HIP(c, hipEventCreateWithFlags(&f.ev_copied[k], hipEventDisableTiming)); PFP_HIP(c, hipEventCreateWithFlags(&f.ev_free[k], hipEventDisableTiming)); }
     PFP_HIP(c, hipMalloc((void **)&f.d_tot, 64));
     PFP_HIP(c, hipHostMalloc((void **)&f.h_tot, 64, hipHostMallocDefault));
@@ -504,6 +505,19 @@ int pfp_parse_feed_fasta_file(pfp_ctx *c, const char *path, unsigned flags, pfp_
     const int rc = ingest_file(c, path, flags, &st);
     if (info) { info->raw_bytes = st.raw_bytes; info->records = st.records; info->n = c->n; info->read_wait_ms = st.read_wait_ms; info->total_ms = st.total_ms; info->mode = st.mode; }
     return rc;
+}
+int pfp_bwt_write(pfp_ctx *c, int fd_bwt, int fd_sa, int fd_ssa, int fd_esa)
+{
+    if (!c) return PFP_E_ARG;
+    if (c->stage < 3) return PFP_E_STATE;
+    PFP_HIP(c, hipSetDevice(c->device));
+    PFP_HIP(c, hipStreamSynchronize(c->stream));
+    const size_t U = (c->flags & PFP_FLAG_U64) ? 8 : 4;
+    if (fd_bwt >= 0) PFP_TRY(write_device_to_fd(c, c->d_bwt, c->slice_rows, fd_bwt));
+    if (fd_sa >= 0) { if (!c->d_sa) return PFP_E_STATE; PFP_TRY(write_device_to_fd(c, c->d_sa, c->slice_rows * U, fd_sa)); }
+    if (fd_ssa >= 0) { if (!c->d_ssa) return PFP_E_STATE; PFP_TRY(write_device_to_fd(c, c->d_ssa, c->runs * 2 * U, fd_ssa)); }
+    if (fd_esa >= 0) { if (!c->d_esa) return PFP_E_STATE; PFP_TRY(write_device_to_fd(c, c->d_esa, c->esa_pairs * 2 * U, fd_esa)); }
+    return PFP_OK;
 }
 int pfp_parse_docs(pfp_ctx *c, uint64_t *count) { if (!c || !count) return PFP_E_ARG; *count = c->doc_names.size(); return PFP_OK; }
 int pfp_parse_doc_get(pfp_ctx *c, uint64_t i, const char **name, uint64_t *start)

@@ -88,6 +88,16 @@ template <template <typename, typename...> class ReadConType, template <typename
         built_ = true;
     }
 
+    // the command line's fast path: the build, and the outputs straight from the device to the files (fd < 0: not wanted) --
+    // no host copy of the whole output, no per-row callback.  runs() / easy_cases() / hard_cases() are valid afterwards.
+    void build_to_files(int fd_bwt, int fd_sa, int fd_ssa, int fd_esa)
+    {
+        pfp_bwt_sizes bs;
+        engine_check(ctx_, pfp_bwt_build(ctx_, build_sa ? 1 : 0, build_rssa ? 1 : 0, &bs), "pfp_bwt_build");
+        nout_ = bs.nout; r_ = bs.r; easy_ = bs.easy_cases; hard_ = bs.hard_cases;
+        engine_check(ctx_, pfp_bwt_write(ctx_, fd_bwt, build_sa ? fd_sa : -1, build_rssa ? fd_ssa : -1, build_rssa ? fd_esa : -1), "pfp_bwt_write");
+    }
+
     template <typename Fn> void generate_bwt_lcp(Fn out_fn)
     {
         if (verbose) fprintf(stderr, "generating dict suffixes\n");

@@ -87,11 +87,6 @@ FILE *open_out(const Options &o, const char *ext)
     if (f == NULL) die(name.c_str());
     return f;
 }
-template <typename T> void write_all(FILE *f, const std::vector<T> &v)
-{
-    if (v.size() && fwrite(v.data(), sizeof(T), v.size(), f) != v.size()) die("could not write file");
-    if (f != stdout) fclose(f); else fflush(f);
-}
 
 using parser_t = pfbwtf::PfParser<WangHash>;
 
@@ -142,10 +137,11 @@ template <template <typename, typename...> class R, template <typename, typename
     pfbwt_t *p = (parsed && parsed->engine() && parsed->parse_bwt_done()) ? new pfbwt_t(parsed->engine(), a) : new pfbwt_t(a, n);
     {
         StageTimer t((o.sa || o.rssa) ? "TASK\tgenerating final BWT w/ full and/or run-length SA\t" : "TASK\tgenerating final BWT w/o SA\t");
-        p->build();                                            // generate_bwt_lcp + out_fn, fused on the device
-        write_all(bwt_fp, p->bwt());
-        if (o.sa) write_all(open_out(o, "sa"), p->sa());
-        if (o.rssa) { write_all(open_out(o, "ssa"), p->ssa()); write_all(open_out(o, "esa"), p->esa()); }
+        // generate_bwt_lcp + out_fn, fused on the device; the outputs go from the device to the files in blocks
+        FILE *sa_fp = o.sa ? open_out(o, "sa") : NULL, *ssa_fp = o.rssa ? open_out(o, "ssa") : NULL, *esa_fp = o.rssa ? open_out(o, "esa") : NULL;
+        fflush(stdout);
+        p->build_to_files(fileno(bwt_fp), sa_fp ? fileno(sa_fp) : -1, ssa_fp ? fileno(ssa_fp) : -1, esa_fp ? fileno(esa_fp) : -1);
+        for (FILE *f : {bwt_fp, sa_fp, ssa_fp, esa_fp}) if (f && f != stdout) fclose(f);
     }
     fprintf(stderr, "# easy cases: %lu, # hard cases: %lu\n", (unsigned long)p->easy_cases(), (unsigned long)p->hard_cases());
     fprintf(stderr, "n: %lu\n", (unsigned long)n);
