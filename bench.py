@@ -269,8 +269,8 @@ def e2e_child(a):
         bufs = {"bwt": np.empty(fsize + 64, np.uint8)}
         if want_sa:
             bufs["sa"] = np.empty((fsize + 64) * U, np.uint8)
-        if want_rssa:      # r is not known in advance: room for n / 6 runs (4 * U bytes each), pageable arrays if there are more
-            bufs["samples"] = np.empty((fsize // 6 + 64) * 4 * U, np.uint8)
+        if want_rssa:      # r is not known in advance: page-locked room for n / 128 runs (4 * U bytes each; S-32G has n / 383), pageable arrays if there are more
+            bufs["samples"] = np.empty((fsize // 128 + 64) * 4 * U, np.uint8)
         step = 1 << 28
         with ThreadPoolExecutor(max_workers=16) as ex:
             for b in bufs.values():
