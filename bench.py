@@ -284,7 +284,9 @@ def e2e_child(a):
     th = threading.Thread(target=prepare_outputs); th.start()
     ctx = pfbwt_hip.PfpContext(w=w, p=p, u64=u64, sai=True, device=0)
     runs = []
-    for it in range(2):
+    rle = want_rssa and not want_sa      # -r: the .bwt crosses PCIe as one byte per run and is written out by host threads (pfp_bwt_get_expanded)
+    for it in range(3 if rle else 2):
+        expanded = rle and it < 2          # run 2 (warm): every row over PCIe while the emission runs (pfp_bwt_build_stream), for comparison
         t0 = t_start if it == 0 else time.perf_counter()
         t_in0 = time.perf_counter()
         info = ctx.feed_fasta_file(a.e2e_child)
@@ -293,7 +295,10 @@ def e2e_child(a):
         t2 = time.perf_counter()
         th.join()
         t3 = time.perf_counter()
-        b = ctx.bwt_build_stream(outs["bwt"].ctypes.data, outs["sa"].ctypes.data if want_sa else None, rssa=want_rssa)
+        if expanded:
+            b = ctx.bwt_build(sa=False, rssa=True)
+        else:
+            b = ctx.bwt_build_stream(outs["bwt"].ctypes.data, outs["sa"].ctypes.data if want_sa else None, rssa=want_rssa)
         t4 = time.perf_counter()
         ssa = esa = None
         if want_rssa:
@@ -303,12 +308,20 @@ def e2e_child(a):
             else:
                 ssa, esa = ctx.samples_get()
         t5 = time.perf_counter()
+        if expanded:
+            ctx.bwt_get_expanded(outs["bwt"].ctypes.data, ssa, threads=16)
+        t6 = time.perf_counter()
         n = sz.n
-        runs.append({"ms": 1e3 * (t5 - t0), "startup_ms": 1e3 * (t_in0 - t0), "ingest_ms": 1e3 * (t1 - t_in0), "reader_GBps": info.raw_bytes / (t1 - t_in0) / 1e9,
+        if expanded and it == 1:      # checked apart from the streamed copy that overwrites the buffer in run 2
+            exp_sum = host_wordsum(outs["bwt"][:n + 1])
+        runs.append({"ms": 1e3 * (t6 - t0), "startup_ms": 1e3 * (t_in0 - t0), "ingest_ms": 1e3 * (t1 - t_in0), "reader_GBps": info.raw_bytes / (t1 - t_in0) / 1e9,
                      "reader_mode": info.mode, "reader_wait_ms": info.read_wait_ms, "parse_ms": 1e3 * (t2 - t1), "wait_for_output_buffers_ms": 1e3 * (t3 - t2),
-                     "emit_and_download_ms": 1e3 * (t4 - t3), "samples_download_ms": 1e3 * (t5 - t4), "value": n / (t5 - t0) / 1e9, "unit": "Gbases/s",
-                     "n": int(n), "r": int(b.r), "raw_bytes": int(info.raw_bytes), "records": int(info.records)})
+                     ("emit_ms" if expanded else "emit_and_download_ms"): 1e3 * (t4 - t3), "samples_download_ms": 1e3 * (t5 - t4),
+                     "bwt_from_runs_ms": 1e3 * (t6 - t5) if expanded else None, "bwt_path": "one byte per run over PCIe + 16 host threads (pfp_bwt_get_expanded)" if expanded else "every row over PCIe, overlapped with the emission (pfp_bwt_build_stream)",
+                     "value": n / (t6 - t0) / 1e9, "unit": "Gbases/s", "n": int(n), "r": int(b.r), "raw_bytes": int(info.raw_bytes), "records": int(info.records)})
     res = {"cold": runs[0], "warm": runs[1], "output_buffers": {"fault_ms": outs["fault_ms"], "register_ms": outs["register_ms"]}}
+    if rle:
+        res["warm_streamed"] = runs[2]; res["sum_bwt_from_runs"] = exp_sum
     # what reached host memory: word sums of .bwt (and .sa), compared by the parent with the device-resident outputs of the timed steps
     n = runs[1]["n"]
     res["sums"] = {"bwt": host_wordsum(outs["bwt"][:n + 1])}
@@ -556,11 +569,14 @@ def main():
                     raise RuntimeError("child failed: " + pc.stderr[-600:])
                 ej = json.loads(pc.stdout.strip().splitlines()[-1])
                 ej["match_device_outputs"] = {k: ej["sums"][k] == v for k, v in dev_sums.items()}
+                if "sum_bwt_from_runs" in ej:
+                    ej["match_device_outputs"]["bwt_from_runs"] = ej.pop("sum_bwt_from_runs") == dev_sums["bwt"]
                 del ej["sums"]
                 ej["child_process_wall_ms"] = 1e3 * wall
                 ej["image"] = {"bytes": fbytes, "where": os.path.dirname(img), "written_in_s": t_img, "format": "one record per haplotype, >hap<h>, 60 000-character lines"}
                 ej["what"] = ("FASTA image (memory-resident file) -> pfp_parse_feed_fasta_file (the call PfParser::add_fasta makes: parallel pread into page-locked blocks, "
-                              "upload, header / newline stripping on the device) -> parse -> emission streamed to page-locked host memory -> run samples.  cold: clock starts "
+                              "upload, header / newline stripping on the device) -> parse -> emission -> run samples + .bwt to page-locked host memory (-r: the .bwt as one byte per run, written out by 16 host "
+                              "threads; warm_streamed: every row over PCIe while the emission runs).  cold: clock starts "
                               "before the library is loaded in a fresh process on an idle card; warm: second build in that process")
                 res["end_to_end_fasta"] = ej
                 if not all(ej["match_device_outputs"].values()) or not all(res["end_to_end"]["outputs_match_device"].values()):

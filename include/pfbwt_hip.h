@@ -203,6 +203,11 @@ int pfp_bwt_build_slice(pfp_ctx *ctx, int want_sa, int want_rssa, int slice, int
                         uint64_t *slice_begin, uint64_t *slice_rows, uint64_t *esa_pairs);
 /* copy results to host (NULL skips): bwt nout bytes; sa nout U-wide; ssa 2*r, esa 2*r (slices: 2*esa_pairs) U-wide */
 int pfp_bwt_get(pfp_ctx *ctx, uint8_t *bwt, void *sa, void *ssa, void *esa);
+/* `.bwt` into host memory through its run-length form (needs the state left by pfp_bwt_build(want_rssa = 1) over the whole output):
+ * row `.ssa[k]` starts run k, so one byte per run crosses PCIe (r bytes instead of n + 1 -- 84 MB instead of 32 GB on a 1000-haplotype
+ * collection) and `threads` host threads write the runs out.  ssa_host: the 2 * r U-wide values pfp_bwt_get returned for `.ssa`
+ * (NULL: fetched again).  host_bwt receives exactly the n + 1 bytes of pfp_bwt_get. */
+int pfp_bwt_get_expanded(pfp_ctx *ctx, uint8_t *host_bwt, const void *ssa_host, int threads);
 /* The results of the last build straight to file descriptors (-1 skips one): what out_fn of src/pfbwt-f.cpp:298-328 writes with two to
  * four fwrite calls per base.  The bytes leave the device in 64 MiB blocks through page-locked buffers; the transfer of a block
  * overlaps the write of the one before; a regular file is written by several threads (pwrite at the block's offset), a pipe --

@@ -139,7 +139,7 @@ struct pfp_ctx {
     bool have_sa = false, have_rssa = false;
     uint64_t *d_ma = nullptr; uint64_t ma_words = 0;      // marker array (pfp_marker_array)
     size_t ma_lo_mark = (size_t)-1, ma_lo_end = 0;        // where its result sits at the low end of the arena (released by the next call)
-    size_t lo_after_parse = 0, lo_after_pbwt = 0;
+    size_t lo_after_parse = 0, lo_after_pbwt = 0, emit_scratch_mark = 0;
     // --- instrumentation
     bool prof_on = false; uint64_t prof_mask = ~0ULL;
     pfp::ProfRec prof[pfp::K_COUNT_];

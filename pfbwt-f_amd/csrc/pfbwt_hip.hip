@@ -519,6 +519,45 @@ int pfp_bwt_write(pfp_ctx *c, int fd_bwt, int fd_sa, int fd_ssa, int fd_esa)
     if (fd_esa >= 0) { if (!c->d_esa) return PFP_E_STATE; PFP_TRY(write_device_to_fd(c, c->d_esa, c->esa_pairs * 2 * U, fd_esa)); }
     return PFP_OK;
 }
+// .bwt over the slow link in its run-length form: with the run samples at hand, .ssa[k].row starts run k, so ONE byte per run (r bytes:
+// 84 MB on S-32G) crosses PCIe instead of n + 1 (32 GB), and host threads write the runs out (memset) at memory bandwidth.
+extern "C++" {
+template <typename SAT> __global__ __launch_bounds__(BLOCK) void k_run_heads(const uint8_t *bwt, const SAT *ssa, uint64_t r, uint8_t *heads)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (k < r) heads[k] = bwt[(uint64_t)ssa[2 * k]];
+}
+}
+int pfp_bwt_get_expanded(pfp_ctx *c, uint8_t *host_bwt, const void *ssa_host, int threads)
+{
+    if (!c || !host_bwt) return PFP_E_ARG;
+    if (c->stage < 3 || !c->d_ssa || !c->d_bwt || c->slice_rows != c->nout || c->slice_begin != 0) return PFP_E_STATE;      // needs the whole output's run samples
+    PFP_HIP(c, hipSetDevice(c->device));
+    const bool u64 = (c->flags & PFP_FLAG_U64) != 0;
+    const uint64_t r = c->runs, nout = c->nout;
+    const size_t mk = c->arena.mark_hi();
+    uint8_t *d_heads; PFP_ALLOC_HI(c, d_heads, uint8_t, r);
+    if (u64) PFP_LAUNCH(c, K_MISC, r * 9, (k_run_heads<uint64_t>), nblocks(r, BLOCK), (const uint8_t *)c->d_bwt, (const uint64_t *)c->d_ssa, r, d_heads);
+    else PFP_LAUNCH(c, K_MISC, r * 5, (k_run_heads<uint32_t>), nblocks(r, BLOCK), (const uint8_t *)c->d_bwt, (const uint32_t *)c->d_ssa, r, d_heads);
+    std::vector<uint8_t> heads((size_t)r);
+    PFP_HIP(c, hipMemcpyAsync(heads.data(), d_heads, (size_t)r, hipMemcpyDeviceToHost, c->stream));
+    std::vector<uint8_t> own;
+    if (!ssa_host) { own.resize((size_t)r * 2 * (u64 ? 8 : 4)); PFP_HIP(c, hipMemcpyAsync(own.data(), c->d_ssa, own.size(), hipMemcpyDeviceToHost, c->stream)); ssa_host = own.data(); }
+    PFP_HIP(c, hipStreamSynchronize(c->stream));
+    c->arena.release_hi(mk);
+    if (threads < 1) threads = 1;
+    if (threads > 64) threads = 64;
+    auto row = [&](uint64_t k) -> uint64_t { return k >= r ? nout : (u64 ? ((const uint64_t *)ssa_host)[2 * k] : (uint64_t)((const uint32_t *)ssa_host)[2 * k]); };
+    std::vector<std::thread> th;
+    for (int t = 0; t < threads; ++t)
+        th.emplace_back([&, t] {
+            const uint64_t k0 = r * (uint64_t)t / (uint64_t)threads, k1 = r * (uint64_t)(t + 1) / (uint64_t)threads;
+            uint64_t a = row(k0);
+            for (uint64_t k = k0; k < k1; ++k) { const uint64_t b = row(k + 1); memset(host_bwt + a, heads[(size_t)k], (size_t)(b - a)); a = b; }
+        });
+    for (auto &t : th) t.join();
+    return PFP_OK;
+}
 int pfp_parse_docs(pfp_ctx *c, uint64_t *count) { if (!c || !count) return PFP_E_ARG; *count = c->doc_names.size(); return PFP_OK; }
 int pfp_parse_doc_get(pfp_ctx *c, uint64_t i, const char **name, uint64_t *start)
 {
@@ -1480,6 +1519,10 @@ template <typename SAT, typename EBT> static int emit_and_sample(pfp_ctx *c, Emi
     }
     if (want_rssa) {   // .ssa / .esa samples (pfbwt-f.cpp:306-315, 325-328) of the runs that start in this slice
         const uint64_t r = c->runs;
+        if (sabuf) {      // with a full SA the samples need nothing of the per-slot arrays any more (~60 B per dictionary byte): on a
+            PFP_HIP(c, hipStreamSynchronize(c->stream));      // non-repetitive genome (S-3G: r = 0.74 n) they and the samples do not fit together
+            c->arena.release_hi(c->emit_scratch_mark);
+        }
         SAT *ssa, *esa;
         PFP_ALLOC_LO(c, ssa, SAT, 2 * r + 2); PFP_ALLOC_LO(c, esa, SAT, 2 * r + 4);
         c->d_ssa = ssa; c->d_esa = esa;
@@ -1622,6 +1665,7 @@ static int bwt_build_body(pfp_ctx *c, int want_sa, int want_rssa, int slice, int
 {
     HostTimer timer;
     const size_t mk = c->arena.mark_hi();
+    c->emit_scratch_mark = mk;
     const uint64_t dsize = c->dsize, dwords = c->dwords;
     uint32_t *F, *s_sl, *s_fb; uint8_t *s_fl, *s_pc; uint2 *posinfo; uint4 *winfo;
     if (dwords > WID_MASK) return PFP_E_TOO_LARGE;

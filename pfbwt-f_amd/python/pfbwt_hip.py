@@ -104,6 +104,7 @@ def load_library(path=None):
     L.pfp_parse_feed_fasta_file.argtypes = [vp, C.c_char_p, C.c_uint, C.POINTER(IngestInfo)]
     L.pfp_bwt_build_stream.argtypes = [vp, i32, i32, vp, vp, C.POINTER(BwtSizes)]
     L.pfp_text_length.argtypes = [vp, C.POINTER(u64)]
+    L.pfp_bwt_get_expanded.argtypes = [vp, vp, vp, i32]
     L.pfp_text_view.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
     L.pfp_host_register.argtypes = [vp, u64]
     L.pfp_host_unregister.argtypes = [vp]
@@ -202,6 +203,10 @@ class PfpContext:
         o = (C.c_uint64 * 5)()
         self._check(self.L.pfp_debug_check_sample_order(self.h, o))
         return {"pairs": int(o[0]), "order_violations": int(o[1]), "rows_not_adjacent": int(o[2]), "max_lcp": int(o[3]), "mean_lcp": (int(o[4]) / int(o[0])) if o[0] else 0.0}
+
+    def bwt_get_expanded(self, host_bwt_ptr, ssa=None, threads=16):
+        """.bwt into host memory from its run-length form (one byte per run over PCIe, host threads write the runs)"""
+        self._check(self.L.pfp_bwt_get_expanded(self.h, C.c_void_p(host_bwt_ptr), _ptr(ssa), int(threads)))
 
     def samples_get(self, out=None):
         """the run samples of the last build: (ssa, esa) as 2*r U-wide arrays (into out["ssa"] / out["esa"] if given)"""
