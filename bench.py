@@ -510,12 +510,19 @@ def main():
             if want_sa:
                 dev_sums["sa"] = dsum(dp["sa"], (n + 1) * U)
             # host -> host, rows: the text sits in pinned host memory as headerless rows, the outputs end in pinned host memory
-            ob = {"bwt": torch.empty(n + 1, dtype=torch.uint8, pin_memory=True).numpy()}
+            # page-locked output buffers of the exact size (torch's pinned allocator rounds to powers of two and keeps what it freed: on S-3G,
+            # r = 0.74 n, that alone was 160 GB of host memory next to the child process of the FASTA leg)
+            def pinned(nbytes):
+                arr = np.empty(nbytes, np.uint8); arr.fill(0)
+                if ctx.L.pfp_host_register(arr.ctypes.data, arr.size) != 0:
+                    raise RuntimeError("pfp_host_register failed")
+                return arr
+            ob_raw = {"bwt": pinned(n + 1)}
             if want_rssa:
-                ob["ssa"] = torch.empty(2 * r_total * U, dtype=torch.uint8, pin_memory=True).numpy().view(np.uint64 if u64 else np.uint32)
-                ob["esa"] = torch.empty(2 * r_total * U, dtype=torch.uint8, pin_memory=True).numpy().view(np.uint64 if u64 else np.uint32)
+                ob_raw["ssa"] = pinned(2 * r_total * U); ob_raw["esa"] = pinned(2 * r_total * U)
             if want_sa:
-                ob["sa"] = torch.empty((n + 1) * U, dtype=torch.uint8, pin_memory=True).numpy().view(np.uint64 if u64 else np.uint32)
+                ob_raw["sa"] = pinned((n + 1) * U)
+            ob = {k: (v if k == "bwt" else v.view(np.uint64 if u64 else np.uint32)) for k, v in ob_raw.items()}
             best = None
             for _ in range(2):
                 torch.cuda.synchronize(); e0 = time.perf_counter()
@@ -537,8 +544,11 @@ def main():
                          "pcie_cap_Gbases_per_s": n / ((in_b + out_b) / 57e9) / 1e9,
                          "pcie_cap_note": "57 GB/s per direction measured on this box (profiles/r03a_alloc_bench.log; both directions at once: 25 GB/s each, so upload and download "
                                           "are kept apart); the outputs depend on the whole text, so upload + parse + download are serial"})
-            best["outputs_match_device"] = {k: host_wordsum(ob[k].view(np.uint8) if k != "bwt" else ob[k]) == v for k, v in dev_sums.items()}
+            best["outputs_match_device"] = {k: host_wordsum(ob_raw[k]) == v for k, v in dev_sums.items()}
             res["end_to_end"] = best
+            for v in ob_raw.values():
+                ctx.L.pfp_host_unregister(v.ctypes.data)
+            del ob, ob_raw
         ctx.close(); del d_all
         torch.cuda.empty_cache()
         if dev_sums is not None:
