@@ -269,8 +269,8 @@ def e2e_child(a):
         bufs = {"bwt": np.empty(fsize + 64, np.uint8)}
         if want_sa:
             bufs["sa"] = np.empty((fsize + 64) * U, np.uint8)
-        if want_rssa:      # r is not known in advance: page-locked room for n / 128 runs (4 * U bytes each; S-32G has n / 383), pageable arrays if there are more
-            bufs["samples"] = np.empty((fsize // 128 + 64) * 4 * U, np.uint8)
+        if want_rssa:      # r is not known in advance: page-locked room for n / 128 runs of a collection (4 * U bytes each; S-32G has n / 383), pageable arrays if there are more
+            bufs["samples"] = np.empty(((fsize // 128 if H > 1 else fsize * 4 // 5) + 64) * 4 * U, np.uint8)      # (one non-repetitive sequence: r is of the order of n)
         step = 1 << 28
         with ThreadPoolExecutor(max_workers=16) as ex:
             for b in bufs.values():
@@ -570,7 +570,7 @@ def main():
                 del h_all
                 # this process has just released its HBM: the driver wipes freed VRAM in the background (~40 GB/s) and a large
                 # allocation waits for a pending wipe (profiles/r03a_alloc_fresh.log) -- "cold" means a fresh process on an idle card
-                time.sleep(2.0 + (n_local + 3.5 * n) / 40e9 if n > (1 << 30) else 2.0)
+                time.sleep(8.0 if n > (1 << 30) else 2.0)      # (up to ~250 GB were released)
                 t0 = time.perf_counter()
                 pc = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", a.workload, "--e2e-child", img], capture_output=True, text=True)
                 wall = time.perf_counter() - t0
