@@ -29,7 +29,6 @@ import ctypes as C
 import hashlib
 import json
 import os
-import socket
 import subprocess
 import sys
 import tempfile
@@ -272,7 +271,7 @@ def e2e_child(a):
         if want_rssa:      # r is not known in advance: page-locked room for n / 128 runs of a collection (4 * U bytes each; S-32G has n / 383), pageable arrays if there are more
             bufs["samples"] = np.empty(((fsize // 128 if H > 1 else fsize * 4 // 5) + 64) * 4 * U, np.uint8)      # (one non-repetitive sequence: r is of the order of n)
         step = 1 << 28
-        with ThreadPoolExecutor(max_workers=16) as ex:
+        with ThreadPoolExecutor(max_workers=6) as ex:      # few threads: the box gives a one-GPU job 16 cores, and the file reader's 8 threads must not be starved
             for b in bufs.values():
                 list(ex.map(lambda i, b=b: b[i:i + step].fill(0), range(0, b.size, step)))
         t1 = time.perf_counter()
@@ -337,16 +336,22 @@ def e2e_child(a):
 
 def spawn_ranks(n):
     """`python bench.py --gpus N` invoked plainly: start the N ranks as fresh child processes (this process has not
-    touched the GPU) and exit with their status; rank 0's JSON line goes to the inherited stdout"""
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    touched the GPU) and exit with their status; rank 0's JSON line goes to the inherited stdout.  The ranks meet through a
+    file store in a fresh temporary directory (no TCP port to race for with another bench on the same box)."""
+    d = tempfile.mkdtemp(prefix="pfbwt_bench_rdzv_")
     procs = []
     for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), PFP_BENCH_INIT_FILE=os.path.join(d, "store"), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
     for pr in procs:
         rc = max(rc, abs(pr.wait()))
+    try:
+        for f in os.listdir(d):
+            os.remove(os.path.join(d, f))
+        os.rmdir(d)
+    except OSError:
+        pass
     sys.exit(rc)
 
 
@@ -389,7 +394,10 @@ def main():
         import torch.distributed as dist
         if forced and "RANK" not in os.environ:      # the rehearsal started plainly: a group of one rank
             os.environ.update({"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": os.environ.get("MASTER_PORT", str(29000 + os.getpid() % 2000))})
-        dist.init_process_group("nccl", device_id=torch.device("cuda", lrank))
+        if os.environ.get("PFP_BENCH_INIT_FILE"):      # started by spawn_ranks
+            dist.init_process_group("nccl", init_method="file://" + os.environ["PFP_BENCH_INIT_FILE"], rank=rank, world_size=world, device_id=torch.device("cuda", lrank))
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", lrank))
     pfbwt_hip.load_library()  # raises if the gfx950 library is absent
 
     L, H, seed, nruns, w, p, u64 = WORKLOADS[a.workload]
