@@ -235,12 +235,13 @@ int pfp_sacak_int_u32(const uint32_t *s, uint32_t *SA, uint32_t n, uint32_t k);
 int pfp_sacak_int_u64(const uint32_t *s, uint64_t *SA, uint64_t n, uint64_t k);
 
 /* int gsacak(unsigned char *s, uint_t *SA, int_t *LCP, int_t *DA, uint_t n), gsa/gsacak.h:86-96 -- the call made by
- * PrefixFreeBWT::sort_dict_suffixes, include/pfbwt.hpp:211.  s: strings over the dictionary alphabet ('-', A, C, G, N, T and
- * Dollar = 2), each followed by the separator 1, s[n-1] == 0.  SA: suffixes compared up to their separator, byte-identical
- * ones in position order (gsacak.c:877-912); LCP (nullable): stops at the separator (:64), LCP[0] = 0; DA (nullable):
- * index of the string a suffix starts in.  Returns the number of refinement rounds (>= 1; the reference returns its
- * recursion depth) or -1 (NULL s / SA as the reference; also: n >= 2^32 - 64, a byte outside that alphabet, no unique
- * terminator).  The engine itself never materialises LCP (pfp_bwt_build uses class heads instead). */
+ * PrefixFreeBWT::sort_dict_suffixes, include/pfbwt.hpp:211.  s: strings over ANY byte alphabet (the parser's dictionaries use '-', A,
+ * C, G, N, T and Dollar = 2 and take the tuned path), each followed by the separator 1, s[n-1] == 0 and no other 0.  SA: suffixes
+ * compared up to their separator, byte-identical ones in position order (gsacak.c:877-912); LCP (nullable): stops at the
+ * separator (:64), LCP[0] = 0; DA (nullable): index of the string a suffix starts in.  Returns the number of refinement rounds
+ * (>= 1; the reference returns its recursion depth) or -1: NULL s / SA as the reference; also n >= 2^32 - 64 in either width (device
+ * suffix indices are 32-bit: dictionaries below 4 GiB) and a 0 byte that is not the last one.  The engine itself never
+ * materialises LCP (pfp_bwt_build uses class heads instead). */
 int pfp_gsacak_u32(const uint8_t *s, uint32_t *SA, int32_t *LCP, int32_t *DA, uint32_t n);
 int pfp_gsacak_u64(const uint8_t *s, uint64_t *SA, int64_t *LCP, int64_t *DA, uint64_t n);
 

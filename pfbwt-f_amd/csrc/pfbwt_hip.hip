@@ -2041,17 +2041,9 @@ static int sacak_int_impl(const uint32_t *s, void *SA, uint64_t n, uint64_t k, b
 }
 extern "C++" {
 // int gsacak(unsigned char *s, uint_t *SA, int_t *LCP, int_t *DA, uint_t n), gsa/gsacak.h:86-96 -- the call of
-// include/pfbwt.hpp:211.  s = strings over the dictionary alphabet {'-', A, C, G, N, T} and Dollar (2), each followed by
-// the separator 1, s[n-1] = 0.  Suffixes are compared up to their separator; suffixes that are byte-identical up to it
+// include/pfbwt.hpp:211.  s = strings over any byte alphabet (the parser's dictionaries: '-', A, C, G, N, T and Dollar = 2), each
+// followed by the separator 1, s[n-1] = 0.  Suffixes are compared up to their separator; suffixes that are byte-identical up to it
 // are ordered by position (gsacak.c:877-912) and LCP stops at the separator (:64).
-__global__ __launch_bounds__(BLOCK) void k_gsa_check_alphabet(const uint8_t *D, uint64_t n, uint32_t *bad)
-{
-    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n) return;
-    const uint8_t c = D[i];
-    const bool ok = c <= 2 || c == '-' || c == 'A' || c == 'C' || c == 'G' || c == 'N' || c == 'T';
-    if (!ok || (c == 0 && i + 1 != n) || (i + 1 == n && c != 0)) atomicAdd(bad, 1u);
-}
 // LCP[i] of SA[i-1], SA[i]: bytes are compared eight at a time; inside runs of one byte (a 10 Mbp run of N is one phrase whose
 // suffixes are neighbours in SA) the shorter of the two runs is skipped at once (M: run lengths, see k_ss_runend_marks)
 template <typename LT> __global__ __launch_bounds__(BLOCK) void k_gsa_lcp(const uint8_t *D, const uint32_t *SA, const uint32_t *M, uint64_t n, LT *lcp)
@@ -2086,6 +2078,19 @@ static int gsacak_impl(const uint8_t *s, void *SA, void *LCP, void *DA, uint64_t
 {
     if (!s || !SA || n < 2) return -1;
     if (n + 64 >= 0xFFFFFFFFULL) return -1;
+    // the alphabet: bytes 0 (terminator: only at the very end) and 1 (separator) keep their roles; every other byte that occurs gets
+    // the next code in byte order.  The parser's own dictionaries ('-' A C G N T and Dollar) take the tuned 16-characters-per-key
+    // kernel; any other byte set (another caller of gsa/gsacak.h:86-96) takes the generic one with as many characters as fit 51 bits
+    bool seen[256] = {false};
+    for (uint64_t i = 0; i < n; ++i) seen[s[i]] = true;
+    if (s[n - 1] != 0) return -1;
+    for (uint64_t i = 0; i + 1 < n; ++i) if (s[i] == 0) return -1;      // no unique terminator
+    bool dict_alphabet = true;
+    for (int b = 3; b < 256; ++b) if (seen[b] && !(b == '-' || b == 'A' || b == 'C' || b == 'G' || b == 'N' || b == 'T')) dict_alphabet = false;
+    uint8_t code[256]; uint32_t sigma = 2;
+    for (int b = 0; b < 256; ++b) code[b] = (uint8_t)(b <= 1 ? b : 0);
+    for (int b = 2; b < 256; ++b) if (seen[b]) code[b] = (uint8_t)sigma++;
+    uint32_t chars = 0; { unsigned __int128 v = 1; while (chars < 16 && v * sigma < ((unsigned __int128)1 << 51)) { v *= sigma; ++chars; } }
     int st = 0;
     pfp_ctx *c = pfp_create(10, 100, u64 ? PFP_FLAG_U64 : 0u, 0, (uint64_t)(72 * n + (64ULL << 20)), &st);
     if (!c) return -1;
@@ -2097,19 +2102,23 @@ static int gsacak_impl(const uint8_t *s, void *SA, void *LCP, void *DA, uint64_t
         PFP_ALLOC_LO(c, c->d_dict, uint8_t, n + 16);
         PFP_HIP(c, hipMemsetAsync(c->d_dict + n, 0, 16, c->stream));
         PFP_TRY(h2d_copy(c, c->d_dict, s, n));
-        uint32_t *d_bad; PFP_ALLOC_HI(c, d_bad, uint32_t, 1);
-        PFP_HIP(c, hipMemsetAsync(d_bad, 0, 4, c->stream));
-        PFP_LAUNCH(c, K_MISC, n, k_gsa_check_alphabet, nblocks(n, BLOCK), (const uint8_t *)c->d_dict, n, d_bad);
-        uint32_t bad = 0; PFP_TRY(d2h_u32(c, d_bad, &bad));
-        if (bad) return PFP_E_ARG;                                   // a byte outside the dictionary alphabet, or no unique terminator
         // sort_dict_suffixes with a counted round number
         uint64_t *k0, *k1; uint32_t *v0, *v1;
         PFP_ALLOC_LO(c, c->d_gsa, uint32_t, n); PFP_ALLOC_LO(c, c->d_grank, uint2, n);
         const size_t mk = c->arena.mark_hi();
         PFP_ALLOC_HI(c, k0, uint64_t, n); PFP_ALLOC_HI(c, k1, uint64_t, n); PFP_ALLOC_HI(c, v0, uint32_t, n); PFP_ALLOC_HI(c, v1, uint32_t, n);
-        PFP_LAUNCH(c, K_SS_INIT_KEYS, n * 13, k_dict_init_keys, nblocks(n, DK_TILE), (const uint8_t *)c->d_dict, n, k0, v0);
-        BitRange full = {0, DK_KEY_BITS};
-        PFP_TRY(suffix_sort_doubling<true>(c, n, k0, v0, k1, v1, &full, 1, DK_CHARS, c->d_dict, c->d_gsa, (uint32_t *)nullptr, c->d_grank, &rounds));
+        if (dict_alphabet) {
+            PFP_LAUNCH(c, K_SS_INIT_KEYS, n * 13, k_dict_init_keys, nblocks(n, DK_TILE), (const uint8_t *)c->d_dict, n, k0, v0);
+            BitRange full = {0, DK_KEY_BITS};
+            PFP_TRY(suffix_sort_doubling<true>(c, n, k0, v0, k1, v1, &full, 1, DK_CHARS, c->d_dict, c->d_gsa, (uint32_t *)nullptr, c->d_grank, &rounds));
+        } else {
+            uint8_t *d_code; PFP_ALLOC_HI(c, d_code, uint8_t, 256);
+            PFP_HIP(c, hipMemcpyAsync(d_code, code, 256, hipMemcpyHostToDevice, c->stream));
+            PFP_HIP(c, hipStreamSynchronize(c->stream));
+            PFP_LAUNCH(c, K_SS_INIT_KEYS, n * 13, k_dict_init_keys_any, nblocks(n, BLOCK), (const uint8_t *)c->d_dict, n, (const uint8_t *)d_code, sigma, chars, k0, v0);
+            BitRange full = {0, 51};
+            PFP_TRY(suffix_sort_doubling<true>(c, n, k0, v0, k1, v1, &full, 1, chars, c->d_dict, c->d_gsa, (uint32_t *)nullptr, c->d_grank, &rounds, sigma));
+        }
         c->arena.release_hi(mk);
         PFP_HIP(c, hipStreamSynchronize(c->stream));
         if (!u64) PFP_HIP(c, hipMemcpy(SA, c->d_gsa, n * 4, hipMemcpyDeviceToHost));

@@ -54,6 +54,23 @@ __global__ __launch_bounds__(BLOCK) void k_dict_init_keys(const uint8_t *D, uint
     }
 }
 
+// The same for ANY byte alphabet (the gsacak drop-in called with strings that are not dictionaries of this parser): code[] maps the
+// bytes that occur to 0 (terminator), 1 (separator), 2, 3, ... in byte order, sigma = number of codes, the key holds the first
+// `chars` characters as a base-sigma number (sigma^chars < 2^51, chars <= 16).  One thread per suffix: this path is not timed.
+__global__ __launch_bounds__(BLOCK) void k_dict_init_keys_any(const uint8_t *D, uint64_t dsize, const uint8_t *code, uint32_t sigma, uint32_t chars, uint64_t *keys, uint32_t *vals)
+{
+    const uint64_t x = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (x >= dsize) return;
+    uint64_t key = 0; bool stop = false; uint32_t off = chars;
+    for (uint32_t j = 0; j < chars; ++j) {
+        const uint32_t cc = x + j < dsize ? code[D[x + j]] : 0u;
+        key = key * sigma + (stop ? 0u : cc);
+        if (!stop && cc <= 1) off = j + 1u;
+        stop = stop || cc <= 1;
+    }
+    keys[x] = key | ((uint64_t)off << 56); vals[x] = (uint32_t)x;
+}
+
 // parse keys: (S[x], S[x+1]) with S = ranks + [0]  (pfparser.hpp:407-410)
 __global__ __launch_bounds__(BLOCK) void k_int_init_keys(const uint32_t *S, uint64_t N, int symbits, uint64_t *keys, uint32_t *vals)
 {
@@ -104,7 +121,6 @@ __global__ __launch_bounds__(BLOCK) void k_ss_runend_marks(const uint8_t *D, uin
 // two behind; (dictionary) the jump behind the third}: ONE 16-byte gather per pair then orders the class by three further
 // prefixes, the covered prefix grows 4x per round and the rounds (gathers, scatters, compactions) halve.  When few pairs
 // are left the table is not worth a pass over all N positions: the kernel then follows the chain itself.
-constexpr uint32_t RUN_MIN = DK_CHARS;
 constexpr uint8_t RF_KEEP = 1, RF_CHANGED = 2, RF_DONE = 4;
 #ifndef PFP_K3_ITEMS
 #define PFP_K3_ITEMS 9
@@ -161,7 +177,7 @@ template <bool DICT> __global__ __launch_bounds__(BLOCK) void k_round_table(cons
 // third rank.
 template <bool DICT, int K> __global__ __launch_bounds__(BLOCK) void k_round(const uint32_t *aslot, const uint32_t *arnk, const uint32_t *ajmp, uint64_t na, uint64_t N,
                                                                              uint32_t *SA, const uint32_t *rank, const uint2 *rj, const uint4 *T /*K = 3; null: follow the chain*/, uint32_t h, const uint8_t *D,
-                                                                             const uint32_t *M /*run round (K = 1)*/, int lowbits, uint32_t max_range, uint32_t *newr,
+                                                                             const uint32_t *M /*run round (K = 1)*/, uint32_t run_min /*characters per initial key*/, int lowbits, uint32_t max_range, uint32_t *newr,
                                                                              uint32_t *xout /*the sorted suffixes, in list order*/, uint32_t *tnj, uint32_t *newj, uint8_t *flags, uint32_t *stripe_keep, unsigned long long *ndone)
 {
     constexpr int ITEMS = RoundCfg<K>::ITEMS, TILE = RoundCfg<K>::TILE;
@@ -232,7 +248,7 @@ template <bool DICT, int K> __global__ __launch_bounds__(BLOCK) void k_round(con
                     bool run = false;
                     const uint32_t ip = (uint32_t)(N - 1 - x);
                     const uint32_t d = ip - M[ip] + 1u;
-                    if (d >= RUN_MIN && D[x] > EndOfWord) {
+                    if (d >= run_min && D[x] > EndOfWord) {
                         const uint64_t en = (uint64_t)x + d;
                         const uint8_t nxt = en < N ? D[en] : (uint8_t)0;
                         low = nxt < D[x] ? d : 0xFFFFFFFFu - d; nx = (uint32_t)(en < N ? en : N); run = true;
@@ -387,7 +403,7 @@ template <bool DICT, int K> __global__ __launch_bounds__(BLOCK) void k_round(con
 // payload is the pair's index i in this subset; ux / tnj keep its suffix and new jump.  K = 3: the two ranks of kb are
 // sorted first, then (stable) ka.
 template <bool DICT, int K> __global__ __launch_bounds__(BLOCK) void k_round_keys(const uint32_t *idx, uint64_t nl, const uint32_t *aslot, const uint32_t *arnk, const uint32_t *ajmp, uint64_t N,
-                                                                                  const uint32_t *SA, const uint32_t *rank, const uint2 *rj, const uint4 *T, uint32_t h, const uint8_t *D, const uint32_t *M, int lowbits,
+                                                                                  const uint32_t *SA, const uint32_t *rank, const uint2 *rj, const uint4 *T, uint32_t h, const uint8_t *D, const uint32_t *M, uint32_t run_min, int lowbits,
                                                                                   uint64_t *ka, uint64_t *kb, uint32_t *ux, uint32_t *tnj)
 {
     const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -405,7 +421,7 @@ template <bool DICT, int K> __global__ __launch_bounds__(BLOCK) void k_round_key
         if (M) {
             const uint32_t ip = (uint32_t)(N - 1 - x);
             const uint32_t d = ip - M[ip] + 1u;
-            if (d >= RUN_MIN && D[x] > EndOfWord) {
+            if (d >= run_min && D[x] > EndOfWord) {
                 const uint64_t en = (uint64_t)x + d;
                 const uint8_t nxt = en < N ? D[en] : (uint8_t)0;
                 low = nxt < D[x] ? d : 0xFFFFFFFFu - d; nx = (uint32_t)(en < N ? en : N); run = true;
@@ -495,7 +511,7 @@ template <bool DICT, int K> __global__ __launch_bounds__(BLOCK) void k_round_app
 // rj[].x and keep[a] = the class of a has to be refined.  Dictionary: the initial jump sits in bits 56..60 of the key
 // (k_dict_init_keys) and the covered prefix holds the terminator exactly when the jump offset is below DK_CHARS or the
 // 16th character is the terminator -- no gathers.
-template <bool DICT> __global__ __launch_bounds__(BLOCK) void k_init_state(const uint64_t *keys, const uint32_t *vals, const uint32_t *head, const uint32_t *rk, uint64_t N, uint32_t *rank, uint2 *rj, uint32_t *keep)
+template <bool DICT> __global__ __launch_bounds__(BLOCK) void k_init_state(const uint64_t *keys, const uint32_t *vals, const uint32_t *head, const uint32_t *rk, uint64_t N, uint32_t sigma, uint32_t *rank, uint2 *rj, uint32_t *keep)
 {
     const uint64_t a = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (a >= N) return;
@@ -503,7 +519,7 @@ template <bool DICT> __global__ __launch_bounds__(BLOCK) void k_init_state(const
     if (DICT) rj[x] = make_uint2(rk[a], x + (uint32_t)(keys[a] >> 56)); else rank[x] = rk[a];
     const bool single = head[a] && (a + 1 == N || head[a + 1]);
     bool fin = single;
-    if (DICT && !fin) fin = (keys[a] & ((1ULL << DK_KEY_BITS) - 1)) % 9u <= 1u;   // last base-9 digit: padding behind a terminator, or the terminator itself
+    if (DICT && !fin) fin = (keys[a] & ((1ULL << 56) - 1)) % sigma <= 1u;   // last base-sigma digit: padding behind a terminator, or the terminator itself
     keep[a] = fin ? 0u : 1u;
 }
 template <bool DICT> __global__ __launch_bounds__(BLOCK) void k_init_active(const uint64_t *keys, const uint32_t *vals, const uint32_t *rk, const uint32_t *keep, const uint32_t *pos, uint64_t N,
@@ -520,6 +536,7 @@ struct RoundBufs {
     uint32_t *aslot[2], *arnk[2], *ajmp[2], *newr, *xout, *tnj, *newj, *M, *stripe, *lidx, *head, *keep, *pos, *d_cnt;
     uint8_t *flags; unsigned long long *d_done; uint4 *T;
     uint64_t *k0, *k1; uint32_t *v0, *v1;
+    uint32_t run_min;      // dictionary: characters per initial key (a suffix inside a run of at least that many equal bytes is ordered by the run round)
 };
 
 // one refinement round over the active list `cur` (na pairs) -> list cur ^ 1; *na_out = its length
@@ -542,7 +559,7 @@ template <bool DICT, int K> inline int suffix_sort_round(pfp_ctx *c, RoundBufs &
     // algorithmic bytes per active suffix: list entry 8 (+4 jump), SA[slot] 4 in + 4 out, the gathered
     // rank 4 (K = 3: 12; dictionary: + jump 4, + 1 terminator byte), new rank 4 (+ new jump 4 + 4 through scratch), flag 1
     PFP_LAUNCH(c, K_CLASS_SORT, (uint64_t)na * ((DICT ? 46 : 25) + (K == 3 ? 8 : 0)), (k_round<DICT, K>), gs, (const uint32_t *)b.aslot[cur], (const uint32_t *)b.arnk[cur], (const uint32_t *)b.ajmp[cur], (uint64_t)na, N, SA,
-               (const uint32_t *)rank, (const uint2 *)rj, T, hh, D, Mr, lowbits, max_range, b.newr, b.xout, b.tnj, b.newj, b.flags, b.stripe, b.d_done);
+               (const uint32_t *)rank, (const uint2 *)rj, T, hh, D, Mr, b.run_min, lowbits, max_range, b.newr, b.xout, b.tnj, b.newj, b.flags, b.stripe, b.d_done);
     unsigned long long nd = 0;
     PFP_HIP(c, hipMemcpyAsync(&nd, b.d_done, 8, hipMemcpyDeviceToHost, c->stream));
     PFP_HIP(c, hipStreamSynchronize(c->stream));
@@ -557,7 +574,7 @@ template <bool DICT, int K> inline int suffix_sort_round(pfp_ctx *c, RoundBufs &
         PFP_LAUNCH(c, K_COMPACT, (uint64_t)na * 5, k_not_done, ga, (const uint8_t *)b.flags, (uint64_t)na, b.keep);
         PFP_TRY(device_compact(c, nullptr, b.keep, na, b.lidx, b.pos, b.d_cnt));
         PFP_LAUNCH(c, K_SS_MAKE_KEYS, nl * 48, (k_round_keys<DICT, K>), gl, (const uint32_t *)b.lidx, nl, (const uint32_t *)b.aslot[cur], (const uint32_t *)b.arnk[cur], (const uint32_t *)b.ajmp[cur], N, (const uint32_t *)SA,
-                   (const uint32_t *)rank, (const uint2 *)rj, T, hh, D, Mr, lowbits, ka, kb, ux, b.tnj);
+                   (const uint32_t *)rank, (const uint2 *)rj, T, hh, D, Mr, b.run_min, lowbits, ka, kb, ux, b.tnj);
         uint64_t *lsk = b.k0; uint32_t *lsv = b.v0; uint64_t *alk = b.k1; uint32_t *alv = b.v1;
         if (K == 3) {
             PFP_LAUNCH(c, K_SS_MAKE_KEYS, nl * 20, k_copy_keys_iota, gl, (const uint64_t *)kb, nl, b.k0, b.v0);
@@ -594,10 +611,12 @@ template <bool DICT, int K> inline int suffix_sort_round(pfp_ctx *c, RoundBufs &
 // (dictionary, DICT = true: suffixes end at their EndOfWord, byte-identical suffixes stay one class; D enables the run
 // round).  k0/v0 and their twins k1/v1 (N entries each) are scratch owned by the caller.
 template <bool DICT> inline int suffix_sort_doubling(pfp_ctx *c, uint64_t N, uint64_t *k0, uint32_t *v0, uint64_t *k1, uint32_t *v1,
-                                                    const BitRange *init_ranges, int n_init_ranges, uint32_t h0, const uint8_t *D, uint32_t *SA, uint32_t *rank, uint2 *rj, int *rounds_out)
+                                                    const BitRange *init_ranges, int n_init_ranges, uint32_t h0, const uint8_t *D, uint32_t *SA, uint32_t *rank, uint2 *rj, int *rounds_out,
+                                                    uint32_t sigma = 9 /*dictionary: codes of the initial keys' number system*/)
 {
     const size_t mk = c->arena.mark_hi();
     RoundBufs b{};
+    b.run_min = h0;
     uint32_t *aux;
     PFP_ALLOC_HI(c, b.head, uint32_t, N); PFP_ALLOC_HI(c, aux, uint32_t, N); PFP_ALLOC_HI(c, b.keep, uint32_t, N); PFP_ALLOC_HI(c, b.pos, uint32_t, N);
     PFP_ALLOC_HI(c, b.d_cnt, uint32_t, 4);
@@ -607,7 +626,7 @@ template <bool DICT> inline int suffix_sort_doubling(pfp_ctx *c, uint64_t N, uin
     uint64_t keymask = 0; for (int r = 0; r < n_init_ranges; ++r) for (int bb = init_ranges[r].lo; bb < init_ranges[r].hi; ++bb) keymask |= 1ULL << bb;
     PFP_LAUNCH(c, K_SS_HEADS, N * 24, k_ss_heads, gN, (const uint64_t *)sk, (const uint32_t *)sv, N, keymask, SA, b.head, aux);
     PFP_TRY((device_scan<uint32_t, 1>(c, aux, aux, N, nullptr)));
-    PFP_LAUNCH(c, K_SS_WRITE_RANK, N * 24, (k_init_state<DICT>), gN, (const uint64_t *)sk, (const uint32_t *)sv, (const uint32_t *)b.head, (const uint32_t *)aux, N, rank, rj, b.keep);
+    PFP_LAUNCH(c, K_SS_WRITE_RANK, N * 24, (k_init_state<DICT>), gN, (const uint64_t *)sk, (const uint32_t *)sv, (const uint32_t *)b.head, (const uint32_t *)aux, N, sigma, rank, rj, b.keep);
     PFP_TRY((device_scan<uint32_t, 0>(c, b.keep, b.pos, N, b.d_cnt)));
     uint32_t na = 0; PFP_TRY(d2h_u32(c, b.d_cnt, &na));
     int rounds = 1;

@@ -303,9 +303,35 @@ def _gsacak_check(lib, names, nruns_case=True):
                 assert np.array_equal(sa, SA) and np.array_equal(lcp, LCP) and np.array_equal(da, DA)
         sa2, l2, d2, _ = pfbwt_hip.gsacak(d, lib=lib)                      # SA only
         assert l2 is None and d2 is None and np.array_equal(sa2.astype(np.uint64), a)
-    bad = dicts[0].copy(); bad[5] = ord("R")
+    # any byte alphabet (another caller of gsa/gsacak.h:86-96): protein-like strings, all 254 other byte values, runs of one byte
+    rng = np.random.default_rng(9)
+    others = []
+    for alpha, nstr, mx in ((list(b"ACDEFGHIKLMNPQRSTVWY"), 40, 300), (list(range(2, 256)), 25, 500), (list(b"ab"), 30, 200)):
+        parts = []
+        for _ in range(nstr):
+            t = rng.choice(alpha, int(rng.integers(1, mx))).astype(np.uint8)
+            if rng.random() < 0.3:
+                t[: t.size // 2] = t[0]                                    # a long run of one byte
+            parts += [t, np.array([1], np.uint8)]
+        parts += parts[:4]                                                 # repeated strings: byte-identical suffixes in position order
+        others.append(np.concatenate(parts + [np.array([0], np.uint8)]))
+    for d in others:
+        n = d.size
+        sa, lcp, da, r = pfbwt_hip.gsacak(d, lcp=True, da=True, u64=True, lib=lib)
+        assert r >= 1
+        if G is not None:
+            SA = np.zeros(n, np.uint64); LCP = np.zeros(n, np.int64); DA = np.zeros(n, np.int64)
+            G.gsacak(d.ctypes.data_as(C.c_void_p), SA.ctypes.data_as(C.c_void_p), LCP.ctypes.data_as(C.c_void_p), DA.ctypes.data_as(C.c_void_p), n)
+            assert np.array_equal(sa, SA) and np.array_equal(lcp, LCP) and np.array_equal(da, DA)
+        else:      # (GPU box: no reference build) suffixes in order up to their separators, ties by position
+            key = lambda x: (bytes(d[x:]).split(b"\x01")[0] + b"\x01" if 1 in d[x:] else bytes(d[x:]), x)
+            idx = sa.astype(np.int64)
+            step = max(1, n // 400)
+            assert all(key(int(idx[i])) < key(int(idx[i + 1])) for i in range(0, n - 1, step))
+            assert sorted(idx.tolist()) == list(range(n))
+    bad = dicts[0].copy(); bad[5] = 0
     with pytest.raises(pfbwt_hip.PfpError):
-        pfbwt_hip.gsacak(bad, lib=lib)                                    # a byte outside the dictionary alphabet: -1
+        pfbwt_hip.gsacak(bad, lib=lib)                                    # a second terminator: -1
 
 
 def test_emu_gsacak_dropin(emu_factory):
