@@ -9,6 +9,9 @@
 #include "emit.h"
 #include "markers.h"
 #include <map>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 
 using namespace pfp;
 
@@ -528,6 +531,24 @@ template <typename SAT> __global__ __launch_bounds__(BLOCK) void k_run_heads(con
     if (k < r) heads[k] = bwt[(uint64_t)ssa[2 * k]];
 }
 }
+// one run of the .bwt into host memory.  A run is a few hundred bytes on a pangenome: memset would write them with ordinary stores, and
+// every cache line of the 32 GB output would first be READ from memory to be owned; the 16-byte aligned body of a run goes out with
+// streaming stores instead (the buffer is written once and not read again by the writer)
+static inline void fill_run(uint8_t *p, uint8_t v, size_t len)
+{
+#if defined(__SSE2__)
+    if (len >= 64) {
+        const size_t head = (size_t)(-(uintptr_t)p & 15u);
+        memset(p, v, head); p += head; len -= head;
+        const __m128i x = _mm_set1_epi8((char)v);
+        size_t i = 0;
+        for (; i + 16 <= len; i += 16) _mm_stream_si128(reinterpret_cast<__m128i *>(p + i), x);
+        memset(p + i, v, len - i);
+        return;
+    }
+#endif
+    memset(p, v, len);
+}
 int pfp_bwt_get_expanded(pfp_ctx *c, uint8_t *host_bwt, const void *ssa_host, int threads)
 {
     if (!c || !host_bwt) return PFP_E_ARG;
@@ -553,7 +574,10 @@ int pfp_bwt_get_expanded(pfp_ctx *c, uint8_t *host_bwt, const void *ssa_host, in
         th.emplace_back([&, t] {
             const uint64_t k0 = r * (uint64_t)t / (uint64_t)threads, k1 = r * (uint64_t)(t + 1) / (uint64_t)threads;
             uint64_t a = row(k0);
-            for (uint64_t k = k0; k < k1; ++k) { const uint64_t b = row(k + 1); memset(host_bwt + a, heads[(size_t)k], (size_t)(b - a)); a = b; }
+            for (uint64_t k = k0; k < k1; ++k) { const uint64_t b = row(k + 1); fill_run(host_bwt + a, heads[(size_t)k], (size_t)(b - a)); a = b; }
+#if defined(__SSE2__)
+            _mm_sfence();      // the streaming stores of this thread are globally visible before it ends
+#endif
         });
     for (auto &t : th) t.join();
     return PFP_OK;
