@@ -169,6 +169,7 @@ void pfp_destroy(pfp_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)hipDeviceSynchronize();      // other contexts may still read this one's text / shard view on their streams: unmapping does not wait for them
     prof_collect(c);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     c->text.destroy();
@@ -276,7 +277,9 @@ static int feed_common(pfp_ctx *c, const void *src, uint64_t len, int end_of_seq
     }
     // the caller may reuse its buffer on return: a pageable source went through the staging ring (its DMA transfers overlap
     // the caller's next read / decompression, include/kseq.h:228), only a page-locked source is read in place
-    if (in_flight) PFP_HIP(c, hipStreamSynchronize(c->stream));
+    // (a device source may belong to another context that its owner destroys right after this call -- PfParser::operator+= with a
+    // temporary right-hand side, src/merge_pfp.cpp:100-112: unmapping on-demand committed memory does not wait for copies in flight)
+    if (in_flight || (len && kind == hipMemcpyDeviceToDevice)) PFP_HIP(c, hipStreamSynchronize(c->stream));
     c->tb_n = c->n;
     return PFP_OK;
 }
