@@ -97,6 +97,7 @@ struct Tunables {
     long big_group_members = -2;       // -2: BIG_GROUP_MEMBERS (emit.h); < 0 otherwise: never take the sort route
     int force_wide_rows = 0;           // 64-bit row counters on small texts
     uint64_t ingest_block_bytes = 0;   // block size of the file reader (0: 64 MiB)
+    uint32_t emit_group_rows = 4096;   // rows per batch of the group-stationary emission of the special rows (0: every special row through k_emit; smaller: more groups left to k_emit)
     uint64_t fasta_chunk_bytes = 0;    // size of the raw-FASTA device buffers (0: 1 MiB ... 256 MiB by the size of the first call)
 };
 

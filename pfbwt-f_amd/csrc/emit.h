@@ -122,6 +122,10 @@ struct EmitArgs {
     const void *ENB; const uint32_t *etile_slot, *elist, *cpos; uint32_t ecount; int special; uint64_t q0;
     const uint32_t *qspec;  // samples-only mode: parse rows of the special rows of this window
     const uint32_t *gqf, *gql;   // per head slot of a uniform multi-member group: parse row of its first / last output row
+    // group-stationary route of the special rows (k_emit_groups): what it leaves to k_emit -- gleft[j] != 0: the group whose head is
+    // the j-th special slot; tile_left[t] != 0: enumeration tile t of this launch holds rows of such a group.  nullptr: k_emit walks everything
+    uint8_t *gleft, *tile_left; uint32_t group_rows_cap;
+    unsigned long long *gstat;   // PFP_VERBOSE: rows left to k_emit by reason [0] whole-word member, [1] sort route, [2] too many rows, [3] too many slots; [4..11] rows of left groups by log4 of the group's rows
 };
 constexpr uint8_t SF_MULTI = 1, SF_FULL = 2, SF_BIG = 4, SF_GFULL = 8, SF_NONUNI = 16;   // GFULL: some member of the group is a whole word; NONUNI: members with different preceding bytes
 __device__ __forceinline__ bool slot_is_special(uint32_t fl) { return (fl & (SF_FULL | SF_GFULL | SF_NONUNI)) != 0; }
@@ -458,6 +462,7 @@ template <typename SAT, typename EBT> __global__ __launch_bounds__(BLOCK) void k
     const EBT *ENB = reinterpret_cast<const EBT *>(a.ENB);      // enumeration order: == EB unless only the special slots are walked
     // tiles are aligned to multiples of EMIT_TILE in the global row numbering, so that the slots under a tile come from
     // the precomputed tile_slot table (k_tile_slots) instead of two 27-step bisections of EB per workgroup
+    if (a.tile_left && !a.tile_left[blockIdx.x]) return;     // k_emit_groups has written every row of this tile
     const uint64_t tb = a.e0 / EMIT_TILE + blockIdx.x;
     const uint64_t o0 = tb * EMIT_TILE > a.e0 ? tb * EMIT_TILE : a.e0;
     const uint64_t o1 = ((tb + 1) * EMIT_TILE < a.e1) ? (tb + 1) * EMIT_TILE : a.e1;   // exclusive
@@ -507,12 +512,22 @@ template <typename SAT, typename EBT> __global__ __launch_bounds__(BLOCK) void k
             if (in_lds) { const uint32_t j = rs[(uint32_t)(oo - o0)]; i[u] = i0 + j; r[u] = (uint32_t)(oo - ebase) - eb[j]; }
             else { i[u] = upper_bound_t<EBT>(ENB, a.ecount, (EBT)oo) - 1u; r[u] = (uint32_t)(oo - (uint64_t)ENB[i[u]]); }
         }
+        uint32_t jc[EMIT_ROWS_IN_FLIGHT];
+#pragma unroll
+        for (int u = 0; u < EMIT_ROWS_IN_FLIGHT; ++u) jc[u] = i[u];
         if (a.elist) {
 #pragma unroll
             for (int u = 0; u < EMIT_ROWS_IN_FLIGHT; ++u) i[u] = a.elist[i[u]];       // index in the list of special slots -> slot
         }
 #pragma unroll
         for (int u = 0; u < EMIT_ROWS_IN_FLIGHT; ++u) { S[u] = a.sinfo[i[u]]; fl[u] = (uint8_t)(S[u].w >> 24); }
+        if (a.gleft) {      // only the rows of the groups k_emit_groups left alone
+#pragma unroll
+            for (int u = 0; u < EMIT_ROWS_IN_FLIGHT; ++u) {
+                const uint32_t jh = (fl[u] & SF_MULTI) ? jc[u] - (i[u] - S[u].z) : jc[u];
+                if (on[u] && !a.gleft[jh]) on[u] = false;
+            }
+        }
 #pragma unroll
         for (int u = 0; u < EMIT_ROWS_IN_FLIGHT; ++u) q[u] = a.ilist[S[u].x + r[u]];                   // parse-BWT row of this occurrence
 #pragma unroll
@@ -577,6 +592,144 @@ template <typename SAT, typename EBT> __global__ __launch_bounds__(BLOCK) void k
             }
             if (qrow && !a.special) qrow[pos - a.w0] = q[u];
         }
+    }
+}
+
+// Group-stationary emission of the special rows (run-aware mode; pfbwt.hpp:116-181 for the rows k_fill cannot write as runs).
+// k_emit ranks every row of a multi-member group in the other members' occurrence lists by bisections in memory -- ~10 dependent
+// loads per row, 52 ms for the 1.3 G special rows of S-32G (0.03 of the HBM roofline, latency-bound).  Here the tile follows the
+// GROUPS, not the rows: a workgroup owns the groups whose first enumeration row lies in its stripe of EMIT_TILE rows, takes them in
+// batches of whole groups (at most EG_BUF rows, EG_SLOTS slots), reads the members' occurrence lists ONCE, coalesced, into LDS,
+// ranks there, and writes bytes and parse rows in output order through LDS.  A whole-word slot is a group of one list (its bytes
+// are bwlast[q]: the one random gather left).  Groups that do not fit a batch, groups with a whole-word member (reference quirk,
+// multi_group_pos) and sort-route groups are left to k_emit: their heads are marked in gleft[], the enumeration tiles their rows
+// touch in tile_left[].
+constexpr int EG_BUF = 4096, EG_SLOTS = 2 * BLOCK, EG_PER_THREAD = EG_BUF / BLOCK;
+__device__ __forceinline__ uint32_t group_members(const EmitArgs &a, const uint4 &S) { const uint32_t k = S.w & 0xFFFFFFu; return k == 0xFFFFFFu ? a.gk[S.z] : k; }
+template <typename EBT> __global__ __launch_bounds__(BLOCK) void k_emit_groups(EmitArgs a, uint8_t *bwt, uint32_t *qrow)
+{
+    __shared__ uint32_t LQ[EG_BUF];             // parse rows of the batch, in enumeration order (= list by list)
+    __shared__ uint32_t OQ[EG_BUF];             // the same in output order
+    __shared__ uint8_t OB[EG_BUF];              // BWT bytes in output order
+    __shared__ uint32_t s_eb[EG_SLOTS + 1], s_fb[EG_SLOTS], s_kf[EG_SLOTS], s_dl[EG_SLOTS];
+    __shared__ uint64_t s_ob[EG_SLOTS];         // output row of the first row of the slot's group, minus that row's place in the batch
+    __shared__ uint8_t s_pc[EG_SLOTS];
+    __shared__ uint32_t red[4];
+    __shared__ uint64_t jb[2];
+    const EBT *EB = reinterpret_cast<const EBT *>(a.EB);
+    const EBT *ENB = reinterpret_cast<const EBT *>(a.ENB);
+    const uint64_t tile0 = a.e0 / EMIT_TILE, tb = tile0 + blockIdx.x;
+    const uint64_t o0 = tb * EMIT_TILE > a.e0 ? tb * EMIT_TILE : a.e0;
+    const uint64_t o1 = ((tb + 1) * EMIT_TILE < a.e1) ? (tb + 1) * EMIT_TILE : a.e1;
+    if (threadIdx.x < 2) {      // head of the first group that starts at or behind row v (v = o0: first owned group, v = o1: end of the owned groups)
+        const uint64_t v = threadIdx.x ? o1 : o0;
+        uint64_t lo = a.etile_slot[tb], hi = (uint64_t)a.etile_slot[tb + 1] + 1u;
+        if (hi > a.ecount) hi = a.ecount;
+        if (lo > hi) lo = hi;
+        while (lo < hi) { const uint64_t mid = lo + ((hi - lo) >> 1); if ((uint64_t)ENB[mid] < v) lo = mid + 1; else hi = mid; }
+        uint64_t j = lo;
+        if (j < a.ecount) {
+            const uint32_t i = a.elist[j]; const uint4 S = a.sinfo[i];
+            if ((S.w >> 24) & SF_MULTI) { const uint64_t head = j - (i - S.z); j = (uint64_t)ENB[head] < v ? head + group_members(a, S) : head; }
+        }
+        jb[threadIdx.x] = j;
+    }
+    __syncthreads();
+    uint64_t j = jb[0]; const uint64_t jE = jb[1];
+    const uint32_t cap = a.group_rows_cap < (uint32_t)EG_BUF ? a.group_rows_cap : (uint32_t)EG_BUF;
+    while (j < jE) {                                            // uniform: one batch of whole groups per turn
+        const uint32_t nload = jE - j < (uint64_t)EG_SLOTS ? (uint32_t)(jE - j) : (uint32_t)EG_SLOTS;
+        const uint64_t B0 = (uint64_t)ENB[j];
+        uint32_t cand[2] = {0u, 0u}, bad = 0xFFFFFFFFu;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const uint32_t s = threadIdx.x + (uint32_t)t * BLOCK;
+            if (s < nload) {
+                const uint32_t i = a.elist[j + s]; const uint4 S = a.sinfo[i];
+                const uint32_t fl = S.w >> 24; const bool multi = (fl & SF_MULTI) != 0;
+                const uint32_t dl = multi ? i - S.z : 0u, k = multi ? group_members(a, S) : 1u;
+                const uint64_t e0 = (uint64_t)ENB[j + s] - B0, e1 = (uint64_t)ENB[j + s + 1] - B0;
+                s_eb[s] = e0 < 0xFFFFFFFFull ? (uint32_t)e0 : 0xFFFFFFFFu;
+                if (s + 1 == nload) s_eb[nload] = e1 < 0xFFFFFFFFull ? (uint32_t)e1 : 0xFFFFFFFFu;
+                s_fb[s] = S.x; s_kf[s] = (k < 0xFFFFFFu ? k : 0xFFFFFFu) | (fl << 24); s_dl[s] = dl; s_pc[s] = a.s_pc[i];
+                s_ob[s] = (uint64_t)EB[multi ? S.z : i];
+                if ((fl & (SF_GFULL | SF_BIG)) && s < bad) bad = s;
+                if (dl + 1u == k && e1 <= (uint64_t)cap) cand[t] = s + 1u;       // a batch may end behind this slot
+            }
+        }
+        uint32_t tot;
+        (void)block_incl_max(~bad, red, &tot);
+        const uint32_t firstbad = ~tot;                        // first slot of a group k_emit keeps (all members of such a group carry the flag)
+        uint32_t c = 0;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) if (cand[t] && cand[t] <= firstbad && cand[t] > c) c = cand[t];
+        uint32_t cut;
+        (void)block_incl_max(c, red, &cut);
+        if (cut == 0) {      // the group at j is left to k_emit
+            const uint32_t k0 = (s_kf[0] >> 24) & SF_MULTI ? ((s_kf[0] & 0xFFFFFFu) == 0xFFFFFFu ? a.gk[a.elist[j]] : (s_kf[0] & 0xFFFFFFu)) : 1u;
+            const uint64_t r0 = B0, r1 = (uint64_t)ENB[j + k0];
+            if (threadIdx.x == 0) a.gleft[j] = 1;
+            if (a.gstat && threadIdx.x == 0) {
+                const uint32_t f0 = s_kf[0] >> 24;
+                atomicAdd(&a.gstat[(f0 & SF_GFULL) ? 0 : (f0 & SF_BIG) ? 1 : (r1 - r0 > (uint64_t)cap) ? 2 : 3], (unsigned long long)(r1 - r0));
+                int b = 0; while (b < 7 && (1024ull << (2 * b)) <= r1 - r0) ++b;
+                atomicAdd(&a.gstat[4 + b], (unsigned long long)(r1 - r0));
+            }
+            if (r1 > r0) for (uint64_t t = r0 / EMIT_TILE + threadIdx.x; t <= (r1 - 1) / EMIT_TILE; t += BLOCK) a.tile_left[t - tile0] = 1;
+            j += k0;
+            __syncthreads();
+            continue;
+        }
+        __syncthreads();
+        const uint32_t nrows = s_eb[cut];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) { const uint32_t s = threadIdx.x + (uint32_t)t * BLOCK; if (s < cut) s_ob[s] -= (uint64_t)s_eb[s - s_dl[s]]; }
+        // the lists, coalesced (consecutive rows of a slot are consecutive list entries), then the bytes of the whole-word rows
+        uint32_t qv[EG_PER_THREAD], sv[EG_PER_THREAD]; uint8_t cv[EG_PER_THREAD];
+#pragma unroll
+        for (int it = 0; it < EG_PER_THREAD; ++it) {
+            const uint32_t r = threadIdx.x + (uint32_t)it * BLOCK;
+            sv[it] = 0; qv[it] = 0;
+            if (r < nrows) { const uint32_t s = upper_bound_t<uint32_t>(s_eb, cut, r) - 1u; sv[it] = s; qv[it] = a.ilist[s_fb[s] + (r - s_eb[s])]; }
+        }
+#pragma unroll
+        for (int it = 0; it < EG_PER_THREAD; ++it) {
+            const uint32_t r = threadIdx.x + (uint32_t)it * BLOCK;
+            cv[it] = 0;
+            if (r < nrows) { LQ[r] = qv[it]; const uint32_t fl = s_kf[sv[it]] >> 24; cv[it] = (fl & SF_MULTI) ? s_pc[sv[it]] : a.bwlast[qv[it]]; }
+        }
+        __syncthreads();
+        // place inside the group: own index + entries of the other members' lists in front of q (pfbwt.hpp:137-181), ranked in LDS
+#pragma unroll
+        for (int it = 0; it < EG_PER_THREAD; ++it) {
+            const uint32_t r = threadIdx.x + (uint32_t)it * BLOCK;
+            if (r < nrows) {
+                const uint32_t s = sv[it], kf = s_kf[s];
+                uint32_t pos = r;
+                if ((kf >> 24) & SF_MULTI) {
+                    const uint32_t sh = s - s_dl[s], k = kf & 0xFFFFFFu, q = qv[it];
+                    uint32_t before = 0;
+                    for (uint32_t mm = 0; mm < k; ++mm) {
+                        const uint32_t sm = sh + mm;
+                        if (sm != s) before += lower_bound_u32(LQ + s_eb[sm], s_eb[sm + 1] - s_eb[sm], q);
+                    }
+                    pos = s_eb[sh] + before + (r - s_eb[s]);
+                }
+                OQ[pos] = qv[it]; OB[pos] = cv[it];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < EG_PER_THREAD; ++it) {
+            const uint32_t r = threadIdx.x + (uint32_t)it * BLOCK;
+            if (r < nrows) {
+                if (qrow) qrow[B0 - a.q0 + r] = OQ[r];
+                const uint64_t pos = s_ob[sv[it]] + r;          // r lies in the rows of sv's group, whatever member wrote it
+                if (pos >= a.w0 && pos < a.w1) bwt[pos - a.w0] = OB[r];
+            }
+        }
+        __syncthreads();
+        j += cut;
     }
 }
 

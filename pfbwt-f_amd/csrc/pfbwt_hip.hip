@@ -35,8 +35,13 @@ static int ensure_arena(pfp_ctx *c, uint64_t n_hint)
     }
     want &= ~(size_t)4095;     // both ends of the arena hand out 256-byte aligned blocks
     if (c->arena.base && c->arena.cap >= want) return PFP_OK;
-    if (c->arena.base) { PFP_HIP(c, hipStreamSynchronize(c->stream)); c->arena.vm.destroy(); c->arena.base = nullptr; c->arena.cap = 0; }
-    if (c->arena.vm.reserve(want, c->device) != hipSuccess) { c->arena.want = want; return PFP_E_NOMEM; }
+    // a larger range for a context that already has one (the same context parsed a shard and now merges all of them): the new range
+    // is reserved BEFORE the old one is given back, so that it never sits at the addresses kernels of this process used a moment ago
+    // (seen on the MI355X box: memory access faults / garbage in the stages behind such a re-reservation at the same address)
+    VmRegion nv;
+    if (nv.reserve(want, c->device) != hipSuccess) { c->arena.want = want; return PFP_E_NOMEM; }
+    if (c->arena.base) { PFP_HIP(c, hipStreamSynchronize(c->stream)); (void)hipDeviceSynchronize(); c->arena.vm.destroy(); c->arena.base = nullptr; c->arena.cap = 0; }
+    c->arena.vm = nv; nv.base = nullptr;
     c->arena.base = c->arena.vm.base; c->arena.cap = want; c->arena.reset();
     return PFP_OK;
 }
@@ -83,7 +88,7 @@ static void reset_results(pfp_ctx *c)
 
 // ---- route / tuning switches (pfbwt_hip_dev.h) -----------------------------------------------------
 static const char *const tunable_names[] = {"verbose", "seg_grid", "seg_stage", "sort_k", "sort_no_table", "class_sort_maxrange", "dedup_table_log2", "no_trigger_table",
-                                            "emit_chunk_rows", "fill_subs", "sample_cap", "no_runaware", "big_group_members", "force_wide_rows", "fasta_chunk_bytes", "ingest_block_bytes"};
+                                            "emit_chunk_rows", "fill_subs", "sample_cap", "no_runaware", "big_group_members", "force_wide_rows", "fasta_chunk_bytes", "ingest_block_bytes", "emit_group_rows"};
 static int set_tunable(pfp_ctx *c, const char *key, long long v)
 {
     Tunables &t = c->tun;
@@ -103,6 +108,7 @@ static int set_tunable(pfp_ctx *c, const char *key, long long v)
     else if (!strcmp(key, "force_wide_rows")) t.force_wide_rows = (int)v;
     else if (!strcmp(key, "fasta_chunk_bytes")) t.fasta_chunk_bytes = v > 0 ? (uint64_t)v : 0;
     else if (!strcmp(key, "ingest_block_bytes")) t.ingest_block_bytes = v > 0 ? (uint64_t)v : 0;
+    else if (!strcmp(key, "emit_group_rows")) t.emit_group_rows = v > 0 ? (uint32_t)v : 0u;
     else return PFP_E_ARG;
     return PFP_OK;
 }
@@ -1419,6 +1425,24 @@ template <typename SAT, typename EBT> static int emit_and_sample(pfp_ctx *c, Emi
         PFP_ALLOC_HI(c, bv0, uint32_t, ea.big_total); PFP_ALLOC_HI(c, bv1, uint32_t, ea.big_total); PFP_ALLOC_HI(c, btg, uint32_t, ea.big_total);
     }
     ea.big_keys = bk0; ea.big_vals = bv0; ea.big_count = d_b + 4; ea.big_cap = ea.big_total;
+    // group-stationary route of the special rows (k_emit_groups); what it leaves behind is marked for k_emit
+    ea.gleft = ea.tile_left = nullptr; ea.group_rows_cap = c->tun.emit_group_rows;
+    const uint64_t max_etiles = maxq / EMIT_TILE + 3;
+    if (runaware && ea.group_rows_cap && tot2) {
+        PFP_ALLOC_HI(c, ea.gleft, uint8_t, (size_t)ea.ecount + 1); PFP_ALLOC_HI(c, ea.tile_left, uint8_t, max_etiles);
+        PFP_HIP(c, hipMemsetAsync(ea.gleft, 0, (size_t)ea.ecount + 1, c->stream));      // which groups are left is a property of the build, not of a window
+    }
+    ea.gstat = nullptr;
+    if (ea.gleft && c->tun.verbose) { PFP_ALLOC_HI(c, ea.gstat, unsigned long long, 12); PFP_HIP(c, hipMemsetAsync(ea.gstat, 0, 96, c->stream)); }
+    struct GStat { pfp_ctx *c; EmitArgs &ea; ~GStat() {
+        if (!ea.gstat) return;
+        unsigned long long h[12];
+        if (hipMemcpy(h, ea.gstat, 96, hipMemcpyDeviceToHost) != hipSuccess) return;
+        fprintf(stderr, "[pfbwt_hip] special rows left to the row-wise kernel (counted once per window that enumerates them): whole-word member %llu, sort route %llu, too many rows %llu, too many slots %llu; by group rows (<1K <4K <16K <64K <256K <1M <4M more):",
+                h[0], h[1], h[2], h[3]);
+        for (int b = 0; b < 8; ++b) fprintf(stderr, " %llu", h[4 + b]);
+        fprintf(stderr, "\n");
+    } } gstat_print{c, ea};
     const BitRange big_ranges[2] = {{0, bits_for(c->nrows)}, {32, 32 + bits_for(ea.dsize)}};
     const uint32_t fill_subs_env = c->tun.fill_subs;     // super-tiles (4 x 4096 rows) per workgroup
     const uint32_t fill_subs = fill_subs_env < 1u ? 1u : fill_subs_env > FILL_MAX_SUBS ? FILL_MAX_SUBS : fill_subs_env;
@@ -1435,8 +1459,15 @@ template <typename SAT, typename EBT> static int emit_and_sample(pfp_ctx *c, Emi
                 const uint64_t nsub = (ea.w1 - 1) / super - ea.w0 / super + 1;
                 PFP_LAUNCH(c, K_FILL, rows, (k_fill<EBT>), nblocks(nsub, fill_subs), ea, bwt_at, fill_subs);
             }
-            if (ea.e1 > ea.e0)
-                PFP_LAUNCH(c, K_EMIT, (ea.e1 - ea.e0) * (1 + 4 + (q_at ? 4 : 0)), (k_emit<SAT, EBT>), (unsigned)((ea.e1 - 1) / EMIT_TILE - ea.e0 / EMIT_TILE + 1), ea, bwt_at, (SAT *)nullptr, q_at);
+            if (ea.e1 > ea.e0) {
+                const unsigned ge = (unsigned)((ea.e1 - 1) / EMIT_TILE - ea.e0 / EMIT_TILE + 1);
+                if (ea.gleft) {
+                    PFP_HIP(c, hipMemsetAsync(ea.tile_left, 0, (size_t)ge, c->stream));
+                    PFP_LAUNCH(c, K_EMIT, (ea.e1 - ea.e0) * (1 + 4 + (q_at ? 4 : 0)), (k_emit_groups<EBT>), ge, ea, bwt_at, q_at);
+                    PFP_LAUNCH(c, K_EMIT_BIG, 0, (k_emit<SAT, EBT>), ge, ea, bwt_at, (SAT *)nullptr, q_at);      // the groups left over (workgroups of other tiles return at once)
+                } else
+                PFP_LAUNCH(c, K_EMIT, (ea.e1 - ea.e0) * (1 + 4 + (q_at ? 4 : 0)), (k_emit<SAT, EBT>), ge, ea, bwt_at, (SAT *)nullptr, q_at);
+            }
         } else {
             ea.e0 = wn.e0; ea.e1 = wn.e1; ea.q0 = 0;
             PFP_LAUNCH(c, K_EMIT, rows * (1 + 4 + (sa_at ? 8 + sizeof(SAT) : 0) + (q_at ? 4 : 0)),   // per row: BWT byte out, ilist entry in, (bwsai gather + SA out | parse row out)

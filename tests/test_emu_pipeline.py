@@ -142,7 +142,7 @@ F = lambda **kw: pfbwt_hip.PfpContext(lib=EMU_SO, **kw)
 import os, random
 man, recs = golden_case("w4p7")
 cases = [([s for _, s in recs], man["w"], man["p"])]
-if "PFP_BIG_GROUP_MEMBERS" in os.environ or "PFP_CLASS_SORT_MIN" in os.environ:       # a small "panel": many words share long suffixes -> groups with many members
+if "PFP_BIG_GROUP_MEMBERS" in os.environ or "PFP_CLASS_SORT_MIN" in os.environ or "PFP_EMIT_GROUP_ROWS" in os.environ:       # a small "panel": many words share long suffixes -> groups with many members
     rng = random.Random(5); base = [rng.choice("ACGT") for _ in range(1500)]; haps = []
     for h in range(7):
         b = list(base)
@@ -163,6 +163,7 @@ print("variant ok")
 
 @pytest.mark.parametrize("env", [{"PFP_FORCE_WIDE_ROWS": "1"}, {"PFP_FORCE_WIDE_ROWS": "1", "PFP_EMIT_CHUNK_ROWS": "1000"},
                                  {"PFP_EMIT_CHUNK_ROWS": "777", "PFP_SAMPLE_CAP": "40"},
+                                 {"PFP_EMIT_GROUP_ROWS": "0"}, {"PFP_EMIT_GROUP_ROWS": "4096", "PFP_EMIT_CHUNK_ROWS": "1500"}, {"PFP_EMIT_GROUP_ROWS": "12", "PFP_EMIT_CHUNK_ROWS": "900", "PFP_FORCE_WIDE_ROWS": "1"},
                                  {"PFP_DEDUP_TABLE_LOG2": "4", "PFP_NO_TRIGGER_TABLE": "1", "PFP_NO_RUNAWARE": "1"},
                                  {"PFP_BIG_GROUP_MEMBERS": "1", "PFP_CLASS_SORT_MIN": "1"},
                                  {"PFP_BIG_GROUP_MEMBERS": "2", "PFP_EMIT_CHUNK_ROWS": "5000", "PFP_CLASS_SORT_MIN": "1", "PFP_CLASS_SORT_MAXRANGE": "150"},
