@@ -157,7 +157,9 @@ typedef struct pfp_shard_view {
     const uint32_t *d_ws;           /* dwords+1 word starts in d_dict */
     const uint32_t *d_pid;          /* m: word id of every phrase */
     const uint64_t *d_ye;           /* m: 1-based end position of every phrase in the shard's text (= sai) */
-    const uint8_t *d_last;          /* m */
+    const uint8_t *d_last;          /* m.  d_ye and d_last may BOTH be NULL: pfp_merge_shards then derives them from d_dict / d_ws / d_pid
+                                       (a phrase ends where its predecessor ended + its word's length - w), so that only the dictionary
+                                       and 4 bytes per phrase have to travel between GPUs */
     uint64_t left_context;          /* bytes of left context in front of the shard's own text: w (pfp_parse_feed_left_context: the
                                        shard was parsed knowing that w 'A's precede it) or 0 (a stand-alone parse, e.g. one made by
                                        `pfbwt-f --parse-only` and loaded with pfp_shard_load: the merge then re-tests the first w

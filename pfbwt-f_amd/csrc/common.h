@@ -27,14 +27,14 @@ enum KernelId {
     K_TRIGGER_SCAN, K_PHRASE_ENDS, K_PHRASE_HASH, K_PHRASE_HASH_LONG, K_DEDUP_HEADS, K_DEDUP_LONG,
     K_DICT_BUILD, K_RADIX_HIST, K_RADIX_SCATTER, K_SCAN_REDUCE, K_SCAN_SPINE, K_SCAN_APPLY,
     K_SS_INIT_KEYS, K_SS_HEADS, K_SS_MAKE_KEYS, K_SS_WRITE_RANK, K_SS_FLAG_ACTIVE, K_COMPACT,
-    K_WORD_RANK, K_PARSE_RANKS, K_DICT_SORTED, K_PBWT_ROWS, K_EMIT_COUNT, K_EMIT, K_RUNS, K_SAMPLES, K_MISC, K_EMIT_BIG, K_FILL, K_CLASS_SORT, K_FASTA,
+    K_WORD_RANK, K_PARSE_RANKS, K_DICT_SORTED, K_PBWT_ROWS, K_EMIT_COUNT, K_EMIT, K_RUNS, K_SAMPLES, K_MISC, K_EMIT_BIG, K_FILL, K_CLASS_SORT, K_FASTA, K_EMIT_LARGE,
     K_COUNT_
 };
 static const char *const kernel_names[K_COUNT_] = {
     "trigger_scan", "phrase_ends", "phrase_hash", "phrase_hash_long", "dedup_heads", "dedup_long",
     "dict_build", "radix_hist", "radix_scatter", "scan_reduce", "scan_spine", "scan_apply",
     "ss_init_keys", "ss_heads", "ss_make_keys", "ss_write_rank", "ss_flag_active", "compact",
-    "word_rank", "parse_ranks", "dict_sorted", "pbwt_rows", "emit_count", "emit", "runs", "samples", "misc", "emit_big", "fill", "class_sort", "fasta_strip"};
+    "word_rank", "parse_ranks", "dict_sorted", "pbwt_rows", "emit_count", "emit", "runs", "samples", "misc", "emit_big", "fill", "class_sort", "fasta_strip", "emit_large"};
 
 struct ProfRec { uint64_t launches = 0; double ms = 0, bytes = 0; };
 
@@ -134,6 +134,7 @@ struct pfp_ctx {
     // --- parse-BWT results
     uint64_t nrows = 0;
     uint8_t *d_bwlast = nullptr; uint32_t *d_ilist = nullptr; uint64_t *d_bwsai = nullptr;
+    uint8_t *d_bwl_il = nullptr;    // bwlast in ilist order, bwl_il[k] = bwlast[ilist[k]] (nullptr: not made -- loaded files, 2^29 parse rows or more)
     // --- BWT results
     uint64_t nout = 0, runs = 0, esa_pairs = 0, easy = 0, hard = 0, slice_begin = 0, slice_rows = 0;
     uint8_t *d_bwt = nullptr; void *d_sa = nullptr; void *d_ssa = nullptr; void *d_esa = nullptr;

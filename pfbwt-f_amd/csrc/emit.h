@@ -26,17 +26,41 @@ __global__ __launch_bounds__(BLOCK) void k_pbwt_pack(const uint32_t *P, const ui
     const uint64_t v = sai ? (uint64_t)sai[j] : 0ULL;
     rec[j] = make_uint4((uint32_t)v, (uint32_t)(v >> 32), P[j], (uint32_t)last[j ? j - 1 : m - 1]);
 }
-__global__ __launch_bounds__(BLOCK) void k_pbwt_rows(const uint32_t *SAP, const uint4 *rec, uint64_t m, uint8_t *bwlast, tpos_t *bwsai, uint32_t *W, uint32_t *rowid)
+// The emission of a whole-word slot writes bwlast[ilist[k]] for the word's occurrences k (pfbwt.hpp:116-128): 325 M random byte
+// reads on S-32G (12 ms).  With fewer than 2^29 parse rows the byte travels through the sort that makes ilist instead, as a 3-bit
+// code in the top bits of the row id: 0 (the row of the end-of-string phrase), Dollar, '-', A, C, G, N, T -- the bytes a normalised
+// text holds.  Any other byte sets *bad and the caller gathers.
+constexpr int BWL_SHIFT = 29;
+__device__ __forceinline__ uint32_t bwl_code(uint32_t c) { return c == 0 ? 0u : c == Dollar ? 1u : c == '-' ? 2u : c == 'A' ? 3u : c == 'C' ? 4u : c == 'G' ? 5u : c == 'N' ? 6u : c == 'T' ? 7u : 8u; }
+__device__ __forceinline__ uint8_t bwl_byte(uint32_t code) { return code == 0 ? (uint8_t)0 : code == 1 ? Dollar : code == 2 ? (uint8_t)'-' : code == 3 ? (uint8_t)'A' : code == 4 ? (uint8_t)'C' : code == 5 ? (uint8_t)'G' : code == 6 ? (uint8_t)'N' : (uint8_t)'T'; }
+__global__ __launch_bounds__(BLOCK) void k_pbwt_rows(const uint32_t *SAP, const uint4 *rec, uint64_t m, uint8_t *bwlast, tpos_t *bwsai, uint32_t *W, uint32_t *rowid, int pack, uint32_t *bad)
 {
     const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i > m) return;
     const uint32_t s = SAP[i];
-    rowid[i] = (uint32_t)i;
-    if (s == 0) { bwlast[i] = 0; if (bwsai) bwsai[i] = 0; W[i] = 0; return; }
+    if (s == 0) { bwlast[i] = 0; if (bwsai) bwsai[i] = 0; W[i] = 0; rowid[i] = (uint32_t)i; return; }
     const uint4 R = rec[s - 1];
     bwlast[i] = (uint8_t)R.w;                                   // last[s - 2], last[m - 1] when s == 1 (:443-449)
     if (bwsai) bwsai[i] = (tpos_t)(((uint64_t)R.y << 32) | R.x);
     W[i] = R.z;
+    uint32_t id = (uint32_t)i;
+    if (pack) { const uint32_t code = bwl_code(R.w & 0xFFu); if (code > 7u) *bad = 1u; else id |= code << BWL_SHIFT; }
+    rowid[i] = id;
+}
+// the sorted (packed) row ids -> ilist and the bytes in ilist order
+__global__ __launch_bounds__(BLOCK) void k_ilist_split(const uint32_t *packed, uint64_t n, uint32_t *ilist, uint8_t *bwl_il)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t v = packed[k];
+    ilist[k] = v & ((1u << BWL_SHIFT) - 1u); bwl_il[k] = bwl_byte(v >> BWL_SHIFT);
+}
+__global__ __launch_bounds__(BLOCK) void k_ilist_gather(const uint32_t *packed, uint64_t n, uint32_t mask, const uint8_t *bwlast, uint32_t *ilist, uint8_t *bwl_il)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t q = packed[k] & mask;
+    ilist[k] = q; bwl_il[k] = bwlast[q];
 }
 
 __global__ __launch_bounds__(BLOCK) void k_u32_add_store(const uint32_t *in, uint64_t n, uint32_t add, uint32_t *out)
@@ -96,6 +120,7 @@ struct EmitArgs {
     const uint2 *posinfo;
     const uint4 *winfo;     // per word id: { first byte, offset of its EndOfWord, first ilist index F[rank], occ[rank] }
     const uint8_t *bwlast;
+    const uint8_t *bwl_il;  // nullable: bwlast in ilist order
     const void *EB;         // exclusive scan of the per-slot row counts: uint32_t, or uint64_t when n+1 >= 2^32 (template EBT)
     const uint32_t *s_sl;   // per slot: suffix length
     const uint32_t *s_fb;   // per slot: first ilist index of the slot's word (F[rank])
@@ -125,6 +150,10 @@ struct EmitArgs {
     // group-stationary route of the special rows (k_emit_groups): what it leaves to k_emit -- gleft[j] != 0: the group whose head is
     // the j-th special slot; tile_left[t] != 0: enumeration tile t of this launch holds rows of such a group.  nullptr: k_emit walks everything
     uint8_t *gleft, *tile_left; uint32_t group_rows_cap;
+    const uint4 *cinfo;          // per special slot j (k_special_pack): { first ilist index, members of its group, its index inside the group, preceding byte | SF_* flags << 8 }
+    const unsigned long long *cgb;   // per special slot: output row of the first row of its group
+    const uint32_t *town;        // per enumeration tile t: head (index of special slots) of the first group that starts at or behind row t * EMIT_TILE
+    uint32_t *lglist; unsigned long long *lgcount; uint64_t lgcap; int qpasses /*8-bit digits that hold a parse row*/;   // groups of more rows than a batch holds, taken one per workgroup by k_emit_groups_large (heads as indices of special slots)
     unsigned long long *gstat;   // PFP_VERBOSE: rows left to k_emit by reason [0] whole-word member, [1] sort route, [2] too many rows, [3] too many slots; [4..11] rows of left groups by log4 of the group's rows
 };
 constexpr uint8_t SF_MULTI = 1, SF_FULL = 2, SF_BIG = 4, SF_GFULL = 8, SF_NONUNI = 16;   // GFULL: some member of the group is a whole word; NONUNI: members with different preceding bytes
@@ -600,37 +629,63 @@ template <typename SAT, typename EBT> __global__ __launch_bounds__(BLOCK) void k
 // loads per row, 52 ms for the 1.3 G special rows of S-32G (0.03 of the HBM roofline, latency-bound).  Here the tile follows the
 // GROUPS, not the rows: a workgroup owns the groups whose first enumeration row lies in its stripe of EMIT_TILE rows, takes them in
 // batches of whole groups (at most EG_BUF rows, EG_SLOTS slots), reads the members' occurrence lists ONCE, coalesced, into LDS,
-// ranks there, and writes bytes and parse rows in output order through LDS.  A whole-word slot is a group of one list (its bytes
+// ranks there, and stores bytes and parse rows at their places in the group's stretch of the output.  A whole-word slot is a group of one list (its bytes
 // are bwlast[q]: the one random gather left).  Groups that do not fit a batch, groups with a whole-word member (reference quirk,
 // multi_group_pos) and sort-route groups are left to k_emit: their heads are marked in gleft[], the enumeration tiles their rows
 // touch in tile_left[].
 constexpr int EG_BUF = 4096, EG_SLOTS = 2 * BLOCK, EG_PER_THREAD = EG_BUF / BLOCK;
+constexpr int EG1_BUF = 8192, EG2_BUF = 16384;              // rows of a group k_emit_groups_large holds in LDS (S-32G: 349 M special rows sit in groups of 4-16 K rows, 8-63 members)
 __device__ __forceinline__ uint32_t group_members(const EmitArgs &a, const uint4 &S) { const uint32_t k = S.w & 0xFFFFFFu; return k == 0xFFFFFFu ? a.gk[S.z] : k; }
+// what a batch needs of a special slot, gathered once per build (the chain elist -> sinfo -> s_pc / EB costs a workgroup three
+// dependent memory round trips per batch otherwise: k_emit_groups is bound by such chains, not by bytes)
+template <typename EBT> __global__ __launch_bounds__(BLOCK) void k_special_pack(EmitArgs a, uint32_t nsp, uint4 *cinfo, unsigned long long *cgb)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (j >= nsp) return;
+    const uint32_t i = a.elist[j]; const uint4 S = a.sinfo[i];
+    const uint32_t fl = S.w >> 24; const bool multi = (fl & SF_MULTI) != 0;
+    cinfo[j] = make_uint4(S.x, multi ? group_members(a, S) : 1u, multi ? i - S.z : 0u, (uint32_t)a.s_pc[i] | (fl << 8));
+    cgb[j] = (unsigned long long)reinterpret_cast<const EBT *>(a.EB)[multi ? S.z : i];
+}
+// head of the first group that starts at or behind enumeration row v, searched from slot `lo` on (a slot at or in front of it)
+template <typename EBT> __device__ __forceinline__ uint64_t group_start_at_or_after(const EBT *ENB, const uint4 *cinfo, uint64_t nsp, uint64_t lo, uint64_t v)
+{
+    while (lo < nsp && (uint64_t)ENB[lo] < v) ++lo;
+    if (lo >= nsp) return nsp;
+    const uint4 ci = cinfo[lo];
+    if (!((ci.w >> 8) & SF_MULTI)) return lo;
+    const uint64_t head = lo - ci.z;
+    return (uint64_t)ENB[head] < v ? head + ci.y : head;
+}
+template <typename EBT> __global__ __launch_bounds__(BLOCK) void k_tile_own(const EBT *ENB, const uint4 *cinfo, const uint32_t *etile_slot, uint64_t nsp, uint64_t ntiles, uint32_t *town)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t > ntiles) return;
+    town[t] = (uint32_t)group_start_at_or_after<EBT>(ENB, cinfo, nsp, etile_slot[t], t * EMIT_TILE);      // every special slot has rows: the walk is one or two steps
+}
 template <typename EBT> __global__ __launch_bounds__(BLOCK) void k_emit_groups(EmitArgs a, uint8_t *bwt, uint32_t *qrow)
 {
     __shared__ uint32_t LQ[EG_BUF];             // parse rows of the batch, in enumeration order (= list by list)
-    __shared__ uint32_t OQ[EG_BUF];             // the same in output order
-    __shared__ uint8_t OB[EG_BUF];              // BWT bytes in output order
     __shared__ uint32_t s_eb[EG_SLOTS + 1], s_fb[EG_SLOTS], s_kf[EG_SLOTS], s_dl[EG_SLOTS];
     __shared__ uint64_t s_ob[EG_SLOTS];         // output row of the first row of the slot's group, minus that row's place in the batch
     __shared__ uint8_t s_pc[EG_SLOTS];
     __shared__ uint32_t red[4];
     __shared__ uint64_t jb[2];
-    const EBT *EB = reinterpret_cast<const EBT *>(a.EB);
     const EBT *ENB = reinterpret_cast<const EBT *>(a.ENB);
     const uint64_t tile0 = a.e0 / EMIT_TILE, tb = tile0 + blockIdx.x;
     const uint64_t o0 = tb * EMIT_TILE > a.e0 ? tb * EMIT_TILE : a.e0;
     const uint64_t o1 = ((tb + 1) * EMIT_TILE < a.e1) ? (tb + 1) * EMIT_TILE : a.e1;
     if (threadIdx.x < 2) {      // head of the first group that starts at or behind row v (v = o0: first owned group, v = o1: end of the owned groups)
         const uint64_t v = threadIdx.x ? o1 : o0;
-        uint64_t lo = a.etile_slot[tb], hi = (uint64_t)a.etile_slot[tb + 1] + 1u;
-        if (hi > a.ecount) hi = a.ecount;
-        if (lo > hi) lo = hi;
-        while (lo < hi) { const uint64_t mid = lo + ((hi - lo) >> 1); if ((uint64_t)ENB[mid] < v) lo = mid + 1; else hi = mid; }
-        uint64_t j = lo;
-        if (j < a.ecount) {
-            const uint32_t i = a.elist[j]; const uint4 S = a.sinfo[i];
-            if ((S.w >> 24) & SF_MULTI) { const uint64_t head = j - (i - S.z); j = (uint64_t)ENB[head] < v ? head + group_members(a, S) : head; }
+        const uint64_t tv = threadIdx.x ? tb + 1 : tb;
+        uint64_t j;
+        if (v == tv * EMIT_TILE) j = a.town[tv];
+        else {                          // first / last tile of a window that does not start / end on a tile boundary
+            uint64_t lo = a.etile_slot[tb], hi = (uint64_t)a.etile_slot[tb + 1] + 1u;
+            if (hi > a.ecount) hi = a.ecount;
+            if (lo > hi) lo = hi;
+            while (lo < hi) { const uint64_t mid = lo + ((hi - lo) >> 1); if ((uint64_t)ENB[mid] < v) lo = mid + 1; else hi = mid; }
+            j = group_start_at_or_after<EBT>(ENB, a.cinfo, a.ecount, lo, v);
         }
         jb[threadIdx.x] = j;
     }
@@ -645,14 +700,13 @@ template <typename EBT> __global__ __launch_bounds__(BLOCK) void k_emit_groups(E
         for (int t = 0; t < 2; ++t) {
             const uint32_t s = threadIdx.x + (uint32_t)t * BLOCK;
             if (s < nload) {
-                const uint32_t i = a.elist[j + s]; const uint4 S = a.sinfo[i];
-                const uint32_t fl = S.w >> 24; const bool multi = (fl & SF_MULTI) != 0;
-                const uint32_t dl = multi ? i - S.z : 0u, k = multi ? group_members(a, S) : 1u;
+                const uint4 ci = a.cinfo[j + s];
+                const uint32_t fl = ci.w >> 8, dl = ci.z, k = ci.y;
                 const uint64_t e0 = (uint64_t)ENB[j + s] - B0, e1 = (uint64_t)ENB[j + s + 1] - B0;
                 s_eb[s] = e0 < 0xFFFFFFFFull ? (uint32_t)e0 : 0xFFFFFFFFu;
                 if (s + 1 == nload) s_eb[nload] = e1 < 0xFFFFFFFFull ? (uint32_t)e1 : 0xFFFFFFFFu;
-                s_fb[s] = S.x; s_kf[s] = (k < 0xFFFFFFu ? k : 0xFFFFFFu) | (fl << 24); s_dl[s] = dl; s_pc[s] = a.s_pc[i];
-                s_ob[s] = (uint64_t)EB[multi ? S.z : i];
+                s_fb[s] = ci.x; s_kf[s] = (k < 0xFFFFFFu ? k : 0xFFFFFFu) | (fl << 24); s_dl[s] = dl; s_pc[s] = (uint8_t)ci.w;
+                s_ob[s] = (uint64_t)a.cgb[j + s];
                 if ((fl & (SF_GFULL | SF_BIG)) && s < bad) bad = s;
                 if (dl + 1u == k && e1 <= (uint64_t)cap) cand[t] = s + 1u;       // a batch may end behind this slot
             }
@@ -666,8 +720,24 @@ template <typename EBT> __global__ __launch_bounds__(BLOCK) void k_emit_groups(E
         uint32_t cut;
         (void)block_incl_max(c, red, &cut);
         if (cut == 0) {      // the group at j is left to k_emit
-            const uint32_t k0 = (s_kf[0] >> 24) & SF_MULTI ? ((s_kf[0] & 0xFFFFFFu) == 0xFFFFFFu ? a.gk[a.elist[j]] : (s_kf[0] & 0xFFFFFFu)) : 1u;
+            const uint32_t k0 = a.cinfo[j].y;
             const uint64_t r0 = B0, r1 = (uint64_t)ENB[j + k0];
+            {   // a group of ordinary members that is only too long for a batch: one workgroup of k_emit_groups_large takes it
+                const uint32_t f0 = s_kf[0] >> 24;
+                if (threadIdx.x == 0) {
+                    unsigned long long idx = ~0ULL;
+                    if (a.lglist && (f0 & SF_MULTI) && !(f0 & (SF_GFULL | SF_BIG)) && k0 <= (uint32_t)EG_SLOTS && r1 - r0 <= (uint64_t)EG2_BUF) {
+                        const int big = r1 - r0 > (uint64_t)EG1_BUF ? 1 : 0;      // two lists: a workgroup that holds 8 K rows leaves room for a second one on its CU
+                        idx = atomicAdd(a.lgcount + big, 1ULL);
+                        if (idx < a.lgcap) a.lglist[(uint64_t)big * a.lgcap + idx] = (uint32_t)j;
+                    }
+                    jb[0] = idx < a.lgcap ? 1 : 0;
+                }
+                __syncthreads();
+                const bool taken = jb[0] != 0;
+                __syncthreads();
+                if (taken) { j += k0; continue; }
+            }
             if (threadIdx.x == 0) a.gleft[j] = 1;
             if (a.gstat && threadIdx.x == 0) {
                 const uint32_t f0 = s_kf[0] >> 24;
@@ -689,17 +759,24 @@ template <typename EBT> __global__ __launch_bounds__(BLOCK) void k_emit_groups(E
 #pragma unroll
         for (int it = 0; it < EG_PER_THREAD; ++it) {
             const uint32_t r = threadIdx.x + (uint32_t)it * BLOCK;
-            sv[it] = 0; qv[it] = 0;
-            if (r < nrows) { const uint32_t s = upper_bound_t<uint32_t>(s_eb, cut, r) - 1u; sv[it] = s; qv[it] = a.ilist[s_fb[s] + (r - s_eb[s])]; }
+            sv[it] = 0; qv[it] = 0; cv[it] = 0;
+            if (r < nrows) {
+                const uint32_t s = upper_bound_t<uint32_t>(s_eb, cut, r) - 1u, at = s_fb[s] + (r - s_eb[s]);
+                sv[it] = s; qv[it] = a.ilist[at];
+                if (!((s_kf[s] >> 24) & SF_MULTI) && a.bwl_il) cv[it] = a.bwl_il[at];
+            }
         }
 #pragma unroll
         for (int it = 0; it < EG_PER_THREAD; ++it) {
             const uint32_t r = threadIdx.x + (uint32_t)it * BLOCK;
-            cv[it] = 0;
-            if (r < nrows) { LQ[r] = qv[it]; const uint32_t fl = s_kf[sv[it]] >> 24; cv[it] = (fl & SF_MULTI) ? s_pc[sv[it]] : a.bwlast[qv[it]]; }
+            if (r < nrows) { LQ[r] = qv[it]; const uint32_t fl = s_kf[sv[it]] >> 24; if (fl & SF_MULTI) cv[it] = s_pc[sv[it]]; else if (!a.bwl_il) cv[it] = a.bwlast[qv[it]]; }
         }
         __syncthreads();
-        // place inside the group: own index + entries of the other members' lists in front of q (pfbwt.hpp:137-181), ranked in LDS
+        // Place inside the group: own index + entries of the other members' lists in front of q (pfbwt.hpp:137-181), by bisection
+        // in LDS.  Measured on S-32G (tools/emit_bench.py; 12 of the kernel's 18 ms are this ranking): 2, 4 or 8 rows of a thread
+        // ranked in lock step are slower (20 / 23 / 33 ms: the rows of a thread sit in different groups, every row then waits for
+        // the largest group), consecutive rows per thread with the other lists walked or galloped instead of bisected are much
+        // slower (64-110 ms: the slowest lane of a wave sets the pace of every step).
 #pragma unroll
         for (int it = 0; it < EG_PER_THREAD; ++it) {
             const uint32_t r = threadIdx.x + (uint32_t)it * BLOCK;
@@ -715,21 +792,100 @@ template <typename EBT> __global__ __launch_bounds__(BLOCK) void k_emit_groups(E
                     }
                     pos = s_eb[sh] + before + (r - s_eb[s]);
                 }
-                OQ[pos] = qv[it]; OB[pos] = cv[it];
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int it = 0; it < EG_PER_THREAD; ++it) {
-            const uint32_t r = threadIdx.x + (uint32_t)it * BLOCK;
-            if (r < nrows) {
-                if (qrow) qrow[B0 - a.q0 + r] = OQ[r];
-                const uint64_t pos = s_ob[sv[it]] + r;          // r lies in the rows of sv's group, whatever member wrote it
-                if (pos >= a.w0 && pos < a.w1) bwt[pos - a.w0] = OB[r];
+                // stored straight to their places: a whole-word slot's rows are consecutive, a group's rows stay inside its own stretch
+                if (qrow) qrow[B0 - a.q0 + pos] = qv[it];
+                const uint64_t o = s_ob[s] + pos;
+                if (o >= a.w0 && o < a.w1) bwt[o - a.w0] = cv[it];
             }
         }
         __syncthreads();
         j += cut;
+    }
+}
+
+// The groups k_emit_groups found too long for a batch (lglist): one group per workgroup turn.  Ranking every row in every other
+// member's list costs members x log(list) LDS reads per row (measured on S-32G, groups of 4-16 K rows with 8-63 members: 66 ms,
+// twice what k_emit needs in memory); merging the members' lists is SORTING the group's parse rows, so the (parse row, member)
+// pairs are radix-sorted in LDS -- the wave-ballot LSD passes of the class sort (sufsort.h), 8-bit digits, as many passes as the
+// parse has row bits -- and the sorted order IS the output order: bytes and parse rows leave coalesced.
+template <int ITEMS> __device__ __forceinline__ void lds_sort_pairs_u32(uint32_t *keys, uint16_t *vals, uint32_t n, int npass, uint32_t (*wh)[RS_RADIX], uint32_t *red)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t nit = (n + BLOCK - 1) / BLOCK;                  // <= ITEMS; wave w owns the contiguous pairs [w * nit * 64, (w + 1) * nit * 64)
+    for (uint32_t j = n + threadIdx.x; j < nit * BLOCK; j += BLOCK) { keys[j] = 0xFFFFFFFFu; vals[j] = 0; }      // padding stays behind the real pairs (stable)
+    const uint32_t base = (uint32_t)wave * (nit * WAVE) + lane;
+    for (int p = 0; p < npass; ++p) {
+        const int sh = 8 * p;
+        uint32_t k[ITEMS], dg[ITEMS]; uint16_t v[ITEMS];
+#pragma unroll
+        for (int w = 0; w < BLOCK / WAVE; ++w) wh[w][threadIdx.x] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            if ((uint32_t)it < nit) {
+                const uint32_t i = base + (uint32_t)it * WAVE;
+                k[it] = keys[i]; v[it] = vals[i];
+                const uint32_t d = (k[it] >> sh) & 255u;
+                uint32_t plo = 0xFFFFFFFFu, phi = 0xFFFFFFFFu;
+                same_digit_lanes(d, plo, phi);
+                const int leader = plo ? __builtin_ctz(plo) : 32 + __builtin_ctz(phi);
+                uint32_t old = 0;
+                if (lane == leader) { old = wh[wave][d]; wh[wave][d] = old + (uint32_t)__builtin_popcount(plo) + (uint32_t)__builtin_popcount(phi); }
+                old = __shfl(old, leader);
+                dg[it] = d | ((old + __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u))) << 8);
+            }
+        }
+        __syncthreads();
+        {
+            const unsigned d = threadIdx.x;
+            uint32_t cw[BLOCK / WAVE]; uint32_t total = 0;
+#pragma unroll
+            for (int w = 0; w < BLOCK / WAVE; ++w) { cw[w] = wh[w][d]; total += cw[w]; }
+            uint32_t tt;
+            uint32_t run = block_excl_sum(total, red, &tt);
+#pragma unroll
+            for (int w = 0; w < BLOCK / WAVE; ++w) { wh[w][d] = run; run += cw[w]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            if ((uint32_t)it < nit) { const uint32_t li = wh[wave][dg[it] & 255u] + (dg[it] >> 8); keys[li] = k[it]; vals[li] = v[it]; }
+        }
+        __syncthreads();
+    }
+}
+template <typename EBT, int BUF> __global__ __launch_bounds__(BLOCK) void k_emit_groups_large(EmitArgs a, uint8_t *bwt, uint32_t *qrow)
+{
+    __shared__ uint32_t LQ[BUF];
+    __shared__ uint16_t LS[BUF];
+    __shared__ uint32_t wh[BLOCK / WAVE][RS_RADIX];
+    __shared__ uint32_t s_eb[EG_SLOTS + 1], s_fb[EG_SLOTS];
+    __shared__ uint8_t s_pc[EG_SLOTS];
+    __shared__ uint32_t red[4];
+    const EBT *ENB = reinterpret_cast<const EBT *>(a.ENB);
+    constexpr int WHICH = BUF > EG1_BUF ? 1 : 0;
+    const unsigned long long have = a.lgcount[WHICH];
+    const uint64_t cnt = have < a.lgcap ? have : a.lgcap;
+    for (uint64_t g = blockIdx.x; g < cnt; g += gridDim.x) {      // uniform
+        const uint64_t j = a.lglist[(uint64_t)WHICH * a.lgcap + g];
+        const uint32_t k = a.cinfo[j].y;                           // <= EG_SLOTS, rows <= BUF (k_emit_groups checked)
+        const uint64_t B0 = (uint64_t)ENB[j], outbase = (uint64_t)a.cgb[j];
+        for (uint32_t s = threadIdx.x; s < k; s += BLOCK) {
+            const uint4 ci = a.cinfo[j + s];
+            s_eb[s] = (uint32_t)((uint64_t)ENB[j + s] - B0); s_fb[s] = ci.x; s_pc[s] = (uint8_t)ci.w;
+            if (s + 1 == k) s_eb[k] = (uint32_t)((uint64_t)ENB[j + k] - B0);
+        }
+        __syncthreads();
+        const uint32_t nrows = s_eb[k];
+        for (uint32_t r = threadIdx.x; r < nrows; r += BLOCK) { const uint32_t s = upper_bound_t<uint32_t>(s_eb, k, r) - 1u; LQ[r] = a.ilist[s_fb[s] + (r - s_eb[s])]; LS[r] = (uint16_t)s; }
+        __syncthreads();
+        lds_sort_pairs_u32<BUF / BLOCK>(LQ, LS, nrows, a.qpasses, wh, red);      // distinct words' occurrence lists share no parse row: no ties
+        for (uint32_t r = threadIdx.x; r < nrows; r += BLOCK) {
+            if (qrow) qrow[B0 - a.q0 + r] = LQ[r];
+            const uint64_t o = outbase + r;
+            if (o >= a.w0 && o < a.w1) bwt[o - a.w0] = s_pc[LS[r]];
+        }
+        __syncthreads();
     }
 }
 

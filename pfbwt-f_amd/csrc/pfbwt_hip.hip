@@ -78,7 +78,7 @@ static void reset_results(pfp_ctx *c)
 {
     c->stage = 0; c->n = 0; c->tb_n = 0; c->left_ctx = 0; c->m = c->dwords = c->dsize = 0; c->nrows = 0; c->nout = c->runs = c->esa_pairs = 0;
     c->gsa_valid = false; c->d_wrank = nullptr; c->d_bwt = nullptr; c->d_sa = c->d_ssa = c->d_esa = nullptr;
-    c->d_bwlast = nullptr; c->d_ilist = nullptr; c->d_bwsai = nullptr;
+    c->d_bwlast = nullptr; c->d_ilist = nullptr; c->d_bwsai = nullptr; c->d_bwl_il = nullptr;
     c->d_ma = nullptr; c->ma_words = 0; c->ma_lo_mark = (size_t)-1;
     c->d_ye = nullptr; c->d_pid = nullptr; c->d_parse = nullptr; c->d_last = nullptr; c->d_dict = nullptr; c->d_ws = nullptr; c->d_wordid = nullptr;
     c->d_occ = nullptr; c->d_sdict = nullptr; c->d_gsa = nullptr; c->d_grank = nullptr;
@@ -898,6 +898,19 @@ __global__ __launch_bounds__(BLOCK) void k_shard_phrases(const uint32_t *parse, 
     adv[j] = j ? (unsigned long long)(len - (uint32_t)w) : (unsigned long long)len;      // phrase 0 starts at Y[0] (its Dollar); later ones overlap by w
     last[j] = dict[s + len - (uint32_t)w - 1u];                                          // pfparser.hpp:599
 }
+// a shard view without d_ye / d_last (what travels over xGMI is dictionary + word starts + phrase ids only): phrase j is word
+// pid[j], it advances the text by its length minus the w bytes it shares with its predecessor, its `last` byte sits in the word
+__global__ __launch_bounds__(BLOCK) void k_view_phrases(const uint32_t *pid, const uint32_t *ws, const uint8_t *dict, uint64_t m, uint32_t dwords, int w, unsigned long long *adv, uint8_t *last, uint32_t *bad)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (j >= m) return;
+    const uint32_t id = pid[j];
+    if (id >= dwords) { atomicAdd(bad, 1u); adv[j] = 0; last[j] = 0; return; }
+    const uint32_t s = ws[id], len = ws[id + 1] - s - 1u;
+    if (len <= (uint32_t)w) { atomicAdd(bad, 1u); adv[j] = 0; last[j] = 0; return; }
+    adv[j] = j ? (unsigned long long)(len - (uint32_t)w) : (unsigned long long)len;
+    last[j] = dict[s + len - (uint32_t)w - 1u];
+}
 __global__ __launch_bounds__(BLOCK) void k_shard_ends(const unsigned long long *adv_ex, const unsigned long long *adv, uint64_t m, tpos_t *ye)
 {
     const uint64_t j = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -992,7 +1005,7 @@ static int merge_shards_impl(pfp_ctx *c, int nshards, const pfp_shard_view *v, p
     for (int r = 0; r < nshards; ++r) {
         const uint64_t lc = v[r].left_context;
         if ((lc != 0 && lc != w) || (r == 0 && lc != 0)) return PFP_E_ARG;
-        if (v[r].m < 1 || v[r].n < lc + 1 || !v[r].d_dict || !v[r].d_ws || !v[r].d_pid || !v[r].d_ye || !v[r].d_last) return PFP_E_ARG;
+        if (v[r].m < 1 || v[r].n < lc + 1 || !v[r].d_dict || !v[r].d_ws || !v[r].d_pid || (!v[r].d_ye) != (!v[r].d_last)) return PFP_E_ARG;      // d_ye and d_last: both or neither (derived below)
         ia[r] = r ? 1 : 0; ib[r] = r + 1 < nshards ? v[r].m - 1 : v[r].m;
         if (ib[r] < ia[r]) ib[r] = ia[r];
         ntot += v[r].n - lc; mtot += ib[r] - ia[r]; dtot += v[r].dsize; ctot += v[r].dwords;
@@ -1128,6 +1141,28 @@ static int merge_shards_impl(pfp_ctx *c, int nshards, const pfp_shard_view *v, p
     PFP_ALLOC_LO(c, c->d_pid, uint32_t, mtot); PFP_ALLOC_LO(c, c->d_ye, tpos_t, mtot); PFP_ALLOC_LO(c, c->d_last, uint8_t, mtot);
     PFP_ALLOC_HI(c, occw, uint32_t, dwords);
     PFP_HIP(c, hipMemsetAsync(occw, 0, dwords * 4, c->stream));
+    // compact views (no d_ye / d_last): phrase ends and last bytes from the shard's own dictionary and phrase ids
+    std::vector<const tpos_t *> vye((size_t)nshards); std::vector<const uint8_t *> vlast((size_t)nshards);
+    for (int r = 0; r < nshards; ++r) {
+        vye[r] = v[r].d_ye; vlast[r] = v[r].d_last;
+        if (v[r].d_ye) continue;
+        const uint64_t mr = v[r].m;
+        tpos_t *ye; uint8_t *la; unsigned long long *adv, *advx, *d_tot; uint32_t *d_bad;
+        PFP_ALLOC_HI(c, ye, tpos_t, mr); PFP_ALLOC_HI(c, la, uint8_t, mr);
+        const size_t mk2 = c->arena.mark_hi();
+        PFP_ALLOC_HI(c, adv, unsigned long long, mr); PFP_ALLOC_HI(c, advx, unsigned long long, mr); PFP_ALLOC_HI(c, d_tot, unsigned long long, 1); PFP_ALLOC_HI(c, d_bad, uint32_t, 1);
+        PFP_HIP(c, hipMemsetAsync(d_bad, 0, 4, c->stream));
+        PFP_LAUNCH(c, K_MISC, mr * 24, k_view_phrases, nblocks(mr, BLOCK), v[r].d_pid, v[r].d_ws, v[r].d_dict, mr, (uint32_t)v[r].dwords, (int)w, adv, la, d_bad);
+        PFP_TRY((device_scan<unsigned long long, 0>(c, adv, advx, mr, d_tot)));
+        PFP_LAUNCH(c, K_MISC, mr * 24, k_shard_ends, nblocks(mr, BLOCK), (const unsigned long long *)advx, (const unsigned long long *)adv, mr, ye);
+        uint32_t bad = 0; unsigned long long tot = 0;
+        PFP_HIP(c, hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, c->stream));
+        PFP_HIP(c, hipMemcpyAsync(&tot, d_tot, 8, hipMemcpyDeviceToHost, c->stream));
+        PFP_HIP(c, hipStreamSynchronize(c->stream));
+        if (bad || tot != v[r].n + 1 + (uint64_t)w) return PFP_E_CORRUPT;      // Y holds Dollar + (context +) text + w Dollars
+        c->arena.release_hi(mk2);
+        vye[r] = ye; vlast[r] = la;
+    }
     {
         uint64_t goff = 0;
         for (int r = 0; r < nshards; ++r) {
@@ -1139,7 +1174,7 @@ static int merge_shards_impl(pfp_ctx *c, int nshards, const pfp_shard_view *v, p
             }
             const uint32_t cnt = (uint32_t)(ib[r] - ia[r]);
             if (cnt) {
-                PFP_LAUNCH(c, K_MISC, cnt * 24, k_merge_phrases, nblocks(cnt, BLOCK), v[r].d_pid, v[r].d_ye, v[r].d_last, (uint32_t)ib[r], (uint32_t)ia[r], (uint32_t)goff, coff[r], shift[r],
+                PFP_LAUNCH(c, K_MISC, cnt * 24, k_merge_phrases, nblocks(cnt, BLOCK), v[r].d_pid, vye[r], vlast[r], (uint32_t)ib[r], (uint32_t)ia[r], (uint32_t)goff, coff[r], shift[r],
                            (const uint32_t *)cand_id, (tpos_t)0, 0u, 0, c->d_pid, c->d_ye, c->d_last, occw);
                 goff += cnt;
             }
@@ -1219,7 +1254,7 @@ int pfp_parse_bwt(pfp_ctx *c)
     c->arena.release_lo(c->lo_after_parse);
     ArenaGuard g(c);
     const int rc = g.done(parse_bwt_impl(c));
-    if (rc != PFP_OK) { c->stage = 1; c->d_bwlast = nullptr; c->d_ilist = nullptr; c->d_bwsai = nullptr; c->nrows = 0; }
+    if (rc != PFP_OK) { c->stage = 1; c->d_bwlast = nullptr; c->d_ilist = nullptr; c->d_bwsai = nullptr; c->d_bwl_il = nullptr; c->nrows = 0; }
     return rc;
 }
 static int parse_bwt_impl(pfp_ctx *c)
@@ -1233,6 +1268,10 @@ static int parse_bwt_impl(pfp_ctx *c)
     PFP_ALLOC_LO(c, c->d_ilist, uint32_t, N);
     const bool sai = (c->flags & PFP_FLAG_SAI) != 0;
     if (sai) PFP_ALLOC_LO(c, c->d_bwsai, tpos_t, N); else c->d_bwsai = nullptr;
+    PFP_ALLOC_LO(c, c->d_bwl_il, uint8_t, N);
+    uint32_t *d_bad; PFP_ALLOC_HI(c, d_bad, uint32_t, 1);
+    PFP_HIP(c, hipMemsetAsync(d_bad, 0, 4, c->stream));
+    const int pack = N <= (1ULL << BWL_SHIFT) ? 1 : 0;
     PFP_ALLOC_HI(c, SAP, uint32_t, N); PFP_ALLOC_HI(c, rk, uint32_t, N);
     PFP_ALLOC_HI(c, W, uint32_t, N); PFP_ALLOC_HI(c, rowid, uint32_t, N);
     PFP_ALLOC_HI(c, W2, uint32_t, N); PFP_ALLOC_HI(c, rowid2, uint32_t, N);
@@ -1241,13 +1280,16 @@ static int parse_bwt_impl(pfp_ctx *c)
     {
         uint4 *rec; PFP_ALLOC_HI(c, rec, uint4, m);
         PFP_LAUNCH(c, K_PBWT_ROWS, m * 29, k_pbwt_pack, nblocks(m, BLOCK), (const uint32_t *)c->d_parse, (const uint8_t *)c->d_last, sai ? (const tpos_t *)c->d_ye : (const tpos_t *)nullptr, m, rec);
-        PFP_LAUNCH(c, K_PBWT_ROWS, N * (4 + 16 + 17), k_pbwt_rows, nblocks(N, BLOCK), (const uint32_t *)SAP, (const uint4 *)rec, m, c->d_bwlast, c->d_bwsai, W, rowid);
+        PFP_LAUNCH(c, K_PBWT_ROWS, N * (4 + 16 + 17), k_pbwt_rows, nblocks(N, BLOCK), (const uint32_t *)SAP, (const uint4 *)rec, m, c->d_bwlast, c->d_bwsai, W, rowid, pack, d_bad);
     }
     // ilist: rows grouped by word, ascending inside a word (:452-462) = stable sort of row ids by word
     BitRange wr = {0, bits_for(c->dwords)};
     uint32_t *sw, *sr;
     PFP_TRY(radix_sort_pairs<uint32_t>(c, W, rowid, W2, rowid2, N, &wr, 1, &sw, &sr));
-    PFP_HIP(c, hipMemcpyAsync(c->d_ilist, sr, N * 4, hipMemcpyDeviceToDevice, c->stream));
+    uint32_t bad = 0;
+    if (pack) PFP_TRY(d2h_u32(c, d_bad, &bad));
+    if (pack && !bad) PFP_LAUNCH(c, K_PBWT_ROWS, N * 9, k_ilist_split, nblocks(N, BLOCK), (const uint32_t *)sr, N, c->d_ilist, c->d_bwl_il);
+    else PFP_LAUNCH(c, K_PBWT_ROWS, N * 10, k_ilist_gather, nblocks(N, BLOCK), (const uint32_t *)sr, N, pack ? (1u << BWL_SHIFT) - 1u : 0xFFFFFFFFu, (const uint8_t *)c->d_bwlast, c->d_ilist, c->d_bwl_il);
     PFP_HIP(c, hipStreamSynchronize(c->stream));
     c->arena.release_hi(mk);
     c->nrows = N; c->stage = 2;
@@ -1428,9 +1470,15 @@ template <typename SAT, typename EBT> static int emit_and_sample(pfp_ctx *c, Emi
     // group-stationary route of the special rows (k_emit_groups); what it leaves behind is marked for k_emit
     ea.gleft = ea.tile_left = nullptr; ea.group_rows_cap = c->tun.emit_group_rows;
     const uint64_t max_etiles = maxq / EMIT_TILE + 3;
-    if (runaware && ea.group_rows_cap && tot2) {
+    if (runaware && ea.group_rows_cap && tot2 && ea.cinfo) {
         PFP_ALLOC_HI(c, ea.gleft, uint8_t, (size_t)ea.ecount + 1); PFP_ALLOC_HI(c, ea.tile_left, uint8_t, max_etiles);
         PFP_HIP(c, hipMemsetAsync(ea.gleft, 0, (size_t)ea.ecount + 1, c->stream));      // which groups are left is a property of the build, not of a window
+    }
+    ea.lglist = nullptr; ea.lgcount = nullptr; ea.lgcap = 0; ea.qpasses = (bits_for(c->nrows ? c->nrows : 0xFFFFFFFFULL) + 7) / 8;
+    if (ea.gleft) {
+        const uint32_t cap = ea.group_rows_cap < (uint32_t)EG_BUF ? ea.group_rows_cap : (uint32_t)EG_BUF;
+        ea.lgcap = maxq / cap + 2;
+        PFP_ALLOC_HI(c, ea.lglist, uint32_t, 2 * ea.lgcap); PFP_ALLOC_HI(c, ea.lgcount, unsigned long long, 2);
     }
     ea.gstat = nullptr;
     if (ea.gleft && c->tun.verbose) { PFP_ALLOC_HI(c, ea.gstat, unsigned long long, 12); PFP_HIP(c, hipMemsetAsync(ea.gstat, 0, 96, c->stream)); }
@@ -1463,7 +1511,10 @@ template <typename SAT, typename EBT> static int emit_and_sample(pfp_ctx *c, Emi
                 const unsigned ge = (unsigned)((ea.e1 - 1) / EMIT_TILE - ea.e0 / EMIT_TILE + 1);
                 if (ea.gleft) {
                     PFP_HIP(c, hipMemsetAsync(ea.tile_left, 0, (size_t)ge, c->stream));
+                    PFP_HIP(c, hipMemsetAsync(ea.lgcount, 0, 16, c->stream));
                     PFP_LAUNCH(c, K_EMIT, (ea.e1 - ea.e0) * (1 + 4 + (q_at ? 4 : 0)), (k_emit_groups<EBT>), ge, ea, bwt_at, q_at);
+                    PFP_LAUNCH(c, K_EMIT_LARGE, 0, (k_emit_groups_large<EBT, EG1_BUF>), ge < 1024u ? ge : 1024u, ea, bwt_at, q_at);      // the groups too long for a batch, one per workgroup turn
+                    PFP_LAUNCH(c, K_EMIT_LARGE, 0, (k_emit_groups_large<EBT, EG2_BUF>), ge < 512u ? ge : 512u, ea, bwt_at, q_at);
                     PFP_LAUNCH(c, K_EMIT_BIG, 0, (k_emit<SAT, EBT>), ge, ea, bwt_at, (SAT *)nullptr, q_at);      // the groups left over (workgroups of other tiles return at once)
                 } else
                 PFP_LAUNCH(c, K_EMIT, (ea.e1 - ea.e0) * (1 + 4 + (q_at ? 4 : 0)), (k_emit<SAT, EBT>), ge, ea, bwt_at, (SAT *)nullptr, q_at);
@@ -1651,7 +1702,7 @@ template <typename EBT> static int emit_stage(pfp_ctx *c, EmitArgs ea, int want_
         ea.tile_slot = tile_slot;
     }
     // enumeration order of k_emit: every row, or (run-aware) the rows of the special slots through a compacted list of them
-    ea.ENB = EB; ea.etile_slot = ea.tile_slot; ea.elist = nullptr; ea.cpos = nullptr; ea.ecount = (uint32_t)dsize; ea.special = 0; ea.q0 = 0; ea.qspec = nullptr;
+    ea.ENB = EB; ea.etile_slot = ea.tile_slot; ea.elist = nullptr; ea.cpos = nullptr; ea.ecount = (uint32_t)dsize; ea.special = 0; ea.q0 = 0; ea.qspec = nullptr; ea.cinfo = nullptr; ea.cgb = nullptr; ea.town = nullptr;
     uint64_t tot2 = 0;
     if (runaware) {
         uint32_t *flag, *cpos, *spl, *d_cnt;
@@ -1676,6 +1727,15 @@ template <typename EBT> static int emit_stage(pfp_ctx *c, EmitArgs ea, int want_
             ea.etile_slot = et;
         } else PFP_HIP(c, hipMemsetAsync(ENBc, 0, sizeof(EBT), c->stream));
         ea.ENB = ENBc; ea.elist = spl; ea.cpos = cpos; ea.ecount = nsp; ea.special = 1;
+        ea.cinfo = nullptr; ea.cgb = nullptr; ea.town = nullptr;
+        if (nsp && c->tun.emit_group_rows) {      // per special slot / per enumeration tile: what k_emit_groups would otherwise chase through three arrays per batch
+            const uint64_t ntiles2 = (tot2 + EMIT_TILE - 1) / EMIT_TILE;
+            uint4 *cinfo; unsigned long long *cgb; uint32_t *town;
+            PFP_ALLOC_HI(c, cinfo, uint4, nsp); PFP_ALLOC_HI(c, cgb, unsigned long long, nsp); PFP_ALLOC_HI(c, town, uint32_t, ntiles2 + 1);
+            PFP_LAUNCH(c, K_EMIT_COUNT, (uint64_t)nsp * 50, (k_special_pack<EBT>), nblocks(nsp, BLOCK), ea, nsp, cinfo, cgb);
+            PFP_LAUNCH(c, K_EMIT_COUNT, (ntiles2 + 1) * 40, (k_tile_own<EBT>), nblocks(ntiles2 + 1, BLOCK), (const EBT *)ENBc, (const uint4 *)cinfo, (const uint32_t *)ea.etile_slot, (uint64_t)nsp, ntiles2, town);
+            ea.cinfo = cinfo; ea.cgb = cgb; ea.town = town;
+        }
     }
     if (c->tun.verbose) {
         unsigned long long *d_hist, hist[64]; PFP_ALLOC_HI(c, d_hist, unsigned long long, 64);
@@ -1738,7 +1798,7 @@ static int bwt_build_body(pfp_ctx *c, int want_sa, int want_rssa, int slice, int
     EmitArgs ea;
     ea.D = c->d_dict; ea.dsize = dsize; ea.dwords = (uint32_t)dwords; ea.w = c->w;
     ea.SA = c->d_gsa; ea.posinfo = posinfo; ea.ws = c->d_ws; ea.wrank = c->d_wrank;
-    ea.occ = c->d_occ; ea.F = F; ea.ilist = c->d_ilist; ea.bwsai = c->d_bwsai; ea.bwlast = c->d_bwlast;
+    ea.occ = c->d_occ; ea.F = F; ea.ilist = c->d_ilist; ea.bwsai = c->d_bwsai; ea.bwlast = c->d_bwlast; ea.bwl_il = c->d_bwl_il;
     PFP_ALLOC_HI(c, winfo, uint4, dwords);
     PFP_LAUNCH(c, K_MISC, dwords * 32, k_pack_winfo, nblocks(dwords, BLOCK), (const uint32_t *)c->d_ws, (const uint32_t *)c->d_wrank, (const uint32_t *)c->d_occ, (const uint32_t *)F, dwords, winfo);
     ea.winfo = winfo;

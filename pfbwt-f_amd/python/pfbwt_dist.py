@@ -1,6 +1,6 @@
 """Sharded parse across GPUs: one process per GPU, torch.distributed (backend "nccl" = RCCL over
 xGMI; "gloo" in the CPU tests).  Every rank parses a run of whole sequences on its own GPU, the per-rank phrase
-dictionaries and parses travel in ONE all-gather (padded to the largest rank: all_gather needs equal sizes, this is
+dictionaries and phrase-id sequences travel in ONE all-gather (padded to the largest rank: all_gather needs equal sizes, this is
 the all-gather-v of the design); every rank then merges them, sorts the merged dictionary and the parse, and emits
 its own slice of the BWT/SA rows (see sharded_build).
 torch is plumbing here: device buffers + the collective."""
@@ -13,14 +13,16 @@ def _align(x, a=256):
 
 
 def pack_local_shard(ctx, device):
-    """Copy the five device arrays of the finished local parse into one contiguous uint8 tensor."""
+    """Copy the dictionary, the word starts and the phrase ids of the finished local parse into one contiguous uint8 tensor
+    (phrase ends and last bytes do not travel: every phrase is a dictionary word, pfp_merge_shards derives them -- S-32G at 8 ranks:
+    ~290 MB per rank instead of 657 MB)."""
     v = ctx.shard_view()
-    sizes = v.nbytes()
+    sizes = v.nbytes(compact=True)
     offs, tot = [], 0
     for b in sizes:
         offs.append(tot); tot = _align(tot + b)
     buf = torch.empty(max(tot, 256), dtype=torch.uint8, device=device)
-    for off, b, ptr in zip(offs, sizes, (v.d_dict, v.d_ws, v.d_pid, v.d_ye, v.d_last)):
+    for off, b, ptr in zip(offs, sizes, (v.d_dict, v.d_ws, v.d_pid)):
         ctx.device_copy(buf.data_ptr() + off, ptr, b)
     meta = torch.tensor([v.n, v.m, v.dwords, v.dsize, tot, v.left_context], dtype=torch.int64, device=device)
     return buf, meta
@@ -53,9 +55,10 @@ def allgather_shards(ctx, device, group=None):
         n, m, dw, ds, _, lc = (int(x) for x in metas[r])
         v = pfbwt_hip.ShardView(); v.n, v.m, v.dwords, v.dsize, v.left_context = n, m, dw, ds, lc
         off, ptrs = 0, []
-        for b in v.nbytes():
+        for b in v.nbytes(compact=True):
             ptrs.append(recv[r].data_ptr() + off); off = _align(off + b)
-        v.d_dict, v.d_ws, v.d_pid, v.d_ye, v.d_last = ptrs
+        v.d_dict, v.d_ws, v.d_pid = ptrs
+        v.d_ye = v.d_last = None
         views.append(v)
     return views, recv
 

@@ -36,9 +36,10 @@ class ShardView(C.Structure):
                 ("d_dict", C.c_void_p), ("d_ws", C.c_void_p), ("d_pid", C.c_void_p), ("d_ye", C.c_void_p), ("d_last", C.c_void_p),
                 ("left_context", C.c_uint64)]
 
-    def nbytes(self):
-        """byte sizes of the five device arrays, in field order"""
-        return [self.dsize, 4 * (self.dwords + 1), 4 * self.m, 8 * self.m, self.m]
+    def nbytes(self, compact=False):
+        """byte sizes of the device arrays, in field order (compact: dictionary, word starts, phrase ids -- pfp_merge_shards derives
+        the phrase ends and last bytes)"""
+        return [self.dsize, 4 * (self.dwords + 1), 4 * self.m] + ([] if compact else [8 * self.m, self.m])
 
 
 _libs = {}

@@ -20,7 +20,7 @@ def synth(seed, L, H, nruns=(0, 0, 0, 0)):
     return out
 
 
-def sharded_single_process(factory, seqs, shards, w, p, U, mode="context"):
+def sharded_single_process(factory, seqs, shards, w, p, U, mode="context", compact=False):
     """mode: "context" -- shard r > 0 is parsed with the w 'A's of its left neighbour (the multi-GPU convention);
     "standalone" -- every shard is parsed on its own, the merge re-tests the first w windows (PfParser::operator+=, :226-245);
     "loaded" -- every shard is parsed on its own by the ORACLE, saved as .dict / .parse images and loaded (merge_pfp from files)"""
@@ -38,6 +38,8 @@ def sharded_single_process(factory, seqs, shards, w, p, U, mode="context"):
             c.finalize(shard=(len(shards) % 2 == 1))      # both ways: a shard needs no dictionary sort / ranks of its own
         ctxs.append(c); views.append(c.shard_view())
         assert views[-1].left_context == (w if (r > 0 and mode == "context") else 0)
+        if compact:      # what travels between GPUs: dictionary, word starts, phrase ids -- the merge derives phrase ends and last bytes
+            views[-1].d_ye = views[-1].d_last = None
     g = factory(w=w, p=p, u64=(U == 8), sai=True)
     sz = g.merge_shards(views)
     res = {"n": sz.n, "m": sz.m, "dwords": sz.dwords, "dsize": sz.dsize}
@@ -60,6 +62,7 @@ def test_sharded_merge_emu(emu_factory):
     for w, p, shards in ((10, 100, [[0], [1], [2], [3]]), (4, 7, [[0, 1], [2, 3]]), (4, 7, [[0], [1, 2, 3]])):
         ref = oracle_run(seqs, w=w, p=p, U=4)
         assert compare(sharded_single_process(emu_factory, seqs, shards, w, p, 4), ref, 4) == []
+        assert compare(sharded_single_process(emu_factory, seqs, shards, w, p, 4, compact=True), ref, 4) == []
 
 
 def seam_trigger_seqs():
@@ -326,6 +329,7 @@ def test_sharded_merge_gpu(gpu_ctx_factory):
     seqs = synth(10, 60000, 4)
     ref = oracle_run(seqs, w=4, p=7, U=8)
     assert compare(sharded_single_process(gpu_ctx_factory, seqs, [[0], [1, 2], [3]], 4, 7, 8), ref, 8) == []
+    assert compare(sharded_single_process(gpu_ctx_factory, seqs, [[0], [1, 2], [3]], 4, 7, 8, compact=True), ref, 8) == []
 
 
 @pytest.mark.gpu
