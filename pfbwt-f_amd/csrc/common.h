@@ -98,6 +98,7 @@ struct Tunables {
     int force_wide_rows = 0;           // 64-bit row counters on small texts
     uint64_t ingest_block_bytes = 0;   // block size of the file reader (0: 64 MiB)
     uint32_t emit_group_rows = 4096;   // rows per batch of the group-stationary emission of the special rows (0: every special row through k_emit; smaller: more groups left to k_emit)
+    int no_slot_records = 0;           // k_emit_slots by two gathers (word id | preceding byte, then the word record): the route of dictionaries with words of 64 Mbase and more
     uint64_t fasta_chunk_bytes = 0;    // size of the raw-FASTA device buffers (0: 1 MiB ... 256 MiB by the size of the first call)
 };
 

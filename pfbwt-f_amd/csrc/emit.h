@@ -55,6 +55,11 @@ __global__ __launch_bounds__(BLOCK) void k_ilist_split(const uint32_t *packed, u
     const uint32_t v = packed[k];
     ilist[k] = v & ((1u << BWL_SHIFT) - 1u); bwl_il[k] = bwl_byte(v >> BWL_SHIFT);
 }
+__global__ __launch_bounds__(BLOCK) void k_bwsai_by_ilist(const uint32_t *ilist, const tpos_t *bwsai, uint64_t n, tpos_t *out)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (k < n) out[k] = bwsai[ilist[k]];
+}
 __global__ __launch_bounds__(BLOCK) void k_ilist_gather(const uint32_t *packed, uint64_t n, uint32_t mask, const uint8_t *bwlast, uint32_t *ilist, uint8_t *bwl_il)
 {
     const uint64_t k = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -117,10 +122,14 @@ struct EmitArgs {
     const uint8_t *D; uint64_t dsize; uint32_t dwords; int w;
     const uint32_t *SA, *ws, *wrank /*nullable*/, *occ, *F, *ilist;
     const tpos_t *bwsai;    // nullable
-    const uint2 *posinfo;
+    const uint2 *posinfo;   // nullable (only without prec)
+    const uint4 *prec;      // nullable: per dictionary offset { class-head slot, first ilist index of its word, occ of its word, suffix length | code of the preceding byte << 26 | whole word << 30 | inside a word << 31 }
+    const uint32_t *wordid; // per dictionary offset: word id
+    int use_prec;
     const uint4 *winfo;     // per word id: { first byte, offset of its EndOfWord, first ilist index F[rank], occ[rank] }
     const uint8_t *bwlast;
     const uint8_t *bwl_il;  // nullable: bwlast in ilist order
+    const tpos_t *bwsai_il; // nullable: bwsai in ilist order (full SA wanted): a row of a one-member slot then needs no parse row at all
     const void *EB;         // exclusive scan of the per-slot row counts: uint32_t, or uint64_t when n+1 >= 2^32 (template EBT)
     const uint32_t *s_sl;   // per slot: suffix length
     const uint32_t *s_fb;   // per slot: first ilist index of the slot's word (F[rank])
@@ -178,6 +187,35 @@ __global__ __launch_bounds__(BLOCK) void k_pack_posinfo(const uint8_t *D, const 
     posinfo[x] = make_uint2(wordid[x] | (dict_code4(x ? D[x - 1] : 0u) << 28), grank[x].x);
 }
 
+// prec[x]: everything k_emit_slots needs of dictionary offset x in ONE 16-byte record, written in text order (the word record
+// is read once per word there).  A slot then costs one random gather instead of two dependent ones (posinfo[x], then
+// winfo[word of x]) -- on a non-repetitive text (S-3G: 3.4 G slots) that chain was 166 ms.  Suffix lengths must fit 26 bits
+// (words of 64 Mbase and more: the caller keeps the two-gather route).
+constexpr uint32_t PREC_SL_BITS = 26, PREC_FULL = 1u << 30, PREC_VALID = 1u << 31;
+__global__ __launch_bounds__(BLOCK) void k_pack_prec(const uint8_t *D, const uint32_t *wordid, const uint2 *grank, const uint4 *winfo, uint64_t dsize, uint32_t dwords, uint4 *prec)
+{
+    const uint64_t x = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (x >= dsize) return;
+    const uint32_t id = wordid[x];
+    uint4 R = make_uint4(grank[x].x, 0u, 0u, 0u);
+    if (id < dwords) {
+        const uint4 W = winfo[id];
+        uint32_t code = 0, full = 0;
+        if ((uint32_t)x == W.x) full = PREC_FULL;
+        else { code = dict_code4(D[x - 1]); if (code == Dollar && (uint32_t)x - 1u == W.x) code = 0; }      // pfbwt.hpp:132 "gsa[i]-1 ? dict[..] : 0"
+        R.y = W.z; R.z = W.w; R.w = (W.y - (uint32_t)x) | (code << PREC_SL_BITS) | full | PREC_VALID;
+    }
+    prec[x] = R;
+}
+__global__ __launch_bounds__(BLOCK) void k_max_word_length(const uint32_t *ws, uint64_t dwords, uint32_t *out)
+{
+    __shared__ uint32_t red[4];
+    const uint64_t id = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    uint32_t tot;
+    (void)block_incl_max(id < dwords ? ws[id + 1] - ws[id] : 0u, red, &tot);
+    if (threadIdx.x == 0) atomicMax(out, tot);
+}
+
 __device__ __forceinline__ uint32_t word_rank_of(const EmitArgs &a, uint32_t id) { return a.wrank ? a.wrank[id] : id; }
 
 template <typename T> __device__ __forceinline__ uint32_t upper_bound_t(const T *a, uint32_t n, T x)
@@ -199,14 +237,20 @@ template <typename EBT> __global__ __launch_bounds__(BLOCK) void k_emit_slots(Em
     __shared__ uint32_t red[4];
     const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     const bool valid = i < a.dsize;
-    uint32_t x = 0; uint2 P = make_uint2(0, 0);
-    if (valid) { x = a.SA[i]; P = a.posinfo[x]; }
+    uint32_t x = 0; uint2 P = make_uint2(0, 0); uint4 R = make_uint4(0, 0, 0, 0);
+    if (valid) { x = a.SA[i]; if (a.prec) { R = a.prec[x]; P.y = R.x; } else P = a.posinfo[x]; }
     hd[threadIdx.x] = (valid && P.y == (uint32_t)i) ? 1 : 0;
     if (threadIdx.x == 0) {
         const uint64_t nx = (uint64_t)(blockIdx.x + 1) * BLOCK;
         uint8_t h = 1, hp = 0xFF;
         if (nx < a.dsize) {
-            const uint32_t xn = a.SA[nx]; const uint2 Pn = a.posinfo[xn];
+            const uint32_t xn = a.SA[nx];
+            if (a.prec) {
+                const uint4 Rn = a.prec[xn];
+                h = Rn.x == (uint32_t)nx ? 1 : 0;
+                if (!h && (Rn.w & PREC_VALID) && !(Rn.w & PREC_FULL)) hp = dict_byte4((Rn.w >> PREC_SL_BITS) & 15u);
+            } else {
+            const uint2 Pn = a.posinfo[xn];
             h = Pn.y == (uint32_t)nx ? 1 : 0;
             if (!h) {   // the first slot of the next block continues a group of this block: its preceding byte
                 const uint32_t idn = Pn.x & WID_MASK;
@@ -215,12 +259,23 @@ template <typename EBT> __global__ __launch_bounds__(BLOCK) void k_emit_slots(Em
                     if (xn != wsn) { hp = dict_byte4(Pn.x >> 28); if (hp == Dollar && xn - 1 == wsn) hp = 0; }
                 }
             }
+            }
         }
         hd[BLOCK] = h; pcl[BLOCK] = hp;
     }
     __syncthreads();
-    const uint32_t id = P.x & WID_MASK;
     uint32_t c = 0, sl = 0, fb = 0; uint8_t fl = 0, pc = 0;
+    if (a.prec) {
+        if (valid && (R.w & PREC_VALID)) {
+            sl = R.w & ((1u << PREC_SL_BITS) - 1u);
+            if (sl > (uint32_t)a.w) {
+                c = R.z; fb = R.y;
+                if (!hd[threadIdx.x] || (i + 1 < a.dsize && !hd[threadIdx.x + 1])) fl |= SF_MULTI;   // group of >= 2 equal suffixes (pfbwt.hpp:137)
+                if (R.w & PREC_FULL) fl |= SF_FULL; else pc = dict_byte4((R.w >> PREC_SL_BITS) & 15u);
+            }
+        }
+    } else {
+    const uint32_t id = P.x & WID_MASK;
     if (valid && id < a.dwords) {
         const uint4 W = a.winfo[id];
         const uint32_t wsid = W.x;
@@ -231,6 +286,7 @@ template <typename EBT> __global__ __launch_bounds__(BLOCK) void k_emit_slots(Em
             if (x == wsid) fl |= SF_FULL;
             else { pc = dict_byte4(P.x >> 28); if (pc == Dollar && x - 1 == wsid) pc = 0; }   // pfbwt.hpp:132 "gsa[i]-1 ? dict[..] : 0"
         }
+    }
     }
     pcl[threadIdx.x] = (fl & SF_FULL) ? (uint8_t)0xFF : pc;
     __syncthreads();
@@ -415,17 +471,16 @@ template <typename EBT> __device__ __forceinline__ uint64_t plain_group_pos(cons
 // whole-word member contributes dict[gsa-1] == EndOfWord as its BWT byte (:140).
 template <typename EBT> __device__ __forceinline__ uint64_t multi_group_pos(const EmitArgs &a, uint32_t i, uint32_t r, uint32_t q, bool self_full, bool *full_emits_eow)
 {
-    const uint2 P = a.posinfo[a.SA[i]];
-    const uint32_t g0 = P.y;
-    const uint32_t rk = word_rank_of(a, P.x & WID_MASK);
+    const uint32_t g0 = a.s_g0[i];                          // head slot and word of a slot: per-slot array of k_emit_slots, per-offset word ids
+    const uint32_t idi = a.wordid[a.SA[i]];
+    const uint32_t rk = word_rank_of(a, idi);
     uint64_t before = 0;
-    uint32_t first_rk = rk, first_before = 0, first_occ = a.winfo[P.x & WID_MASK].w; bool first_full = self_full;
+    uint32_t first_rk = rk, first_before = 0, first_occ = a.winfo[idi].w; bool first_full = self_full;
     for (uint32_t s = g0; s < a.dsize; ++s) {
-        const uint32_t xs = a.SA[s];
-        const uint2 Ps = a.posinfo[xs];
-        if (Ps.y != g0) break;
+        if (a.s_g0[s] != g0) break;
         if (s == i) continue;
-        const uint32_t ids = Ps.x & WID_MASK;
+        const uint32_t xs = a.SA[s];
+        const uint32_t ids = a.wordid[xs];
         const uint32_t rs = word_rank_of(a, ids);
         const uint4 Ws = a.winfo[ids];
         const uint32_t oc = Ws.w;
@@ -557,10 +612,16 @@ template <typename SAT, typename EBT> __global__ __launch_bounds__(BLOCK) void k
                 if (on[u] && !a.gleft[jh]) on[u] = false;
             }
         }
+        // parse-BWT row of this occurrence -- a random 4-byte read, skipped where nothing asks for it: with bwsai / bwlast in ilist
+        // order (bwsai_il, bwl_il) the rows of one-member slots (nearly all rows of a non-repetitive text) take their SA value and
+        // their whole-word byte from the list position itself
 #pragma unroll
-        for (int u = 0; u < EMIT_ROWS_IN_FLIGHT; ++u) q[u] = a.ilist[S[u].x + r[u]];                   // parse-BWT row of this occurrence
+        for (int u = 0; u < EMIT_ROWS_IN_FLIGHT; ++u) {
+            const bool needq = (fl[u] & SF_MULTI) || qrow || ((fl[u] & SF_FULL) && !a.bwl_il) || (sa && !a.bwsai_il);
+            q[u] = needq ? a.ilist[S[u].x + r[u]] : 0u;
+        }
 #pragma unroll
-        for (int u = 0; u < EMIT_ROWS_IN_FLIGHT; ++u) sv[u] = (sa && on[u] && !(fl[u] & SF_BIG)) ? a.bwsai[q[u]] : 0ULL;
+        for (int u = 0; u < EMIT_ROWS_IN_FLIGHT; ++u) sv[u] = (sa && on[u] && !(fl[u] & SF_BIG)) ? (a.bwsai_il ? (uint64_t)a.bwsai_il[S[u].x + r[u]] : (uint64_t)a.bwsai[q[u]]) : 0ULL;
         // rows in ordinary multi-member groups: the bisections of all rows in flight run in one loop (EMIT_RANK_W lists per
         // row at a time), so that a thread has EMIT_ROWS_IN_FLIGHT * EMIT_RANK_W dependent-load chains going instead of one
         uint32_t before[EMIT_ROWS_IN_FLIGHT], gk_[EMIT_ROWS_IN_FLIGHT], maxk = 0;
@@ -611,7 +672,7 @@ template <typename SAT, typename EBT> __global__ __launch_bounds__(BLOCK) void k
             else if (fl[u] & SF_MULTI) { pos = (uint64_t)EB[S[u].z] + before[u] + r[u]; g = S[u].z; }
             else if (a.special) pos = (uint64_t)EB[i[u]] + r[u];
             if (a.special && qrow) qrow[(uint64_t)ENB[a.cpos[g]] - a.q0 + (pos - (uint64_t)EB[g])] = q[u];   // every enumerated row, also outside the window
-            const uint8_t c = self_full ? (full_emits_eow ? (uint8_t)EndOfWord : a.bwlast[q[u]]) : a.s_pc[i[u]];   // pfbwt.hpp:116-128 / :132
+            const uint8_t c = self_full ? (full_emits_eow ? (uint8_t)EndOfWord : a.bwl_il ? a.bwl_il[S[u].x + r[u]] : a.bwlast[q[u]]) : a.s_pc[i[u]];   // pfbwt.hpp:116-128 / :132
             if (pos < a.w0 || pos >= a.w1) continue;                    // row of a boundary group that lands in another slice
             bwt[pos - a.w0] = c;
             if (sa) {
@@ -899,13 +960,13 @@ template <typename EBT> __global__ __launch_bounds__(BLOCK) void k_slice_bounds(
     const EBT *EB = reinterpret_cast<const EBT *>(a.EB);
     const EBT *ENB = reinterpret_cast<const EBT *>(a.ENB);
     const uint32_t il = slot_of_row<EBT>(a, lo);
-    const uint32_t gh = a.posinfo[a.SA[il]].y;
+    const uint32_t gh = a.s_g0[il];
     out[0] = EB[gh];
     out[2] = a.special ? (unsigned long long)ENB[a.cpos[gh]] : 0ULL;      // the same range in the enumeration of the special rows
     if (hi >= a.nout) { out[1] = a.nout; out[3] = a.special ? (unsigned long long)ENB[a.ecount] : 0ULL; return; }
     uint32_t s = slot_of_row<EBT>(a, hi - 1);
-    const uint32_t g = a.posinfo[a.SA[s]].y;
-    while (s < a.dsize && a.posinfo[a.SA[s]].y == g) ++s;
+    const uint32_t g = a.s_g0[s];
+    while (s < a.dsize && a.s_g0[s] == g) ++s;
     {   // first slot at or behind s whose rows start at or behind hi: EB never decreases (slots that produce no rows -- dictionary
         // suffixes of length <= w come in clusters of millions -- repeat the next one's value), so this is a bisection, not a walk
         uint64_t lo_ = s, hi_ = a.dsize;

@@ -88,7 +88,7 @@ static void reset_results(pfp_ctx *c)
 
 // ---- route / tuning switches (pfbwt_hip_dev.h) -----------------------------------------------------
 static const char *const tunable_names[] = {"verbose", "seg_grid", "seg_stage", "sort_k", "sort_no_table", "class_sort_maxrange", "dedup_table_log2", "no_trigger_table",
-                                            "emit_chunk_rows", "fill_subs", "sample_cap", "no_runaware", "big_group_members", "force_wide_rows", "fasta_chunk_bytes", "ingest_block_bytes", "emit_group_rows"};
+                                            "emit_chunk_rows", "fill_subs", "sample_cap", "no_runaware", "big_group_members", "force_wide_rows", "fasta_chunk_bytes", "ingest_block_bytes", "emit_group_rows", "no_slot_records"};
 static int set_tunable(pfp_ctx *c, const char *key, long long v)
 {
     Tunables &t = c->tun;
@@ -109,6 +109,7 @@ static int set_tunable(pfp_ctx *c, const char *key, long long v)
     else if (!strcmp(key, "fasta_chunk_bytes")) t.fasta_chunk_bytes = v > 0 ? (uint64_t)v : 0;
     else if (!strcmp(key, "ingest_block_bytes")) t.ingest_block_bytes = v > 0 ? (uint64_t)v : 0;
     else if (!strcmp(key, "emit_group_rows")) t.emit_group_rows = v > 0 ? (uint32_t)v : 0u;
+    else if (!strcmp(key, "no_slot_records")) t.no_slot_records = (int)v;
     else return PFP_E_ARG;
     return PFP_OK;
 }
@@ -1437,6 +1438,12 @@ template <typename SAT, typename EBT> static int emit_and_sample(pfp_ctx *c, Emi
     const bool keep_sa = want_sa;                          // a full SA array for this slice lives in the arena
     SAT *sabuf = nullptr;
     if (keep_sa) PFP_ALLOC_LO(c, sabuf, SAT, nrows + lead);
+    ea.bwsai_il = nullptr;
+    if (keep_sa && c->d_bwsai && c->nrows) {      // bwsai in ilist order: one gather per parse row here instead of a second dependent gather per OUTPUT row
+        tpos_t *E; PFP_ALLOC_HI(c, E, tpos_t, c->nrows);
+        PFP_LAUNCH(c, K_MISC, c->nrows * 20, k_bwsai_by_ilist, nblocks(c->nrows, BLOCK), (const uint32_t *)c->d_ilist, (const tpos_t *)c->d_bwsai, c->nrows, E);
+        ea.bwsai_il = E;
+    }
     c->d_sa = sabuf ? sabuf + lead : nullptr;
     c->d_ssa = c->d_esa = nullptr;
     unsigned long long *d_b; PFP_ALLOC_HI(c, d_b, unsigned long long, 6);
@@ -1684,8 +1691,24 @@ template <typename EBT> static int emit_stage(pfp_ctx *c, EmitArgs ea, int want_
         PFP_HIP(c, hipMemsetAsync(gql, 0, dsize * 4, c->stream));
     }
     ea.s_g0 = s_g0; ea.gk = gk; ea.cnt = cnt; ea.gqf = gqf; ea.gql = gql;
+    {   // per dictionary offset, for k_emit_slots only: ONE 16-byte record (suffix lengths must fit 26 bits), else word id | preceding
+        // byte + class head and a second gather of the word record.  The array lives only for that kernel: what is allocated behind
+        // it (the 16-byte per-slot records of the row kernels) takes its place -- same stream, so the reuse is ordered
+        const size_t mkp = c->arena.mark_hi();
+        if (ea.use_prec) {
+            uint4 *prec; PFP_ALLOC_HI(c, prec, uint4, dsize);
+            PFP_LAUNCH(c, K_EMIT_COUNT, dsize * 29, k_pack_prec, nblocks(dsize, BLOCK), ea.D, ea.wordid, (const uint2 *)c->d_grank, ea.winfo, dsize, ea.dwords, prec);
+            ea.prec = prec;
+        } else {
+            uint2 *posinfo; PFP_ALLOC_HI(c, posinfo, uint2, dsize);
+            PFP_LAUNCH(c, K_EMIT_COUNT, dsize * 17, k_pack_posinfo, nblocks(dsize, BLOCK), ea.D, ea.wordid, (const uint2 *)c->d_grank, dsize, posinfo);
+            ea.posinfo = posinfo;
+        }
+        PFP_LAUNCH(c, K_EMIT_COUNT, dsize * (30 + sizeof(EBT)), (k_emit_slots<EBT>), nblocks(dsize, BLOCK), ea, cnt, d_hard, (uint32_t *)ea.s_sl, (uint32_t *)ea.s_fb, (uint8_t *)ea.s_fl, (uint8_t *)ea.s_pc, s_g0, gk, gfl, gnu);
+        c->arena.release_hi(mkp);
+        ea.prec = nullptr; ea.posinfo = nullptr;
+    }
     uint4 *sinfo; PFP_ALLOC_HI(c, sinfo, uint4, dsize); ea.sinfo = sinfo;
-    PFP_LAUNCH(c, K_EMIT_COUNT, dsize * (30 + sizeof(EBT)), (k_emit_slots<EBT>), nblocks(dsize, BLOCK), ea, cnt, d_hard, (uint32_t *)ea.s_sl, (uint32_t *)ea.s_fb, (uint8_t *)ea.s_fl, (uint8_t *)ea.s_pc, s_g0, gk, gfl, gnu);
     const long big_members = c->tun.big_group_members == -2 ? (long)BIG_GROUP_MEMBERS : c->tun.big_group_members;   // < 0: never
     PFP_LAUNCH(c, K_EMIT_COUNT, dsize * 14, (k_big_mark<EBT>), nblocks(dsize, BLOCK), (const EBT *)cnt, (const uint32_t *)s_g0, (const uint32_t *)gk, (const uint8_t *)gfl, (const uint8_t *)gnu, (const uint32_t *)ea.s_fb, ea.ilist, dsize,
                big_members >= 0 ? (uint32_t)big_members : 0xFFFFFFFFu, runaware ? 1 : 0, (uint8_t *)ea.s_fl, sinfo, cnt2, gqf, gql, d_hard + 1);
@@ -1785,10 +1808,8 @@ static int bwt_build_body(pfp_ctx *c, int want_sa, int want_rssa, int slice, int
     const size_t mk = c->arena.mark_hi();
     c->emit_scratch_mark = mk;
     const uint64_t dsize = c->dsize, dwords = c->dwords;
-    uint32_t *F, *s_sl, *s_fb; uint8_t *s_fl, *s_pc; uint2 *posinfo; uint4 *winfo;
+    uint32_t *F, *s_sl, *s_fb; uint8_t *s_fl, *s_pc; uint4 *winfo;
     if (dwords > WID_MASK) return PFP_E_TOO_LARGE;
-    PFP_ALLOC_HI(c, posinfo, uint2, dsize);
-    PFP_LAUNCH(c, K_EMIT_COUNT, dsize * 17, k_pack_posinfo, nblocks(dsize, BLOCK), (const uint8_t *)c->d_dict, (const uint32_t *)c->d_wordid, (const uint2 *)c->d_grank, dsize, posinfo);
     PFP_ALLOC_HI(c, F, uint32_t, dwords + 1);
     PFP_ALLOC_HI(c, s_sl, uint32_t, dsize); PFP_ALLOC_HI(c, s_fb, uint32_t, dsize);
     PFP_ALLOC_HI(c, s_fl, uint8_t, dsize); PFP_ALLOC_HI(c, s_pc, uint8_t, dsize);
@@ -1797,11 +1818,20 @@ static int bwt_build_body(pfp_ctx *c, int want_sa, int want_rssa, int slice, int
     PFP_LAUNCH(c, K_MISC, dwords * 8, k_u32_add_store, nblocks(dwords, BLOCK), (const uint32_t *)F, dwords, 1u, F);
     EmitArgs ea;
     ea.D = c->d_dict; ea.dsize = dsize; ea.dwords = (uint32_t)dwords; ea.w = c->w;
-    ea.SA = c->d_gsa; ea.posinfo = posinfo; ea.ws = c->d_ws; ea.wrank = c->d_wrank;
+    ea.SA = c->d_gsa; ea.ws = c->d_ws; ea.wrank = c->d_wrank;
     ea.occ = c->d_occ; ea.F = F; ea.ilist = c->d_ilist; ea.bwsai = c->d_bwsai; ea.bwlast = c->d_bwlast; ea.bwl_il = c->d_bwl_il;
     PFP_ALLOC_HI(c, winfo, uint4, dwords);
     PFP_LAUNCH(c, K_MISC, dwords * 32, k_pack_winfo, nblocks(dwords, BLOCK), (const uint32_t *)c->d_ws, (const uint32_t *)c->d_wrank, (const uint32_t *)c->d_occ, (const uint32_t *)F, dwords, winfo);
     ea.winfo = winfo;
+    // per dictionary offset: one 16-byte record for k_emit_slots (suffix lengths must fit 26 bits), else word id | preceding byte + class head
+    uint32_t maxlen = 0;
+    {
+        uint32_t *d_ml; PFP_ALLOC_HI(c, d_ml, uint32_t, 1);
+        PFP_HIP(c, hipMemsetAsync(d_ml, 0, 4, c->stream));
+        PFP_LAUNCH(c, K_MISC, dwords * 4, k_max_word_length, nblocks(dwords, BLOCK), (const uint32_t *)c->d_ws, dwords, d_ml);
+        PFP_TRY(d2h_u32(c, d_ml, &maxlen));
+    }
+    ea.posinfo = nullptr; ea.prec = nullptr; ea.wordid = c->d_wordid; ea.use_prec = (maxlen < (1u << PREC_SL_BITS) && !c->tun.no_slot_records) ? 1 : 0;
     ea.EB = nullptr; ea.s_sl = s_sl; ea.s_fb = s_fb; ea.s_fl = s_fl; ea.s_pc = s_pc; ea.nout = 0; ea.n = 0; ea.e0 = ea.e1 = ea.w0 = ea.w1 = 0;
     c->have_sa = want_sa != 0; c->have_rssa = want_rssa != 0;
     // 64-bit row counters when the text may have 2^32 - 1 positions or more (n unknown after pfp_bwt_load without a hint)
