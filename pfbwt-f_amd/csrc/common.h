@@ -98,6 +98,7 @@ struct Tunables {
     int force_wide_rows = 0;           // 64-bit row counters on small texts
     uint64_t ingest_block_bytes = 0;   // block size of the file reader (0: 64 MiB)
     uint32_t emit_group_rows = 4096;   // rows per batch of the group-stationary emission of the special rows (0: every special row through k_emit; smaller: more groups left to k_emit)
+    int dict_text_rounds = -1;         // dictionary suffix sort by text rounds: -1 = when the collection is not repetitive (dictionary > text / 8), 0 never, 1 always
     int no_slot_records = 0;           // k_emit_slots by two gathers (word id | preceding byte, then the word record): the route of dictionaries with words of 64 Mbase and more
     uint64_t fasta_chunk_bytes = 0;    // size of the raw-FASTA device buffers (0: 1 MiB ... 256 MiB by the size of the first call)
 };
@@ -130,6 +131,8 @@ struct pfp_ctx {
     uint32_t *d_occ = nullptr;      // dwords, by rank
     uint8_t *d_sdict = nullptr;     // sorted .dict image (dsize), by rank
     uint32_t *d_gsa = nullptr;      // dsize: suffix array of D'
+    uint8_t *d_sflag = nullptr;     // dsize (text-round sort only): per slot, 1 = the suffix there starts a word
+    uint32_t *d_srank = nullptr;    // dsize: per suffix-array SLOT, the first slot of its class of equal suffixes
     uint2 *d_grank = nullptr;       // dsize: { class-head slot, covered-prefix end } of each D' offset (sufsort.h)
     bool gsa_valid = false;
     // --- parse-BWT results

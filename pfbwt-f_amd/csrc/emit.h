@@ -90,6 +90,21 @@ __global__ __launch_bounds__(BLOCK) void k_word_rank(const uint32_t *sorted_ids,
     const uint32_t id = sorted_ids[r];
     wrank[id] = (uint32_t)r; idofrank[r] = id; occ[r] = occw[id];
 }
+__global__ __launch_bounds__(BLOCK) void k_flags_u8_to_u32(const uint8_t *f, uint64_t n, uint32_t *out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) out[i] = f[i] ? 1u : 0u;
+}
+// word ranks from the word-start flags of the slots (text-round dictionary sort): the r-th flagged slot holds the word of rank r
+__global__ __launch_bounds__(BLOCK) void k_word_rank_flags(const uint8_t *sflag, const uint32_t *fpos, const uint32_t *SA, const uint32_t *wordid, uint64_t dsize, uint32_t dwords,
+                                                         const uint32_t *occw, uint32_t *wrank, uint32_t *idofrank, uint32_t *occ)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= dsize || !sflag[i]) return;
+    const uint32_t r = fpos[i], id = wordid[SA[i]];
+    if (r >= dwords || id >= dwords) return;
+    wrank[id] = r; idofrank[r] = id; occ[r] = occw[id];
+}
 __global__ __launch_bounds__(BLOCK) void k_parse_ranks(const uint32_t *pid, const uint32_t *wrank, uint64_t m, uint32_t *parse)
 {
     const uint64_t j = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -121,9 +136,10 @@ __global__ __launch_bounds__(BLOCK) void k_ws_from_flags(const uint8_t *D, uint6
 struct EmitArgs {
     const uint8_t *D; uint64_t dsize; uint32_t dwords; int w;
     const uint32_t *SA, *ws, *wrank /*nullable*/, *occ, *F, *ilist;
+    const uint32_t *srank;  // per slot: first slot of its class of equal suffixes (kept by the dictionary suffix sort)
     const tpos_t *bwsai;    // nullable
     const uint2 *posinfo;   // nullable (only without prec)
-    const uint4 *prec;      // nullable: per dictionary offset { class-head slot, first ilist index of its word, occ of its word, suffix length | code of the preceding byte << 26 | whole word << 30 | inside a word << 31 }
+    const uint4 *prec;      // nullable: per dictionary offset { unused, first ilist index of its word, occ of its word, suffix length | code of the preceding byte << 26 | whole word << 30 | inside a word << 31 }
     const uint32_t *wordid; // per dictionary offset: word id
     int use_prec;
     const uint4 *winfo;     // per word id: { first byte, offset of its EndOfWord, first ilist index F[rank], occ[rank] }
@@ -180,11 +196,11 @@ __global__ __launch_bounds__(BLOCK) void k_pack_winfo(const uint32_t *ws, const 
     const uint32_t rk = wrank ? wrank[id] : (uint32_t)id;
     winfo[id] = make_uint4(ws[id], ws[id + 1] - 1u, F[rk], occ[rk]);
 }
-__global__ __launch_bounds__(BLOCK) void k_pack_posinfo(const uint8_t *D, const uint32_t *wordid, const uint2 *grank, uint64_t dsize, uint2 *posinfo)
+__global__ __launch_bounds__(BLOCK) void k_pack_posinfo(const uint8_t *D, const uint32_t *wordid, uint64_t dsize, uint2 *posinfo)
 {
     const uint64_t x = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (x >= dsize) return;
-    posinfo[x] = make_uint2(wordid[x] | (dict_code4(x ? D[x - 1] : 0u) << 28), grank[x].x);
+    posinfo[x] = make_uint2(wordid[x] | (dict_code4(x ? D[x - 1] : 0u) << 28), 0u);
 }
 
 // prec[x]: everything k_emit_slots needs of dictionary offset x in ONE 16-byte record, written in text order (the word record
@@ -192,12 +208,12 @@ __global__ __launch_bounds__(BLOCK) void k_pack_posinfo(const uint8_t *D, const 
 // winfo[word of x]) -- on a non-repetitive text (S-3G: 3.4 G slots) that chain was 166 ms.  Suffix lengths must fit 26 bits
 // (words of 64 Mbase and more: the caller keeps the two-gather route).
 constexpr uint32_t PREC_SL_BITS = 26, PREC_FULL = 1u << 30, PREC_VALID = 1u << 31;
-__global__ __launch_bounds__(BLOCK) void k_pack_prec(const uint8_t *D, const uint32_t *wordid, const uint2 *grank, const uint4 *winfo, uint64_t dsize, uint32_t dwords, uint4 *prec)
+__global__ __launch_bounds__(BLOCK) void k_pack_prec(const uint8_t *D, const uint32_t *wordid, const uint4 *winfo, uint64_t dsize, uint32_t dwords, uint4 *prec)
 {
     const uint64_t x = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (x >= dsize) return;
     const uint32_t id = wordid[x];
-    uint4 R = make_uint4(grank[x].x, 0u, 0u, 0u);
+    uint4 R = make_uint4(0u, 0u, 0u, 0u);
     if (id < dwords) {
         const uint4 W = winfo[id];
         uint32_t code = 0, full = 0;
@@ -238,7 +254,7 @@ template <typename EBT> __global__ __launch_bounds__(BLOCK) void k_emit_slots(Em
     const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     const bool valid = i < a.dsize;
     uint32_t x = 0; uint2 P = make_uint2(0, 0); uint4 R = make_uint4(0, 0, 0, 0);
-    if (valid) { x = a.SA[i]; if (a.prec) { R = a.prec[x]; P.y = R.x; } else P = a.posinfo[x]; }
+    if (valid) { x = a.SA[i]; if (a.prec) R = a.prec[x]; else P = a.posinfo[x]; P.y = a.srank[i]; }
     hd[threadIdx.x] = (valid && P.y == (uint32_t)i) ? 1 : 0;
     if (threadIdx.x == 0) {
         const uint64_t nx = (uint64_t)(blockIdx.x + 1) * BLOCK;
@@ -247,11 +263,11 @@ template <typename EBT> __global__ __launch_bounds__(BLOCK) void k_emit_slots(Em
             const uint32_t xn = a.SA[nx];
             if (a.prec) {
                 const uint4 Rn = a.prec[xn];
-                h = Rn.x == (uint32_t)nx ? 1 : 0;
+                h = a.srank[nx] == (uint32_t)nx ? 1 : 0;
                 if (!h && (Rn.w & PREC_VALID) && !(Rn.w & PREC_FULL)) hp = dict_byte4((Rn.w >> PREC_SL_BITS) & 15u);
             } else {
             const uint2 Pn = a.posinfo[xn];
-            h = Pn.y == (uint32_t)nx ? 1 : 0;
+            h = a.srank[nx] == (uint32_t)nx ? 1 : 0;
             if (!h) {   // the first slot of the next block continues a group of this block: its preceding byte
                 const uint32_t idn = Pn.x & WID_MASK;
                 if (idn < a.dwords) {

@@ -81,14 +81,14 @@ static void reset_results(pfp_ctx *c)
     c->d_bwlast = nullptr; c->d_ilist = nullptr; c->d_bwsai = nullptr; c->d_bwl_il = nullptr;
     c->d_ma = nullptr; c->ma_words = 0; c->ma_lo_mark = (size_t)-1;
     c->d_ye = nullptr; c->d_pid = nullptr; c->d_parse = nullptr; c->d_last = nullptr; c->d_dict = nullptr; c->d_ws = nullptr; c->d_wordid = nullptr;
-    c->d_occ = nullptr; c->d_sdict = nullptr; c->d_gsa = nullptr; c->d_grank = nullptr;
+    c->d_occ = nullptr; c->d_sdict = nullptr; c->d_gsa = nullptr; c->d_grank = nullptr; c->d_srank = nullptr; c->d_sflag = nullptr;
     c->arena.reset();
     c->fa.started = false; c->fa.state = 2; c->fa.records = 0; c->fa.rec_raw.clear(); c->fa.rec_pos.clear();
 }
 
 // ---- route / tuning switches (pfbwt_hip_dev.h) -----------------------------------------------------
 static const char *const tunable_names[] = {"verbose", "seg_grid", "seg_stage", "sort_k", "sort_no_table", "class_sort_maxrange", "dedup_table_log2", "no_trigger_table",
-                                            "emit_chunk_rows", "fill_subs", "sample_cap", "no_runaware", "big_group_members", "force_wide_rows", "fasta_chunk_bytes", "ingest_block_bytes", "emit_group_rows", "no_slot_records"};
+                                            "emit_chunk_rows", "fill_subs", "sample_cap", "no_runaware", "big_group_members", "force_wide_rows", "fasta_chunk_bytes", "ingest_block_bytes", "emit_group_rows", "no_slot_records", "dict_text_rounds"};
 static int set_tunable(pfp_ctx *c, const char *key, long long v)
 {
     Tunables &t = c->tun;
@@ -110,6 +110,7 @@ static int set_tunable(pfp_ctx *c, const char *key, long long v)
     else if (!strcmp(key, "ingest_block_bytes")) t.ingest_block_bytes = v > 0 ? (uint64_t)v : 0;
     else if (!strcmp(key, "emit_group_rows")) t.emit_group_rows = v > 0 ? (uint32_t)v : 0u;
     else if (!strcmp(key, "no_slot_records")) t.no_slot_records = (int)v;
+    else if (!strcmp(key, "dict_text_rounds")) t.dict_text_rounds = (int)v;
     else return PFP_E_ARG;
     return PFP_OK;
 }
@@ -614,13 +615,32 @@ static int sort_dict_suffixes(pfp_ctx *c)
     const size_t mk = c->arena.mark_hi();
     uint64_t *k0, *k1; uint32_t *v0, *v1;
     PFP_ALLOC_LO(c, c->d_gsa, uint32_t, N);
-    PFP_ALLOC_LO(c, c->d_grank, uint2, N);
+    PFP_ALLOC_LO(c, c->d_srank, uint32_t, N);
+    const size_t lo_state = c->arena.mark_lo();
     PFP_ALLOC_HI(c, k0, uint64_t, N); PFP_ALLOC_HI(c, k1, uint64_t, N);
     PFP_ALLOC_HI(c, v0, uint32_t, N); PFP_ALLOC_HI(c, v1, uint32_t, N);
-    PFP_LAUNCH(c, K_SS_INIT_KEYS, N * 13, k_dict_init_keys, nblocks(N, DK_TILE), (const uint8_t *)c->d_dict, N, k0, v0);
     BitRange full = {0, DK_KEY_BITS};
     int rounds = 0;
-    PFP_TRY(suffix_sort_doubling<true>(c, N, k0, v0, k1, v1, &full, 1, DK_CHARS, c->d_dict, c->d_gsa, (uint32_t *)nullptr, c->d_grank, &rounds));
+    // A collection that is not repetitive has a dictionary about as large as its text whose suffixes are told apart by their first
+    // few dozen characters: the rounds then read the text itself (sufsort.h, text rounds) and no per-offset rank array exists -- the
+    // emission takes the class heads per SLOT (d_srank), the word ranks come from the word-start flags that travel with the
+    // suffixes (d_sflag).  A repetitive collection (pangenome: dictionary << text, variant words share long prefixes) keeps the
+    // rank-based rounds, whose covered prefix doubles / quadruples; so does a dictionary on which the text rounds are given up.
+    const int want = c->tun.dict_text_rounds;
+    bool text_mode = want > 0 || (want < 0 && c->n != 0 && N > c->n / 8);
+    if (text_mode) {
+        PFP_ALLOC_LO(c, c->d_sflag, uint8_t, N);
+        c->d_grank = nullptr;
+        PFP_LAUNCH(c, K_SS_INIT_KEYS, N * 13, k_dict_init_keys, nblocks(N, DK_TILE), (const uint8_t *)c->d_dict, N, k0, v0);
+        int conv = 1;
+        PFP_TRY(suffix_sort_doubling<true>(c, N, k0, v0, k1, v1, &full, 1, DK_CHARS, c->d_dict, c->d_gsa, (uint32_t *)nullptr, (uint2 *)nullptr, &rounds, 9, c->d_srank, c->d_sflag, 1, &conv));
+        if (!conv) { text_mode = false; c->d_sflag = nullptr; c->arena.release_lo(lo_state); }
+    }
+    if (!text_mode) {
+        PFP_ALLOC_LO(c, c->d_grank, uint2, N);
+        PFP_LAUNCH(c, K_SS_INIT_KEYS, N * 13, k_dict_init_keys, nblocks(N, DK_TILE), (const uint8_t *)c->d_dict, N, k0, v0);
+        PFP_TRY(suffix_sort_doubling<true>(c, N, k0, v0, k1, v1, &full, 1, DK_CHARS, c->d_dict, c->d_gsa, (uint32_t *)nullptr, c->d_grank, &rounds, 9, c->d_srank));
+    }
     c->arena.release_hi(mk);
     c->gsa_valid = true;
     return PFP_OK;
@@ -730,12 +750,25 @@ static int finish_parse(pfp_ctx *c, const uint32_t *occw)
     PFP_ALLOC_LO(c, c->d_occ, uint32_t, dwords);
     PFP_ALLOC_LO(c, c->d_parse, uint32_t, m + 1);
     PFP_ALLOC_LO(c, c->d_sdict, uint8_t, dsize + 16);
-    {
+    if (c->d_grank) {
         PFP_LAUNCH(c, K_WORD_RANK, dwords * 16, k_wordstart_keys, gd, (const uint32_t *)c->d_ws, (const uint2 *)c->d_grank, dwords, wk0, wv0);
         BitRange br = {0, bits_for(dsize)};
         uint32_t *sk32, *sv32;
         PFP_TRY(radix_sort_pairs<uint32_t>(c, wk0, wv0, wk1, wv1, dwords, &br, 1, &sk32, &sv32));
         PFP_LAUNCH(c, K_WORD_RANK, dwords * 20, k_word_rank, gd, (const uint32_t *)sv32, dwords, occw, c->d_wrank, idofrank, c->d_occ);
+    } else {
+        // text-round sort: the suffixes that start a word carry a flag to their slots; in slot order they ARE the words in
+        // lexicographic order (two distinct words are never byte-identical), so their word ids, compacted, are the ids by rank
+        const size_t mkf = c->arena.mark_hi();
+        uint32_t *fl32, *fpos, *d_cnt;
+        PFP_ALLOC_HI(c, fl32, uint32_t, dsize); PFP_ALLOC_HI(c, fpos, uint32_t, dsize); PFP_ALLOC_HI(c, d_cnt, uint32_t, 1);
+        PFP_LAUNCH(c, K_WORD_RANK, dsize * 5, k_flags_u8_to_u32, nblocks(dsize, BLOCK), (const uint8_t *)c->d_sflag, dsize, fl32);
+        PFP_TRY((device_scan<uint32_t, 0>(c, fl32, fpos, dsize, d_cnt)));
+        uint32_t nst = 0; PFP_TRY(d2h_u32(c, d_cnt, &nst));
+        if (nst != dwords) return PFP_E_CORRUPT;
+        PFP_LAUNCH(c, K_WORD_RANK, dsize * 9 + dwords * 24, k_word_rank_flags, nblocks(dsize, BLOCK), (const uint8_t *)c->d_sflag, (const uint32_t *)fpos, (const uint32_t *)c->d_gsa, (const uint32_t *)c->d_wordid, dsize, (uint32_t)dwords,
+                   occw, c->d_wrank, idofrank, c->d_occ);
+        c->arena.release_hi(mkf);
     }
     PFP_LAUNCH(c, K_PARSE_RANKS, m * 12, k_parse_ranks, gm, (const uint32_t *)c->d_pid, (const uint32_t *)c->d_wrank, m, c->d_parse);
     PFP_LAUNCH(c, K_DICT_SORTED, dwords * 12, k_sorted_lengths, gd, (const uint32_t *)c->d_ws, (const uint32_t *)idofrank, dwords, len1, srcstart);
@@ -1697,11 +1730,11 @@ template <typename EBT> static int emit_stage(pfp_ctx *c, EmitArgs ea, int want_
         const size_t mkp = c->arena.mark_hi();
         if (ea.use_prec) {
             uint4 *prec; PFP_ALLOC_HI(c, prec, uint4, dsize);
-            PFP_LAUNCH(c, K_EMIT_COUNT, dsize * 29, k_pack_prec, nblocks(dsize, BLOCK), ea.D, ea.wordid, (const uint2 *)c->d_grank, ea.winfo, dsize, ea.dwords, prec);
+            PFP_LAUNCH(c, K_EMIT_COUNT, dsize * 29, k_pack_prec, nblocks(dsize, BLOCK), ea.D, ea.wordid, ea.winfo, dsize, ea.dwords, prec);
             ea.prec = prec;
         } else {
             uint2 *posinfo; PFP_ALLOC_HI(c, posinfo, uint2, dsize);
-            PFP_LAUNCH(c, K_EMIT_COUNT, dsize * 17, k_pack_posinfo, nblocks(dsize, BLOCK), ea.D, ea.wordid, (const uint2 *)c->d_grank, dsize, posinfo);
+            PFP_LAUNCH(c, K_EMIT_COUNT, dsize * 17, k_pack_posinfo, nblocks(dsize, BLOCK), ea.D, ea.wordid, dsize, posinfo);
             ea.posinfo = posinfo;
         }
         PFP_LAUNCH(c, K_EMIT_COUNT, dsize * (30 + sizeof(EBT)), (k_emit_slots<EBT>), nblocks(dsize, BLOCK), ea, cnt, d_hard, (uint32_t *)ea.s_sl, (uint32_t *)ea.s_fb, (uint8_t *)ea.s_fl, (uint8_t *)ea.s_pc, s_g0, gk, gfl, gnu);
@@ -1818,7 +1851,7 @@ static int bwt_build_body(pfp_ctx *c, int want_sa, int want_rssa, int slice, int
     PFP_LAUNCH(c, K_MISC, dwords * 8, k_u32_add_store, nblocks(dwords, BLOCK), (const uint32_t *)F, dwords, 1u, F);
     EmitArgs ea;
     ea.D = c->d_dict; ea.dsize = dsize; ea.dwords = (uint32_t)dwords; ea.w = c->w;
-    ea.SA = c->d_gsa; ea.ws = c->d_ws; ea.wrank = c->d_wrank;
+    ea.SA = c->d_gsa; ea.srank = c->d_srank; ea.ws = c->d_ws; ea.wrank = c->d_wrank;
     ea.occ = c->d_occ; ea.F = F; ea.ilist = c->d_ilist; ea.bwsai = c->d_bwsai; ea.bwlast = c->d_bwlast; ea.bwl_il = c->d_bwl_il;
     PFP_ALLOC_HI(c, winfo, uint4, dwords);
     PFP_LAUNCH(c, K_MISC, dwords * 32, k_pack_winfo, nblocks(dwords, BLOCK), (const uint32_t *)c->d_ws, (const uint32_t *)c->d_wrank, (const uint32_t *)c->d_occ, (const uint32_t *)F, dwords, winfo);

@@ -30,11 +30,13 @@ constexpr int DK_KEY_BITS = 51;
 __global__ __launch_bounds__(BLOCK) void k_dict_init_keys(const uint8_t *D, uint64_t dsize, uint64_t *keys, uint32_t *vals)
 {
     __shared__ uint8_t tile[DK_TILE + DK_CHARS];
+    __shared__ uint8_t prevc;
     const uint64_t t0 = (uint64_t)blockIdx.x * DK_TILE;
     for (uint32_t i = threadIdx.x; i < DK_TILE + DK_CHARS; i += BLOCK) {
         const uint64_t x = t0 + i;
         tile[i] = x < dsize ? (uint8_t)dict_code(D[x]) : (uint8_t)0;
     }
+    if (threadIdx.x == 0) prevc = t0 ? (uint8_t)dict_code(D[t0 - 1]) : (uint8_t)EndOfWord;
     __syncthreads();
     // consecutive threads take consecutive positions (conflict-free LDS reads, coalesced stores)
 #pragma unroll 1
@@ -50,7 +52,9 @@ __global__ __launch_bounds__(BLOCK) void k_dict_init_keys(const uint8_t *D, uint
         }
         // bits 56..60: length of the prefix the key covers = jump offset (never past the byte behind the terminator)
         const uint64_t x = t0 + l;
-        if (x < dsize) { keys[x] = key | ((uint64_t)off << 56); vals[x] = (uint32_t)x; }
+        // bit 62 (outside every sort range): x starts a word -- the byte in front is an EndOfWord (or x == 0) and x is not the EndOfDict
+        const uint64_t wstart = ((l ? tile[l - 1] : prevc) == EndOfWord && tile[l] != EndOfDict) ? 1ULL : 0ULL;
+        if (x < dsize) { keys[x] = key | ((uint64_t)off << 56) | (wstart << 62); vals[x] = (uint32_t)x; }
     }
 }
 
@@ -81,10 +85,11 @@ __global__ __launch_bounds__(BLOCK) void k_int_init_keys(const uint32_t *S, uint
 }
 
 // after the initial sort of all N suffixes: head flags, SA, head slot for the max-scan
-__global__ __launch_bounds__(BLOCK) void k_ss_heads(const uint64_t *keys, const uint32_t *vals, uint64_t na, uint64_t keymask, uint32_t *SA, uint32_t *head, uint32_t *headslot)
+__global__ __launch_bounds__(BLOCK) void k_ss_heads(const uint64_t *keys, const uint32_t *vals, uint64_t na, uint64_t keymask, uint32_t *SA, uint32_t *head, uint32_t *headslot, uint8_t *sflag /*nullable: per slot, bit 62 of its key (the suffix starts a word)*/)
 {
     const uint64_t a = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (a >= na) return;
+    if (sflag) sflag[a] = (uint8_t)((keys[a] >> 62) & 1ULL);
     const uint32_t hd = (a == 0 || (keys[a] & keymask) != (keys[a - 1] & keymask)) ? 1u : 0u;
     SA[a] = vals[a];
     head[a] = hd;
@@ -146,6 +151,35 @@ __device__ __forceinline__ uint64_t class_start_at_or_after(const uint32_t *arnk
     return lo;
 }
 
+// Text rounds (dictionaries of non-repetitive collections): the next TK_CHARS characters behind the covered prefix, read from the
+// dictionary itself, order a class -- no rank of any other suffix is consulted, so the 8 bytes per dictionary offset of rj[] are
+// neither scattered after the initial sort (S-3G: 3.4 G random 8-byte writes, 126 ms) nor after every round.  Same number system
+// as the initial keys (nothing behind the terminator counts); *nx = end of the prefix the key covers.
+constexpr int TK_CHARS = 10;                                   // 9^10 < 2^32: the key is the `low` word of a K = 1 round
+__device__ __forceinline__ uint32_t text_key(const uint8_t *D, uint64_t N, uint64_t y, uint32_t *nx)
+{
+    // the characters y .. y+9 from three aligned 8-byte loads (measured on S-3G: ten byte loads per pair made the round 40 % slower
+    // than the 8-byte rank gather it replaces).  The dictionary buffer is 8-byte aligned and ends in EndOfDict, behind which
+    // nothing is looked at (stop), so what the loads pick up beyond it does not matter; loads past the buffer's slack are skipped.
+    const uint64_t base = y & ~7ULL, lim = N + 16;
+    const uint64_t w0 = *reinterpret_cast<const uint64_t *>(D + base);
+    const uint64_t w1 = base + 16 <= lim ? *reinterpret_cast<const uint64_t *>(D + base + 8) : 0ULL;
+    const uint64_t w2 = base + 24 <= lim ? *reinterpret_cast<const uint64_t *>(D + base + 16) : 0ULL;
+    const unsigned sh = (unsigned)(y & 7ULL) * 8u;
+    const uint64_t lo = sh ? (w0 >> sh) | (w1 << (64u - sh)) : w0;          // bytes y .. y+7
+    const uint64_t hi = sh ? (w1 >> sh) | (w2 << (64u - sh)) : w1;          // bytes y+8 .. y+15
+    uint32_t key = 0, off = TK_CHARS; bool stop = false;
+#pragma unroll
+    for (int j = 0; j < TK_CHARS; ++j) {
+        const uint32_t cc = dict_code((uint32_t)((j < 8 ? lo >> (8 * j) : hi >> (8 * (j - 8))) & 0xFFu));
+        key = key * 9u + (stop ? 0u : cc);
+        if (!stop && cc <= 1) off = (uint32_t)j + 1u;
+        stop = stop || cc <= 1;
+    }
+    const uint64_t e = y + off;
+    *nx = (uint32_t)(e < N ? e : N);
+    return key;
+}
 // the three ranks behind y (and the jump behind the third), straight from the state: the chain stops at the prefix that
 // holds the word's terminator (nothing behind it is compared; both members of a tie stop at the same link)
 template <bool DICT> __device__ __forceinline__ uint4 chain3(const uint32_t *rank, const uint2 *rj, uint64_t N, uint64_t y, uint32_t h, const uint8_t *D)
@@ -178,7 +212,8 @@ template <bool DICT> __global__ __launch_bounds__(BLOCK) void k_round_table(cons
 template <bool DICT, int K> __global__ __launch_bounds__(BLOCK) void k_round(const uint32_t *aslot, const uint32_t *arnk, const uint32_t *ajmp, uint64_t na, uint64_t N,
                                                                              uint32_t *SA, const uint32_t *rank, const uint2 *rj, const uint4 *T /*K = 3; null: follow the chain*/, uint32_t h, const uint8_t *D,
                                                                              const uint32_t *M /*run round (K = 1)*/, uint32_t run_min /*characters per initial key*/, int lowbits, uint32_t max_range, uint32_t *newr,
-                                                                             uint32_t *xout /*the sorted suffixes, in list order*/, uint32_t *tnj, uint32_t *newj, uint8_t *flags, uint32_t *stripe_keep, unsigned long long *ndone)
+                                                                             uint32_t *xout /*the sorted suffixes, in list order*/, uint32_t *tnj, uint32_t *newj, uint8_t *flags, uint32_t *stripe_keep, unsigned long long *ndone,
+                                                                             uint32_t *srank /*nullable: per SLOT, head slot of its class*/, uint8_t *sflag /*nullable: per slot flag that moves with its suffix*/, int textkeys)
 {
     constexpr int ITEMS = RoundCfg<K>::ITEMS, TILE = RoundCfg<K>::TILE;
     constexpr uint32_t STEP = RoundCfg<K>::STEP;
@@ -212,8 +247,9 @@ template <bool DICT, int K> __global__ __launch_bounds__(BLOCK) void k_round(con
             sl[it] = j < n ? aslot[s + j] : 0u;
             yj[it] = (DICT && j < n) ? ajmp[s + j] : 0u;
         }
+        uint8_t fi[ITEMS];
 #pragma unroll
-        for (int it = 0; it < ITEMS; ++it) { const uint32_t j = threadIdx.x + (uint32_t)it * BLOCK; xi[it] = j < n ? SA[sl[it]] : 0u; }
+        for (int it = 0; it < ITEMS; ++it) { const uint32_t j = threadIdx.x + (uint32_t)it * BLOCK; xi[it] = j < n ? SA[sl[it]] : 0u; fi[it] = (DICT && sflag && j < n) ? sflag[sl[it]] : (uint8_t)0; }
         if (K == 3) {
 #pragma unroll
             for (int it = 0; it < ITEMS; ++it) {
@@ -234,8 +270,8 @@ template <bool DICT, int K> __global__ __launch_bounds__(BLOCK) void k_round(con
 #pragma unroll
             for (int it = 0; it < ITEMS; ++it) {
                 const uint32_t j = threadIdx.x + (uint32_t)it * BLOCK;
-                const uint2 Q = (j < n && yj[it] < N) ? rj[yj[it]] : make_uint2(0u, (uint32_t)N);
-                lowv[it] = Q.x; njv[it] = Q.y;
+                if (textkeys) { uint32_t nx = (uint32_t)N; lowv[it] = (j < n && yj[it] < N) ? text_key(D, N, yj[it], &nx) : 0u; njv[it] = nx; }
+                else { const uint2 Q = (j < n && yj[it] < N) ? rj[yj[it]] : make_uint2(0u, (uint32_t)N); lowv[it] = Q.x; njv[it] = Q.y; }
             }
         } else {
             // run round: c^d a... is ordered among the suffixes that start with c by t = d if a < c else 2^32-1-d, jump = x + d
@@ -253,7 +289,11 @@ template <bool DICT, int K> __global__ __launch_bounds__(BLOCK) void k_round(con
                         const uint8_t nxt = en < N ? D[en] : (uint8_t)0;
                         low = nxt < D[x] ? d : 0xFFFFFFFFu - d; nx = (uint32_t)(en < N ? en : N); run = true;
                     }
-                    if (!run) { const uint32_t y = yj[it]; const uint2 Q = y < N ? rj[y] : make_uint2(0u, (uint32_t)N); low = Q.x; nx = Q.y; }
+                    if (!run) {
+                        const uint32_t y = yj[it];
+                        if (textkeys) { nx = (uint32_t)N; low = y < N ? text_key(D, N, y, &nx) : 0u; }
+                        else { const uint2 Q = y < N ? rj[y] : make_uint2(0u, (uint32_t)N); low = Q.x; nx = Q.y; }
+                    }
                 }
                 lowv[it] = low; njv[it] = nx;
             }
@@ -263,7 +303,7 @@ template <bool DICT, int K> __global__ __launch_bounds__(BLOCK) void k_round(con
             const uint32_t j = threadIdx.x + (uint32_t)it * BLOCK;
             if (j < n) {
                 if (DICT) tnj[s + j] = njv[it];
-                skeys[j] = ((uint64_t)(arnk[s + j] - hmin) << lowbits) | lowv[it]; sidx[j] = (uint16_t)j;
+                skeys[j] = ((uint64_t)(arnk[s + j] - hmin) << lowbits) | lowv[it]; sidx[j] = (uint16_t)(j | ((uint32_t)fi[it] << 15));      // (a tile holds fewer than 2^15 pairs: bit 15 carries the suffix's flag through the sort)
                 if (K == 3) skeyb[j] = ((uint64_t)r2[it] << lowbits) | r3[it];
             }
         }
@@ -354,12 +394,13 @@ template <bool DICT, int K> __global__ __launch_bounds__(BLOCK) void k_round(con
     __syncthreads();
     // ---- output: all gathers first (the old SA of the range's slots is overwritten below; loads of all of a thread's pairs
     //      are in flight together), then the stores
-    uint32_t xs[ITEMS], slo[ITEMS], nrv[ITEMS], njo[ITEMS], oldr[ITEMS]; uint8_t flg[ITEMS]; unsigned long long keepn = 0;     // kept pairs per position stripe (the range touches at most three), 20 bits each
+    uint32_t xs[ITEMS], slo[ITEMS], nrv[ITEMS], njo[ITEMS], oldr[ITEMS]; uint8_t flg[ITEMS], fout[ITEMS]; unsigned long long keepn = 0;     // kept pairs per position stripe (the range touches at most three), 20 bits each
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
         const uint32_t j = threadIdx.x + (uint32_t)it * BLOCK;
         const bool ok = j < n;
-        const uint32_t src = ok ? sidx[j] : 0u, hp = ok ? shp[j] : 0u;
+        const uint32_t sraw = ok ? sidx[j] : 0u, src = sraw & 0x7FFFu, hp = ok ? shp[j] : 0u;
+        fout[it] = (uint8_t)(sraw >> 15);
         xs[it] = ok ? sx[src] : 0u;
         slo[it] = ok ? aslot[s + j] : 0u;
         nrv[it] = ok ? aslot[s + hp] : 0u;
@@ -389,6 +430,8 @@ template <bool DICT, int K> __global__ __launch_bounds__(BLOCK) void k_round(con
             if (flg[it] & RF_KEEP) keepn += 1ULL << (20 * (uint32_t)((s + j) / STEP - blockIdx.x));
             if (DICT) newj[s + j] = njo[it];
             SA[slo[it]] = xs[it]; newr[s + j] = nrv[it]; flags[s + j] = flg[it]; xout[s + j] = xs[it];
+            if (srank) srank[slo[it]] = nrv[it];
+            if (DICT && sflag) sflag[slo[it]] = fout[it];
         }
     }
     unsigned long long kt;
@@ -404,12 +447,13 @@ template <bool DICT, int K> __global__ __launch_bounds__(BLOCK) void k_round(con
 // sorted first, then (stable) ka.
 template <bool DICT, int K> __global__ __launch_bounds__(BLOCK) void k_round_keys(const uint32_t *idx, uint64_t nl, const uint32_t *aslot, const uint32_t *arnk, const uint32_t *ajmp, uint64_t N,
                                                                                   const uint32_t *SA, const uint32_t *rank, const uint2 *rj, const uint4 *T, uint32_t h, const uint8_t *D, const uint32_t *M, uint32_t run_min, int lowbits,
-                                                                                  uint64_t *ka, uint64_t *kb, uint32_t *ux, uint32_t *tnj)
+                                                                                  uint64_t *ka, uint64_t *kb, uint32_t *ux, uint32_t *tnj, const uint8_t *sflag, uint8_t *uf, int textkeys)
 {
     const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= nl) return;
     const uint32_t a = idx[i];
     const uint32_t x = SA[aslot[a]];
+    if (DICT && sflag) uf[i] = sflag[aslot[a]];
     uint32_t low, nx = 0;
     if (K == 3) {
         const uint64_t y = DICT ? (uint64_t)ajmp[a] : (uint64_t)x + h;
@@ -427,7 +471,11 @@ template <bool DICT, int K> __global__ __launch_bounds__(BLOCK) void k_round_key
                 low = nxt < D[x] ? d : 0xFFFFFFFFu - d; nx = (uint32_t)(en < N ? en : N); run = true;
             }
         }
-        if (!run) { const uint32_t y = ajmp[a]; const uint2 Q = y < N ? rj[y] : make_uint2(0u, (uint32_t)N); low = Q.x; nx = Q.y; }
+        if (!run) {
+            const uint32_t y = ajmp[a];
+            if (textkeys) { nx = (uint32_t)N; low = y < N ? text_key(D, N, y, &nx) : 0u; }
+            else { const uint2 Q = y < N ? rj[y] : make_uint2(0u, (uint32_t)N); low = Q.x; nx = Q.y; }
+        }
     }
     if (DICT) tnj[a] = nx;
     ka[i] = ((uint64_t)arnk[a] << lowbits) | low; ux[i] = x;
@@ -454,7 +502,7 @@ __global__ __launch_bounds__(BLOCK) void k_round_subset_heads(const uint64_t *ke
 // the sorted subset goes back to its positions (whole classes, in order): same outputs as k_round
 template <bool DICT> __global__ __launch_bounds__(BLOCK) void k_round_finish(const uint32_t *perm, const uint32_t *ux, const uint32_t *tnj, const uint32_t *headidx /*max-scanned*/, const uint32_t *idx, uint64_t nl, uint64_t N,
                                                                              const uint32_t *aslot, const uint32_t *arnk, uint32_t *SA, const uint8_t *D, uint32_t step,
-                                                                             uint32_t *newr, uint32_t *xout, uint32_t *newj, uint8_t *flags, uint32_t *stripe_keep)
+                                                                             uint32_t *newr, uint32_t *xout, uint32_t *newj, uint8_t *flags, uint32_t *stripe_keep, uint32_t *srank, uint8_t *sflag, const uint8_t *uf)
 {
     const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= nl) return;
@@ -471,6 +519,8 @@ template <bool DICT> __global__ __launch_bounds__(BLOCK) void k_round_finish(con
     } else if (nr != arnk[a]) fl |= RF_CHANGED;
     if (keep) fl |= RF_KEEP;
     SA[aslot[a]] = x; newr[a] = nr; flags[a] = fl; xout[a] = x;
+    if (srank) srank[aslot[a]] = nr;
+    if (DICT && sflag) sflag[aslot[a]] = uf[src];
     if (keep) atomicAdd(&stripe_keep[a / step], 1u);
 }
 
@@ -500,7 +550,7 @@ template <bool DICT, int K> __global__ __launch_bounds__(BLOCK) void k_round_app
     uint32_t nch = 0;
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
-        if (fl[k] & RF_CHANGED) { if (DICT) rj[x[k]] = make_uint2(nr[k], nj[k]); else rank[x[k]] = nr[k]; ++nch; }
+        if (fl[k] & RF_CHANGED) { if (DICT) { if (rj) rj[x[k]] = make_uint2(nr[k], nj[k]); } else rank[x[k]] = nr[k]; ++nch; }
         if (fl[k] & RF_KEEP) { oslot[o] = slot[k]; ornk[o] = nr[k]; if (DICT) ojmp[o] = nj[k]; ++o; }
     }
     if (stat && nch) atomicAdd(stat, (unsigned long long)nch);
@@ -516,7 +566,7 @@ template <bool DICT> __global__ __launch_bounds__(BLOCK) void k_init_state(const
     const uint64_t a = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (a >= N) return;
     const uint32_t x = vals[a];
-    if (DICT) rj[x] = make_uint2(rk[a], x + (uint32_t)(keys[a] >> 56)); else rank[x] = rk[a];
+    if (DICT) { if (rj) rj[x] = make_uint2(rk[a], x + ((uint32_t)(keys[a] >> 56) & 31u)); } else rank[x] = rk[a];
     const bool single = head[a] && (a + 1 == N || head[a + 1]);
     bool fin = single;
     if (DICT && !fin) fin = (keys[a] & ((1ULL << 56) - 1)) % sigma <= 1u;   // last base-sigma digit: padding behind a terminator, or the terminator itself
@@ -529,12 +579,12 @@ template <bool DICT> __global__ __launch_bounds__(BLOCK) void k_init_active(cons
     if (a >= N || !keep[a]) return;
     const uint32_t o = pos[a];
     aslot[o] = (uint32_t)a; arnk[o] = rk[a];
-    if (DICT) ajmp[o] = vals[a] + (uint32_t)(keys[a] >> 56);
+    if (DICT) ajmp[o] = vals[a] + ((uint32_t)(keys[a] >> 56) & 31u);
 }
 
 struct RoundBufs {
     uint32_t *aslot[2], *arnk[2], *ajmp[2], *newr, *xout, *tnj, *newj, *M, *stripe, *lidx, *head, *keep, *pos, *d_cnt;
-    uint8_t *flags; unsigned long long *d_done; uint4 *T;
+    uint8_t *flags; unsigned long long *d_done; uint4 *T; uint32_t *srank; uint8_t *sflag; int textkeys;
     uint64_t *k0, *k1; uint32_t *v0, *v1;
     uint32_t run_min;      // dictionary: characters per initial key (a suffix inside a run of at least that many equal bytes is ordered by the run round)
 };
@@ -544,7 +594,7 @@ template <bool DICT, int K> inline int suffix_sort_round(pfp_ctx *c, RoundBufs &
                                                          uint32_t *SA, uint32_t *rank, uint2 *rj, bool verbose, uint32_t *na_out)
 {
     constexpr uint32_t STEP = RoundCfg<K>::STEP;
-    const int lowbits = run_round ? 32 : rbits;
+    const int lowbits = (run_round || b.textkeys) ? 32 : rbits;      // run tokens and text keys are 32-bit words
     const unsigned gs = nblocks(na, STEP);
     const uint32_t hh = (uint32_t)(h < N ? h : N);
     const uint32_t *Mr = run_round ? (const uint32_t *)b.M : (const uint32_t *)nullptr;
@@ -559,7 +609,7 @@ template <bool DICT, int K> inline int suffix_sort_round(pfp_ctx *c, RoundBufs &
     // algorithmic bytes per active suffix: list entry 8 (+4 jump), SA[slot] 4 in + 4 out, the gathered
     // rank 4 (K = 3: 12; dictionary: + jump 4, + 1 terminator byte), new rank 4 (+ new jump 4 + 4 through scratch), flag 1
     PFP_LAUNCH(c, K_CLASS_SORT, (uint64_t)na * ((DICT ? 46 : 25) + (K == 3 ? 8 : 0)), (k_round<DICT, K>), gs, (const uint32_t *)b.aslot[cur], (const uint32_t *)b.arnk[cur], (const uint32_t *)b.ajmp[cur], (uint64_t)na, N, SA,
-               (const uint32_t *)rank, (const uint2 *)rj, T, hh, D, Mr, b.run_min, lowbits, max_range, b.newr, b.xout, b.tnj, b.newj, b.flags, b.stripe, b.d_done);
+               (const uint32_t *)rank, (const uint2 *)rj, T, hh, D, Mr, b.run_min, lowbits, max_range, b.newr, b.xout, b.tnj, b.newj, b.flags, b.stripe, b.d_done, b.srank, b.sflag, b.textkeys);
     unsigned long long nd = 0;
     PFP_HIP(c, hipMemcpyAsync(&nd, b.d_done, 8, hipMemcpyDeviceToHost, c->stream));
     PFP_HIP(c, hipStreamSynchronize(c->stream));
@@ -567,14 +617,15 @@ template <bool DICT, int K> inline int suffix_sort_round(pfp_ctx *c, RoundBufs &
     if (nl) {   // classes too large for a tile: collect their pairs, sort them globally, put them back
         if (verbose) fprintf(stderr, "[pfbwt_hip]   class sort: %u pairs, %llu in classes too large for one tile\n", na, (unsigned long long)nl);
         const size_t mk = c->arena.mark_hi();
-        uint64_t *ka, *kb = nullptr; uint32_t *ux;
+        uint64_t *ka, *kb = nullptr; uint32_t *ux; uint8_t *uf = nullptr;
         PFP_ALLOC_HI(c, ka, uint64_t, nl); PFP_ALLOC_HI(c, ux, uint32_t, nl);
+        if (DICT && b.sflag) PFP_ALLOC_HI(c, uf, uint8_t, nl);
         if (K == 3) PFP_ALLOC_HI(c, kb, uint64_t, nl);
         const unsigned ga = nblocks(na, BLOCK), gl = nblocks(nl, BLOCK);
         PFP_LAUNCH(c, K_COMPACT, (uint64_t)na * 5, k_not_done, ga, (const uint8_t *)b.flags, (uint64_t)na, b.keep);
         PFP_TRY(device_compact(c, nullptr, b.keep, na, b.lidx, b.pos, b.d_cnt));
         PFP_LAUNCH(c, K_SS_MAKE_KEYS, nl * 48, (k_round_keys<DICT, K>), gl, (const uint32_t *)b.lidx, nl, (const uint32_t *)b.aslot[cur], (const uint32_t *)b.arnk[cur], (const uint32_t *)b.ajmp[cur], N, (const uint32_t *)SA,
-                   (const uint32_t *)rank, (const uint2 *)rj, T, hh, D, Mr, b.run_min, lowbits, ka, kb, ux, b.tnj);
+                   (const uint32_t *)rank, (const uint2 *)rj, T, hh, D, Mr, b.run_min, lowbits, ka, kb, ux, b.tnj, (const uint8_t *)b.sflag, uf, b.textkeys);
         uint64_t *lsk = b.k0; uint32_t *lsv = b.v0; uint64_t *alk = b.k1; uint32_t *alv = b.v1;
         if (K == 3) {
             PFP_LAUNCH(c, K_SS_MAKE_KEYS, nl * 20, k_copy_keys_iota, gl, (const uint64_t *)kb, nl, b.k0, b.v0);
@@ -589,7 +640,7 @@ template <bool DICT, int K> inline int suffix_sort_round(pfp_ctx *c, RoundBufs &
         PFP_LAUNCH(c, K_SS_HEADS, nl * 12, k_round_subset_heads, gl, (const uint64_t *)fsk, (const uint64_t *)kb, (const uint32_t *)fsv, nl, b.head);
         PFP_TRY((device_scan<uint32_t, 1>(c, b.head, b.head, nl, nullptr)));
         PFP_LAUNCH(c, K_SS_WRITE_RANK, nl * 40, (k_round_finish<DICT>), gl, (const uint32_t *)fsv, (const uint32_t *)ux, (const uint32_t *)b.tnj, (const uint32_t *)b.head, (const uint32_t *)b.lidx, nl, N,
-                   (const uint32_t *)b.aslot[cur], (const uint32_t *)b.arnk[cur], SA, D, STEP, b.newr, b.xout, b.newj, b.flags, b.stripe);
+                   (const uint32_t *)b.aslot[cur], (const uint32_t *)b.arnk[cur], SA, D, STEP, b.newr, b.xout, b.newj, b.flags, b.stripe, b.srank, b.sflag, (const uint8_t *)uf);
         c->arena.release_hi(mk);
     }
     PFP_TRY((device_scan<uint32_t, 0>(c, b.stripe, b.stripe, (uint64_t)gs, b.d_cnt)));
@@ -612,19 +663,25 @@ template <bool DICT, int K> inline int suffix_sort_round(pfp_ctx *c, RoundBufs &
 // round).  k0/v0 and their twins k1/v1 (N entries each) are scratch owned by the caller.
 template <bool DICT> inline int suffix_sort_doubling(pfp_ctx *c, uint64_t N, uint64_t *k0, uint32_t *v0, uint64_t *k1, uint32_t *v1,
                                                     const BitRange *init_ranges, int n_init_ranges, uint32_t h0, const uint8_t *D, uint32_t *SA, uint32_t *rank, uint2 *rj, int *rounds_out,
-                                                    uint32_t sigma = 9 /*dictionary: codes of the initial keys' number system*/)
+                                                    uint32_t sigma = 9 /*dictionary: codes of the initial keys' number system*/, uint32_t *srank = nullptr /*N entries, optional: per slot, head slot of its class*/,
+                                                    uint8_t *sflag = nullptr /*N bytes, optional (dictionary): bit 62 of every suffix's initial key, kept at the suffix's slot*/,
+                                                    int text_mode = 0 /*dictionary: every round orders by the next characters of the text, rj is not used (may be null)*/,
+                                                    int *converged = nullptr /*text mode: 0 when the rounds were given up (many long common prefixes): sort again without text_mode*/)
 {
     const size_t mk = c->arena.mark_hi();
     RoundBufs b{};
     b.run_min = h0;
     uint32_t *aux;
-    PFP_ALLOC_HI(c, b.head, uint32_t, N); PFP_ALLOC_HI(c, aux, uint32_t, N); PFP_ALLOC_HI(c, b.keep, uint32_t, N); PFP_ALLOC_HI(c, b.pos, uint32_t, N);
+    PFP_ALLOC_HI(c, b.head, uint32_t, N); if (srank) aux = srank; else PFP_ALLOC_HI(c, aux, uint32_t, N);
+    PFP_ALLOC_HI(c, b.keep, uint32_t, N); PFP_ALLOC_HI(c, b.pos, uint32_t, N);
+    b.srank = srank; b.sflag = sflag; b.textkeys = (DICT && text_mode) ? 1 : 0;
+    if (converged) *converged = 1;
     PFP_ALLOC_HI(c, b.d_cnt, uint32_t, 4);
     uint64_t *sk; uint32_t *sv;
     PFP_TRY(radix_sort_pairs<uint64_t>(c, k0, v0, k1, v1, N, init_ranges, n_init_ranges, &sk, &sv));
     const unsigned gN = nblocks(N, BLOCK);
     uint64_t keymask = 0; for (int r = 0; r < n_init_ranges; ++r) for (int bb = init_ranges[r].lo; bb < init_ranges[r].hi; ++bb) keymask |= 1ULL << bb;
-    PFP_LAUNCH(c, K_SS_HEADS, N * 24, k_ss_heads, gN, (const uint64_t *)sk, (const uint32_t *)sv, N, keymask, SA, b.head, aux);
+    PFP_LAUNCH(c, K_SS_HEADS, N * 24, k_ss_heads, gN, (const uint64_t *)sk, (const uint32_t *)sv, N, keymask, SA, b.head, aux, sflag);
     PFP_TRY((device_scan<uint32_t, 1>(c, aux, aux, N, nullptr)));
     PFP_LAUNCH(c, K_SS_WRITE_RANK, N * 24, (k_init_state<DICT>), gN, (const uint64_t *)sk, (const uint32_t *)sv, (const uint32_t *)b.head, (const uint32_t *)aux, N, sigma, rank, rj, b.keep);
     PFP_TRY((device_scan<uint32_t, 0>(c, b.keep, b.pos, N, b.d_cnt)));
@@ -650,13 +707,18 @@ template <bool DICT> inline int suffix_sort_doubling(pfp_ctx *c, uint64_t N, uin
         // k0 / v0 / k1 / v1 are free from here on: scratch of the large-class route
         b.k0 = k0; b.k1 = k1; b.v0 = v0; b.v1 = v1;
         const bool no_table = c->tun.sort_no_table != 0;                   // tests: the K = 3 rounds follow the chains themselves
-        if (force_k != 1 && !no_table && (uint64_t)na * 8 > N && c->arena.hi - c->arena.lo > 16 * (size_t)N + 40 * (size_t)na + ((size_t)1 << 20))
+        if (!b.textkeys && force_k != 1 && !no_table && (uint64_t)na * 8 > N && c->arena.hi - c->arena.lo > 16 * (size_t)N + 40 * (size_t)na + ((size_t)1 << 20))
             PFP_ALLOC_HI(c, b.T, uint4, N);          // optional: without room for it the K = 3 rounds follow the chains themselves
         const uint32_t max_range_env = c->tun.class_sort_maxrange;   // tests: smaller, to reach the large-class route
         int cur = 0; uint64_t h = h0;
         uint32_t na_before = 0;                 // length of the list the previous round started from (0: no previous round)
         while (na > 0) {
             if (verbose) fprintf(stderr, "[pfbwt_hip] suffix sort N=%llu round %d: %u active\n", (unsigned long long)N, rounds, na);
+            if (b.textkeys && ((rounds >= 4 && (uint64_t)na * 64 > N) || rounds > 40)) {      // a text round adds TK_CHARS characters, a doubling round doubles: give up
+                if (verbose) fprintf(stderr, "[pfbwt_hip] text rounds given up (%u suffixes still share %llu characters): rank-based rounds instead\n", na, (unsigned long long)(h0 + (uint64_t)TK_CHARS * (rounds - 1)));
+                if (converged) *converged = 0;
+                break;
+            }
             if (rounds > 64) return PFP_E_CORRUPT; // cannot happen on well-formed input
             const bool run_round = (b.M != nullptr && rounds == 1);
             uint32_t nn = 0;
@@ -665,7 +727,7 @@ template <bool DICT> inline int suffix_sort_doubling(pfp_ctx *c, uint64_t N, uin
             // the two extra ranks are sorted for nothing: plain doubling (6 passes) from there on
             const bool resolving = na_before != 0 && (uint64_t)na * 2 < na_before;
             na_before = na;
-            if (run_round || force_k == 1 || (resolving && force_k != 3)) {
+            if (run_round || force_k == 1 || b.textkeys || (resolving && force_k != 3)) {
                 const uint32_t mr = max_range_env ? max_range_env : (uint32_t)RoundCfg<1>::TILE;
                 PFP_TRY((suffix_sort_round<DICT, 1>(c, b, cur, na, N, h, D, run_round, rbits, mr < (uint32_t)RoundCfg<1>::TILE ? mr : (uint32_t)RoundCfg<1>::TILE, SA, rank, rj, verbose, &nn)));
                 h *= 2;

@@ -1,11 +1,11 @@
 #!/bin/bash
 # usage (on the GPU box, from the repo root): tools/gpu_final.sh <tag>
-# the evidence set of a round: default bench line, kernel-trace summary of the same command, PMC traffic passes, the small
-# workloads, the GRCh38-size check -- everything under gpurun_out/<tag>_*
+# the evidence set of a round: default bench line, kernel-trace summary of the same command, PMC traffic passes, the other
+# single-GPU workloads (S-chr22 = configs[1], S-3G = configs[2]) with their kernel traces -- everything under gpurun_out/<tag>_*
 tag=$1
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $root
-python bench.py > gpurun_out/${tag}_bench_s32g.json 2> gpurun_out/${tag}_bench_s32g.err; echo "default bench rc=$?"
+python bench.py --steps 5 --warmup 1 > gpurun_out/${tag}_bench_s32g.json 2> gpurun_out/${tag}_bench_s32g.err; echo "default bench rc=$?"
 tools/gpu_prof.sh ${tag}_prof_s32g --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end; echo "prof rc=$?"
 mv gpurun_out/${tag}_prof_s32g_kernel_stats.csv gpurun_out/${tag}_bench_s32g_kernel_stats.csv
 cd /tmp && export TMPDIR=/tmp
@@ -15,9 +15,7 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
 done
 cd $root
 python3 tools/pmc_traffic.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE gpurun_out/${tag}_pmc_traffic_s32g.json S-32G > gpurun_out/${tag}_pmc_traffic_s32g.txt 2>&1; echo "pmc summary rc=$?"
-python bench.py --workload S-chr22 > gpurun_out/${tag}_bench_chr22.json 2> gpurun_out/${tag}_bench_chr22.err; echo "chr22 rc=$?"
-tools/gpu_prof.sh ${tag}_prof_chr22 --workload S-chr22 --steps 5 --warmup 1 --no-cpu-baseline --no-end-to-end
+python bench.py --workload S-chr22 --steps 20 --warmup 2 > gpurun_out/${tag}_bench_chr22.json 2> gpurun_out/${tag}_bench_chr22.err; echo "chr22 rc=$?"
+tools/gpu_prof.sh ${tag}_prof_chr22 --workload S-chr22 --steps 9 --warmup 1 --no-cpu-baseline --no-end-to-end
 mv gpurun_out/${tag}_prof_chr22_kernel_stats.csv gpurun_out/${tag}_bench_chr22_kernel_stats.csv
-python bench.py --workload S-50M > gpurun_out/${tag}_bench_s50m.json 2> gpurun_out/${tag}_bench_s50m.err; echo "s50m rc=$?"
-python tools/big_check.py --L 3100000000 --u64 --reps 2 --nrun 500000000 30000000 2000000000 5000000 > gpurun_out/${tag}_big_S3G_u64.log 2>&1; echo "S3G rc=$?"
-tail -4 gpurun_out/${tag}_big_S3G_u64.log
+python bench.py --workload S-3G --steps 3 --warmup 1 > gpurun_out/${tag}_bench_s3g.json 2> gpurun_out/${tag}_bench_s3g.err; echo "S-3G rc=$?"
