@@ -69,7 +69,7 @@ def oracle_mode(want_sa, want_rssa):
     return ["-s"] * want_sa + ["-r"] * want_rssa
 PARITY_ENV = {"PFP_TEST_HOOKS": "1", "PFP_FORCE_WIDE_ROWS": "1", "PFP_EMIT_CHUNK_ROWS": str(1 << 25)}     # S-32G parity child: k_*<u64, u64>, ~10 windows
 
-KERNEL_SYMBOL = {"emit": "pfp::k_emit<", "fill": "pfp::k_fill<", "radix_scatter": "pfp::k_seg_scatter<unsigned long", "radix_hist": "pfp::k_seg_hist<unsigned long",
+KERNEL_SYMBOL = {"emit": "pfp::k_emit", "emit_large": "pfp::k_emit_groups_large<", "emit_big": "pfp::k_emit<", "fill": "pfp::k_fill<", "radix_scatter": "pfp::k_seg_scatter<unsigned long", "radix_hist": "pfp::k_seg_hist<unsigned long",
                  "class_sort": "pfp::k_round<", "emit_count": "pfp::k_emit_slots<", "samples": "pfp::k_sample_values<", "phrase_hash": "pfp::k_dedup_insert",
                  "trigger_scan": "pfp::k_trigger_scan", "ss_write_rank": "pfp::k_round_apply<"}
 

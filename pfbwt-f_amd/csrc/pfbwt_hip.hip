@@ -47,8 +47,8 @@ static int ensure_arena(pfp_ctx *c, uint64_t n_hint)
 }
 
 // The text buffer: 16 guard bytes + text + w Dollars + slack for whole trigger-scan tiles.  Its address range is reserved once
-// (text_hint bytes if the caller announced a size with pfp_parse_reserve, else what the card could hold) and committed as the
-// text grows: feeding record by record neither re-allocates nor copies.
+// (text_hint bytes if the caller announced a size with pfp_parse_reserve, else four times the first feed, doubled when outgrown) and
+// committed as the text grows: feeding record by record rarely moves the text and never re-allocates piecemeal.
 static int ensure_text(pfp_ctx *c, uint64_t need_n)
 {
     const size_t need = 16 + (((size_t)need_n + 4095) / 4096) * 4096 + 4096 + 64;
@@ -56,7 +56,15 @@ static int ensure_text(pfp_ctx *c, uint64_t need_n)
     if (!c->text.live() || need > c->text.va_bytes) {
         size_t fr = 0, tot = 0;
         if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); tot = (size_t)1 << 38; }
-        size_t va = c->text_hint ? (size_t)c->text_hint + (size_t)c->text_hint / 8 + ((size_t)64 << 20) : tot;
+        // An announced size (pfp_parse_reserve: the file reader knows the file's size) is reserved as it is.  Without one the range
+        // is four times what the first feed needs (at least 64 MiB) and doubles when the text outgrows it: the text is then moved, a
+        // device-to-device copy that costs less than 1 ms per GB and at most twice the text in total.  (Until round 3 every context
+        // reserved the card's whole size and therefore committed HBM in 2 GiB pieces: a 100-byte text of a test created, mapped and
+        // unmapped 2 GiB -- thousands of such contexts per process are what the rare host-side crashes inside pfp_destroy on the
+        // GPU box point at.)
+        size_t va = c->text_hint ? (size_t)c->text_hint + (size_t)c->text_hint / 8 + ((size_t)64 << 20) : (4 * need > ((size_t)64 << 20) ? 4 * need : ((size_t)64 << 20));
+        if (!c->text_hint && c->text.live() && va < 2 * c->text.va_bytes) va = 2 * c->text.va_bytes;
+        if (!c->text_hint && va > tot && tot > need + need / 4) va = tot;
         if (va < need) va = need + need / 4;
         VmRegion nr;
         if (nr.reserve(va, c->device) != hipSuccess) return PFP_E_NOMEM;
