@@ -10,11 +10,37 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 namespace pfp {
 
 constexpr size_t VM_MIN_CHUNK = (size_t)2 << 20, VM_MAX_CHUNK = (size_t)2 << 30;
+
+// Address ranges are never given back to the runtime while the process lives: a destroyed region unmaps and releases its HBM and
+// parks its (empty) range here; a later reservation of a fitting size on the same device maps new pieces INTO that range.  Why
+// (MI355X box, round 3): a range that was freed with hipMemAddressFree and handed out again by hipMemAddressReserve at the same
+// address faulted in the kernels of the next owner -- a context created after a large one was destroyed (tools/shard_sim.py: the
+// second rank's parse, deterministically), a workspace that was re-reserved larger (test_sharded_build_rccl_world1).  Unmapping
+// and mapping again inside a range that stays reserved is what allocators with expandable segments do all day and is not
+// affected.  Address space is plentiful (a process would have to park thousands of card-sized ranges to run out).
+struct VmRangePool {
+    struct Range { char *base; size_t va_bytes, chunk; int device; };
+    std::mutex mu; std::vector<Range> parked;
+    static VmRangePool &get() { static VmRangePool p; return p; }
+    bool take(size_t va, size_t chunk, int device, Range *out)
+    {
+        std::lock_guard<std::mutex> g(mu);
+        size_t best = (size_t)-1;
+        for (size_t i = 0; i < parked.size(); ++i)
+            if (parked[i].device == device && parked[i].chunk == chunk && parked[i].va_bytes >= va && parked[i].va_bytes <= 2 * va + chunk &&
+                (best == (size_t)-1 || parked[i].va_bytes < parked[best].va_bytes)) best = i;
+        if (best == (size_t)-1) return false;
+        *out = parked[best]; parked.erase(parked.begin() + (long)best);
+        return true;
+    }
+    void park(const Range &r) { std::lock_guard<std::mutex> g(mu); parked.push_back(r); }
+};
 
 // One address range, committed in pieces of ONE size (a power of two between 2 MiB and 2 GiB, at most ~256 pieces per range)
 // that sit at multiples of that size -- the layout the runtime was seen to accept for hipMemSetAccess; pieces of mixed sizes
@@ -34,9 +60,12 @@ struct VmRegion {
         device = dev;
         size_t ch = VM_MIN_CHUNK;
         while (ch < VM_MAX_CHUNK && ch * 256 < bytes) ch <<= 1;
-        const size_t va = (bytes + ch - 1) / ch * ch;
+        size_t va = (bytes + ch - 1) / ch * ch;
         void *p = nullptr;
-        hipError_t e = hipMemAddressReserve(&p, va, ch, nullptr, 0);
+        VmRangePool::Range pr;
+        hipError_t e = hipSuccess;
+        if (VmRangePool::get().take(va, ch, dev, &pr)) { p = pr.base; va = pr.va_bytes; }      // an empty range parked by a destroyed region
+        else e = hipMemAddressReserve(&p, va, ch, nullptr, 0);
         if (e == hipSuccess) {
             base = (char *)p; va_bytes = va; chunk = ch; vmm = true; mapped.assign(va / ch, 0); handle.assign(va / ch, hipMemGenericAllocationHandle_t()); lo_edge = 0; hi_edge = va; committed = 0;
             return hipSuccess;
@@ -73,7 +102,7 @@ struct VmRegion {
         if (!base) return;
         if (vmm) {
             for (size_t s = 0; s < mapped.size(); ++s) if (mapped[s]) { (void)hipMemUnmap(base + s * chunk, chunk); (void)hipMemRelease(handle[s]); }
-            (void)hipMemAddressFree(base, va_bytes);
+            VmRangePool::get().park({base, va_bytes, chunk, device});      // the range itself stays reserved (see VmRangePool)
         } else (void)hipFree(base);
         handle.clear(); mapped.clear(); base = nullptr; va_bytes = 0; chunk = 0; committed = 0; lo_edge = hi_edge = 0; vmm = false;
     }

@@ -46,7 +46,9 @@ for r in range(a.ranks):
             ctx.feed_left_context(w)
         for h in range(r * Hl, (r + 1) * Hl):
             ctx.feed(big[h], True)
+            if os.environ.get("SHARD_SIM_TRACE"): sync(); print("  rank %d rep %d fed %d" % (r, rep, h), flush=True)
         t1 = time.time(); sz = ctx.finalize(shard=True); sync(); t2 = time.time()
+        if os.environ.get("SHARD_SIM_TRACE"): print("  rank %d rep %d finalized" % (r, rep), flush=True)
     buf, meta = pfbwt_dist.pack_local_shard(ctx, dev); sync(); t3 = time.time()
     packed.append(buf); metas.append(meta); t_parse.append(t2 - t1)
     print("rank %d: local n=%d m=%d dwords=%d dsize=%d | feed(H2D) %.2fs parse %.3fs pack %.3fs payload %.1f MB"
@@ -57,9 +59,10 @@ for r in range(a.ranks):
     n, m, dw, ds, _, lc = (int(x) for x in metas[r])
     v = pfbwt_hip.ShardView(); v.n, v.m, v.dwords, v.dsize, v.left_context = n, m, dw, ds, lc
     off, ptrs = 0, []
-    for b in v.nbytes():
+    for b in v.nbytes(compact=True):      # what pack_local_shard sends: dictionary, word starts, phrase ids (the merge derives ends / last bytes)
         ptrs.append(packed[r].data_ptr() + off); off = pfbwt_dist._align(off + b)
-    v.d_dict, v.d_ws, v.d_pid, v.d_ye, v.d_last = ptrs
+    v.d_dict, v.d_ws, v.d_pid = ptrs
+    v.d_ye = v.d_last = None
     views.append(v)
 
 # --- what every rank does after the all-gather
