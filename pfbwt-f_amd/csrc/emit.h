@@ -90,20 +90,38 @@ __global__ __launch_bounds__(BLOCK) void k_word_rank(const uint32_t *sorted_ids,
     const uint32_t id = sorted_ids[r];
     wrank[id] = (uint32_t)r; idofrank[r] = id; occ[r] = occw[id];
 }
-__global__ __launch_bounds__(BLOCK) void k_flags_u8_to_u32(const uint8_t *f, uint64_t n, uint32_t *out)
+// word ranks from the word-start flags of the slots (text-round dictionary sort): the r-th flagged slot holds the word of rank r.
+// Flags are counted per tile of WF_TILE slots (16 per thread), the tile counts scanned, the ranks inside a tile by a block scan --
+// the flags are bytes and one in a hundred is set: widening 3.4 G of them to words for a device-wide scan moved 45 GB for nothing.
+constexpr int WF_PER_THREAD = 16, WF_TILE = BLOCK * WF_PER_THREAD;
+__device__ __forceinline__ uint32_t wf_mask16(const uint8_t *sflag, uint64_t i0, uint64_t n)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i < n) out[i] = f[i] ? 1u : 0u;
+    uint32_t m = 0;
+#pragma unroll
+    for (int k = 0; k < WF_PER_THREAD; ++k) if (i0 + k < n && sflag[i0 + k]) m |= 1u << k;
+    return m;
 }
-// word ranks from the word-start flags of the slots (text-round dictionary sort): the r-th flagged slot holds the word of rank r
-__global__ __launch_bounds__(BLOCK) void k_word_rank_flags(const uint8_t *sflag, const uint32_t *fpos, const uint32_t *SA, const uint32_t *wordid, uint64_t dsize, uint32_t dwords,
+__global__ __launch_bounds__(BLOCK) void k_flag_tile_count(const uint8_t *sflag, uint64_t n, uint32_t *tilecnt)
+{
+    __shared__ uint32_t red[4];
+    const uint64_t i0 = ((uint64_t)blockIdx.x * BLOCK + threadIdx.x) * WF_PER_THREAD;
+    uint32_t tot;
+    (void)block_excl_sum((uint32_t)__popc(wf_mask16(sflag, i0, n)), red, &tot);
+    if (threadIdx.x == 0) tilecnt[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(BLOCK) void k_word_rank_flags(const uint8_t *sflag, const uint32_t *tilebase, const uint32_t *SA, const uint32_t *wordid, uint64_t dsize, uint32_t dwords,
                                                          const uint32_t *occw, uint32_t *wrank, uint32_t *idofrank, uint32_t *occ)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= dsize || !sflag[i]) return;
-    const uint32_t r = fpos[i], id = wordid[SA[i]];
-    if (r >= dwords || id >= dwords) return;
-    wrank[id] = r; idofrank[r] = id; occ[r] = occw[id];
+    __shared__ uint32_t red[4];
+    const uint64_t i0 = ((uint64_t)blockIdx.x * BLOCK + threadIdx.x) * WF_PER_THREAD;
+    uint32_t m = wf_mask16(sflag, i0, dsize), tot;
+    uint32_t r = tilebase[blockIdx.x] + block_excl_sum((uint32_t)__popc(m), red, &tot);
+    while (m) {
+        const int k = __ffs((int)m) - 1; m &= m - 1;
+        const uint32_t id = wordid[SA[i0 + k]];
+        if (r < dwords && id < dwords) { wrank[id] = r; idofrank[r] = id; occ[r] = occw[id]; }
+        ++r;
+    }
 }
 __global__ __launch_bounds__(BLOCK) void k_parse_ranks(const uint32_t *pid, const uint32_t *wrank, uint64_t m, uint32_t *parse)
 {

@@ -768,13 +768,14 @@ static int finish_parse(pfp_ctx *c, const uint32_t *occw)
         // text-round sort: the suffixes that start a word carry a flag to their slots; in slot order they ARE the words in
         // lexicographic order (two distinct words are never byte-identical), so their word ids, compacted, are the ids by rank
         const size_t mkf = c->arena.mark_hi();
-        uint32_t *fl32, *fpos, *d_cnt;
-        PFP_ALLOC_HI(c, fl32, uint32_t, dsize); PFP_ALLOC_HI(c, fpos, uint32_t, dsize); PFP_ALLOC_HI(c, d_cnt, uint32_t, 1);
-        PFP_LAUNCH(c, K_WORD_RANK, dsize * 5, k_flags_u8_to_u32, nblocks(dsize, BLOCK), (const uint8_t *)c->d_sflag, dsize, fl32);
-        PFP_TRY((device_scan<uint32_t, 0>(c, fl32, fpos, dsize, d_cnt)));
+        const uint64_t nt = nblocks(dsize, WF_TILE);
+        uint32_t *tcnt, *tbase, *d_cnt;
+        PFP_ALLOC_HI(c, tcnt, uint32_t, nt); PFP_ALLOC_HI(c, tbase, uint32_t, nt); PFP_ALLOC_HI(c, d_cnt, uint32_t, 1);
+        PFP_LAUNCH(c, K_WORD_RANK, dsize, k_flag_tile_count, nt, (const uint8_t *)c->d_sflag, dsize, tcnt);
+        PFP_TRY((device_scan<uint32_t, 0>(c, tcnt, tbase, nt, d_cnt)));
         uint32_t nst = 0; PFP_TRY(d2h_u32(c, d_cnt, &nst));
         if (nst != dwords) return PFP_E_CORRUPT;
-        PFP_LAUNCH(c, K_WORD_RANK, dsize * 9 + dwords * 24, k_word_rank_flags, nblocks(dsize, BLOCK), (const uint8_t *)c->d_sflag, (const uint32_t *)fpos, (const uint32_t *)c->d_gsa, (const uint32_t *)c->d_wordid, dsize, (uint32_t)dwords,
+        PFP_LAUNCH(c, K_WORD_RANK, dsize + dwords * 24, k_word_rank_flags, nt, (const uint8_t *)c->d_sflag, (const uint32_t *)tbase, (const uint32_t *)c->d_gsa, (const uint32_t *)c->d_wordid, dsize, (uint32_t)dwords,
                    occw, c->d_wrank, idofrank, c->d_occ);
         c->arena.release_hi(mkf);
     }

@@ -634,7 +634,7 @@ template <bool DICT, int K> inline int suffix_sort_round(pfp_ctx *c, RoundBufs &
             PFP_LAUNCH(c, K_SS_MAKE_KEYS, nl * 20, k_gather_keys, gl, (const uint64_t *)ka, (const uint32_t *)lsv, nl, lsk);
             alk = lsk == b.k0 ? b.k1 : b.k0; alv = lsv == b.v0 ? b.v1 : b.v0;
         } else PFP_LAUNCH(c, K_SS_MAKE_KEYS, nl * 20, k_copy_keys_iota, gl, (const uint64_t *)ka, nl, b.k0, b.v0);
-        BitRange rr = {0, lowbits + rbits};
+        BitRange rr = {0, lowbits + rbits};      // (skipping the digits that are equal in all keys was tried: the classes of a large range differ in a byte or two of the class part, one pass of eight saved on S-chr22 for a reduction kernel + a host round trip: no gain)
         uint64_t *fsk; uint32_t *fsv;
         PFP_TRY(radix_sort_pairs<uint64_t>(c, lsk, lsv, alk, alv, nl, &rr, 1, &fsk, &fsv));
         PFP_LAUNCH(c, K_SS_HEADS, nl * 12, k_round_subset_heads, gl, (const uint64_t *)fsk, (const uint64_t *)kb, (const uint32_t *)fsv, nl, b.head);
