@@ -96,7 +96,7 @@ static void reset_results(pfp_ctx *c)
 
 // ---- route / tuning switches (pfbwt_hip_dev.h) -----------------------------------------------------
 static const char *const tunable_names[] = {"verbose", "seg_grid", "seg_stage", "sort_k", "sort_no_table", "class_sort_maxrange", "dedup_table_log2", "no_trigger_table",
-                                            "emit_chunk_rows", "fill_subs", "sample_cap", "no_runaware", "big_group_members", "force_wide_rows", "fasta_chunk_bytes", "ingest_block_bytes", "emit_group_rows", "no_slot_records", "dict_text_rounds"};
+                                            "emit_chunk_rows", "fill_subs", "sample_cap", "no_runaware", "big_group_members", "force_wide_rows", "fasta_chunk_bytes", "ingest_block_bytes", "emit_group_rows", "no_slot_records", "dict_text_rounds", "int_key_symbols"};
 static int set_tunable(pfp_ctx *c, const char *key, long long v)
 {
     Tunables &t = c->tun;
@@ -119,6 +119,7 @@ static int set_tunable(pfp_ctx *c, const char *key, long long v)
     else if (!strcmp(key, "emit_group_rows")) t.emit_group_rows = v > 0 ? (uint32_t)v : 0u;
     else if (!strcmp(key, "no_slot_records")) t.no_slot_records = (int)v;
     else if (!strcmp(key, "dict_text_rounds")) t.dict_text_rounds = (int)v;
+    else if (!strcmp(key, "int_key_symbols")) t.int_key_symbols = (int)v;
     else return PFP_E_ARG;
     return PFP_OK;
 }
@@ -1280,9 +1281,10 @@ static int sort_int_suffixes(pfp_ctx *c, const uint32_t *dS, uint64_t N, uint64_
     PFP_ALLOC_HI(c, k0, uint64_t, N); PFP_ALLOC_HI(c, k1, uint64_t, N);
     PFP_ALLOC_HI(c, v0, uint32_t, N); PFP_ALLOC_HI(c, v1, uint32_t, N);
     const int sb = bits_for(maxsym);
-    PFP_LAUNCH(c, K_SS_INIT_KEYS, N * 16, k_int_init_keys, nblocks(N, BLOCK), dS, N, sb, k0, v0);
-    BitRange rr = {0, 2 * sb};
-    PFP_TRY(suffix_sort_doubling<false>(c, N, k0, v0, k1, v1, &rr, 1, 2, (const uint8_t *)nullptr, SA, rank, (uint2 *)nullptr, rounds));
+    const int nsym = (c->tun.int_key_symbols == 3 && 3 * sb <= 64) ? 3 : 2;
+    PFP_LAUNCH(c, K_SS_INIT_KEYS, N * 16, k_int_init_keys, nblocks(N, BLOCK), dS, N, sb, nsym, k0, v0);
+    BitRange rr = {0, nsym * sb};
+    PFP_TRY(suffix_sort_doubling<false>(c, N, k0, v0, k1, v1, &rr, 1, (uint32_t)nsym, (const uint8_t *)nullptr, SA, rank, (uint2 *)nullptr, rounds));
     c->arena.release_hi(mk);
     return PFP_OK;
 }

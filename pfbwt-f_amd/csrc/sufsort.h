@@ -76,11 +76,13 @@ __global__ __launch_bounds__(BLOCK) void k_dict_init_keys_any(const uint8_t *D, 
 }
 
 // parse keys: (S[x], S[x+1]) with S = ranks + [0]  (pfparser.hpp:407-410)
-__global__ __launch_bounds__(BLOCK) void k_int_init_keys(const uint32_t *S, uint64_t N, int symbits, uint64_t *keys, uint32_t *vals)
+__global__ __launch_bounds__(BLOCK) void k_int_init_keys(const uint32_t *S, uint64_t N, int symbits, int nsym, uint64_t *keys, uint32_t *vals)
 {
     const uint64_t x = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (x >= N) return;
-    keys[x] = ((uint64_t)S[x] << symbits) | (x + 1 < N ? S[x + 1] : 0u);      // packed tightly: 2 * symbits key bits (5 radix passes for 20-bit symbols, not 6)
+    uint64_t k = ((uint64_t)S[x] << symbits) | (x + 1 < N ? S[x + 1] : 0u);      // packed tightly: 2 * symbits key bits (5 radix passes for 20-bit symbols, not 6)
+    if (nsym == 3) k = (k << symbits) | (x + 2 < N ? S[x + 2] : 0u);             // three symbols where they fit 64 bits
+    keys[x] = k;
     vals[x] = (uint32_t)x;
 }
 
