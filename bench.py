@@ -473,7 +473,8 @@ def main():
         total_ms = sum(r["ms"] for r in warm_rows)
         traffic = None
         try:   # HBM bytes per launch from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/)
-            pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")))
+            per_wl = os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % a.workload)      # per-workload passes (tools/gpu_final.sh); pmc_traffic_latest.json = the default workload's
+            pt = json.load(open(per_wl if os.path.exists(per_wl) else os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")))
             prefix = KERNEL_SYMBOL.get(dominant, "pfp::k_" + dominant)
             cand = [rec for kname, rec in pt.items() if prefix in kname and pt.get("_workload") == a.workload]
             if cand:       # FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md + WRITE_SIZE (tools/pmc_traffic.py keeps the raw sum too);

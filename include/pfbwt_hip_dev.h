@@ -27,7 +27,8 @@ int pfp_stage_ms(pfp_ctx *ctx, double out[3]);
  *   emit_chunk_rows, fill_subs, sample_cap (< 0: none), no_runaware, big_group_members (< 0: never), force_wide_rows,
  *   fasta_chunk_bytes, ingest_block_bytes, emit_group_rows (0: no group-stationary emission of the special rows; small: most groups left to the row-wise kernel),
  *   no_slot_records (per-slot fields by two gathers: the route of dictionaries with words of 64 Mbase and more),
- *   dict_text_rounds (-1 auto | 0 rank-based dictionary sort only | 1 text rounds forced), int_key_symbols (2 | 3: parse symbols in the initial sort key).
+ *   dict_text_rounds (-1 auto | 0 rank-based dictionary sort only | 1 text rounds forced), int_key_symbols (2 | 3: parse symbols in the initial sort key),
+ *   force_run_round (the run round of the dictionary sort even without a long run).
  * Returns PFP_E_ARG for an unknown key.  In a process started with PFP_TEST_HOOKS=1 pfp_create presets a new context from the
  * environment variables PFP_<KEY IN UPPER CASE>; without PFP_TEST_HOOKS=1 the environment is ignored (PFP_VERBOSE excepted,
  * which only prints). */

@@ -99,6 +99,7 @@ struct Tunables {
     uint64_t ingest_block_bytes = 0;   // block size of the file reader (0: 64 MiB)
     uint32_t emit_group_rows = 4096;   // rows per batch of the group-stationary emission of the special rows (0: every special row through k_emit; smaller: more groups left to k_emit)
     int dict_text_rounds = -1;         // dictionary suffix sort by text rounds: -1 = when the collection is not repetitive (dictionary > text / 8), 0 never, 1 always
+    int force_run_round = 0;           // the run round of the dictionary sort even without a run of 256 equal bytes (tests)
     int int_key_symbols = 3;           // symbols of the parse in the initial sort key: 3 where 3 x symbol bits <= 64 (S-32G: 21-bit symbols, 8 radix passes instead of 6, one refinement round less to pay for: parse BWT 135.7 -> 131.9 ms), else 2
     int no_slot_records = 0;           // k_emit_slots by two gathers (word id | preceding byte, then the word record): the route of dictionaries with words of 64 Mbase and more
     uint64_t fasta_chunk_bytes = 0;    // size of the raw-FASTA device buffers (0: 1 MiB ... 256 MiB by the size of the first call)

@@ -96,7 +96,7 @@ static void reset_results(pfp_ctx *c)
 
 // ---- route / tuning switches (pfbwt_hip_dev.h) -----------------------------------------------------
 static const char *const tunable_names[] = {"verbose", "seg_grid", "seg_stage", "sort_k", "sort_no_table", "class_sort_maxrange", "dedup_table_log2", "no_trigger_table",
-                                            "emit_chunk_rows", "fill_subs", "sample_cap", "no_runaware", "big_group_members", "force_wide_rows", "fasta_chunk_bytes", "ingest_block_bytes", "emit_group_rows", "no_slot_records", "dict_text_rounds", "int_key_symbols"};
+                                            "emit_chunk_rows", "fill_subs", "sample_cap", "no_runaware", "big_group_members", "force_wide_rows", "fasta_chunk_bytes", "ingest_block_bytes", "emit_group_rows", "no_slot_records", "dict_text_rounds", "int_key_symbols", "force_run_round"};
 static int set_tunable(pfp_ctx *c, const char *key, long long v)
 {
     Tunables &t = c->tun;
@@ -120,6 +120,7 @@ static int set_tunable(pfp_ctx *c, const char *key, long long v)
     else if (!strcmp(key, "no_slot_records")) t.no_slot_records = (int)v;
     else if (!strcmp(key, "dict_text_rounds")) t.dict_text_rounds = (int)v;
     else if (!strcmp(key, "int_key_symbols")) t.int_key_symbols = (int)v;
+    else if (!strcmp(key, "force_run_round")) t.force_run_round = (int)v;
     else return PFP_E_ARG;
     return PFP_OK;
 }

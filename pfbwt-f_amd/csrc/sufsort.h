@@ -107,6 +107,18 @@ __global__ __launch_bounds__(BLOCK) void k_ss_runend_marks(const uint8_t *D, uin
     g[ip] = (x + 1 == N || D[x] != D[x + 1]) ? (uint32_t)ip : 0u;
 }
 
+// longest run of equal bytes (from the scanned run-end marks M): without a long run the run round is skipped -- it is a K = 1 round
+// for every suffix that is not inside a run, i.e. on a dictionary without runs it only delays the quadrupling rounds
+__global__ __launch_bounds__(BLOCK) void k_max_run_length(const uint32_t *M, uint64_t N, uint32_t *out)
+{
+    __shared__ uint32_t red[4];
+    const uint64_t ip = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    uint32_t tot;
+    (void)block_incl_max(ip < N ? (uint32_t)ip - M[ip] + 1u : 0u, red, &tot);
+    if (threadIdx.x == 0) atomicMax(out, tot);
+}
+constexpr uint32_t RUN_ROUND_MIN_RUN = 256;      // a run of d equal bytes costs ~log2(d / 16) extra doubling rounds for its few suffixes; the run round costs one K = 1 round for ALL
+
 // ---- state of the refinement -------------------------------------------------------------------------------------
 //   SA[slot] = x                          suffixes in the order found so far; a class = a contiguous range of slots
 //   int alphabet:  rank[x]                slot of the head of x's class (jumps are uniform there: the suffix one covered
@@ -705,6 +717,11 @@ template <bool DICT> inline int suffix_sort_doubling(pfp_ctx *c, uint64_t N, uin
             PFP_ALLOC_HI(c, b.M, uint32_t, N);
             PFP_LAUNCH(c, K_SS_MAKE_KEYS, N * 5, k_ss_runend_marks, gN, D, N, b.M);
             PFP_TRY((device_scan<uint32_t, 1>(c, b.M, b.M, N, nullptr)));
+            uint32_t maxrun = 0;
+            PFP_HIP(c, hipMemsetAsync(b.d_cnt + 1, 0, 4, c->stream));
+            PFP_LAUNCH(c, K_SS_MAKE_KEYS, N * 4, k_max_run_length, gN, (const uint32_t *)b.M, N, b.d_cnt + 1);
+            PFP_TRY(d2h_u32(c, b.d_cnt + 1, &maxrun));
+            if (maxrun < RUN_ROUND_MIN_RUN && !c->tun.force_run_round) b.M = nullptr;      // no run round
         }
         // k0 / v0 / k1 / v1 are free from here on: scratch of the large-class route
         b.k0 = k0; b.k1 = k1; b.v0 = v0; b.v1 = v1;

@@ -163,7 +163,7 @@ print("variant ok")
 
 @pytest.mark.parametrize("env", [{"PFP_FORCE_WIDE_ROWS": "1"}, {"PFP_FORCE_WIDE_ROWS": "1", "PFP_EMIT_CHUNK_ROWS": "1000"},
                                  {"PFP_EMIT_CHUNK_ROWS": "777", "PFP_SAMPLE_CAP": "40"},
-                                 {"PFP_EMIT_GROUP_ROWS": "0", "PFP_NO_SLOT_RECORDS": "1"}, {"PFP_DICT_TEXT_ROUNDS": "0", "PFP_INT_KEY_SYMBOLS": "2"}, {"PFP_DICT_TEXT_ROUNDS": "1", "PFP_CLASS_SORT_MIN": "1", "PFP_CLASS_SORT_MAXRANGE": "150"}, {"PFP_EMIT_GROUP_ROWS": "4096", "PFP_EMIT_CHUNK_ROWS": "1500"}, {"PFP_EMIT_GROUP_ROWS": "12", "PFP_EMIT_CHUNK_ROWS": "900", "PFP_FORCE_WIDE_ROWS": "1"},
+                                 {"PFP_EMIT_GROUP_ROWS": "0", "PFP_NO_SLOT_RECORDS": "1"}, {"PFP_DICT_TEXT_ROUNDS": "0", "PFP_INT_KEY_SYMBOLS": "2", "PFP_FORCE_RUN_ROUND": "1"}, {"PFP_DICT_TEXT_ROUNDS": "1", "PFP_CLASS_SORT_MIN": "1", "PFP_CLASS_SORT_MAXRANGE": "150"}, {"PFP_EMIT_GROUP_ROWS": "4096", "PFP_EMIT_CHUNK_ROWS": "1500"}, {"PFP_EMIT_GROUP_ROWS": "12", "PFP_EMIT_CHUNK_ROWS": "900", "PFP_FORCE_WIDE_ROWS": "1"},
                                  {"PFP_DEDUP_TABLE_LOG2": "4", "PFP_NO_TRIGGER_TABLE": "1", "PFP_NO_RUNAWARE": "1"},
                                  {"PFP_BIG_GROUP_MEMBERS": "1", "PFP_CLASS_SORT_MIN": "1"},
                                  {"PFP_BIG_GROUP_MEMBERS": "2", "PFP_EMIT_CHUNK_ROWS": "5000", "PFP_CLASS_SORT_MIN": "1", "PFP_CLASS_SORT_MAXRANGE": "150"},

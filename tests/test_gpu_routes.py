@@ -60,7 +60,7 @@ ENVS = [
     {"PFP_DEDUP_TABLE_LOG2": "6", "PFP_NO_TRIGGER_TABLE": "1"},      # the phrase table overflows and is rebuilt; the trigger test by hashing every window
     {"PFP_NO_RUNAWARE": "1", "PFP_EMIT_CHUNK_ROWS": "30000"},       # -r with every row enumerated (the route a full SA takes)
     {"PFP_EMIT_GROUP_ROWS": "0", "PFP_EMIT_CHUNK_ROWS": "50000", "PFP_NO_SLOT_RECORDS": "1"},
-    {"PFP_DICT_TEXT_ROUNDS": "0", "PFP_INT_KEY_SYMBOLS": "2"},                                  # dictionary suffix sort: rank-based rounds only
+    {"PFP_DICT_TEXT_ROUNDS": "0", "PFP_INT_KEY_SYMBOLS": "2", "PFP_FORCE_RUN_ROUND": "1"},                                  # dictionary suffix sort: rank-based rounds only
     {"PFP_DICT_TEXT_ROUNDS": "1", "PFP_CLASS_SORT_MAXRANGE": "150"},   # text rounds forced (given up on repetitive inputs: second sort), large classes through the global sort   # special rows: all through the row-wise kernel (the group-stationary kernel off)
     {"PFP_EMIT_GROUP_ROWS": "40", "PFP_EMIT_CHUNK_ROWS": "20000", "PFP_FORCE_WIDE_ROWS": "1"},   # batches of at most 40 rows: most groups are left to the row-wise kernel, the rest goes through LDS
 ]
