@@ -351,7 +351,8 @@ __device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t *a, uint32_t 
 // per row.  Their rows are instead collected as (group head slot, q) keys, sorted, and placed by their index inside
 // the group.  Groups with a whole-word member keep the ranking route (reference quirk handling lives there).
 template <typename EBT> __global__ __launch_bounds__(BLOCK) void k_big_mark(const EBT *cnt, const uint32_t *s_g0, const uint32_t *gk, const uint8_t *gfl, const uint8_t *gnu, const uint32_t *s_fb, const uint32_t *ilist, uint64_t dsize, uint32_t min_members,
-                                                                            int runaware, uint8_t *s_fl, uint4 *sinfo, EBT *cnt2 /*runaware: rows of the special slots*/, uint32_t *gqf, uint32_t *gql, unsigned long long *big_rows)
+                                                                            int runaware, uint8_t *s_fl, uint4 *sinfo, EBT *cnt2 /*runaware: rows of the special slots*/, uint32_t *gqf, uint32_t *gql, unsigned long long *big_rows,
+                                                                            const EBT *EB /*exclusive scan of cnt*/, const EBT *total, uint32_t max_rows /*0: no limit; else groups of more rows take the sort route*/)
 {
     __shared__ unsigned long long red[4];
     const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -367,7 +368,12 @@ template <typename EBT> __global__ __launch_bounds__(BLOCK) void k_big_mark(cons
             else {
                 if (gnu[g0]) fl |= SF_NONUNI;
                 // without a full SA only the groups that are not one run of a byte are merged at all
-                if (k > min_members && (!runaware || (fl & SF_NONUNI))) { fl |= SF_BIG; mine = (unsigned long long)cnt[i]; }
+                bool big = k > min_members;
+                if (!big && max_rows && (fl & SF_NONUNI)) {
+                    const uint64_t grows = (uint64_t)(g0 + k < dsize ? EB[g0 + k] : *total) - (uint64_t)EB[g0];
+                    big = grows > (uint64_t)max_rows;
+                }
+                if (big && (!runaware || (fl & SF_NONUNI))) { fl |= SF_BIG; mine = (unsigned long long)cnt[i]; }
             }
             s_fl[i] = fl;
         }

@@ -1755,9 +1755,12 @@ template <typename EBT> static int emit_stage(pfp_ctx *c, EmitArgs ea, int want_
     }
     uint4 *sinfo; PFP_ALLOC_HI(c, sinfo, uint4, dsize); ea.sinfo = sinfo;
     const long big_members = c->tun.big_group_members == -2 ? (long)BIG_GROUP_MEMBERS : c->tun.big_group_members;   // < 0: never
-    PFP_LAUNCH(c, K_EMIT_COUNT, dsize * 14, (k_big_mark<EBT>), nblocks(dsize, BLOCK), (const EBT *)cnt, (const uint32_t *)s_g0, (const uint32_t *)gk, (const uint8_t *)gfl, (const uint8_t *)gnu, (const uint32_t *)ea.s_fb, ea.ilist, dsize,
-               big_members >= 0 ? (uint32_t)big_members : 0xFFFFFFFFu, runaware ? 1 : 0, (uint8_t *)ea.s_fl, sinfo, cnt2, gqf, gql, d_hard + 1);
     PFP_TRY((device_scan<EBT, 0>(c, cnt, EB, dsize, d_tot)));
+    // run-aware: a group of more rows than k_emit_groups_large holds in LDS takes the sort route too (S-32G: 1.4 M rows in groups of 16-64 K
+    // rows and ~100 members were ranked row by row in memory by k_emit: 9 ms)
+    const uint32_t big_rows = !(runaware && big_members >= 0 && c->tun.emit_group_rows) ? 0u : c->tun.emit_group_rows >= (uint32_t)EG_BUF ? (uint32_t)EG2_BUF : 4u * c->tun.emit_group_rows;      // (tests: small batches -> small limit)
+    PFP_LAUNCH(c, K_EMIT_COUNT, dsize * 14, (k_big_mark<EBT>), nblocks(dsize, BLOCK), (const EBT *)cnt, (const uint32_t *)s_g0, (const uint32_t *)gk, (const uint8_t *)gfl, (const uint8_t *)gnu, (const uint32_t *)ea.s_fb, ea.ilist, dsize,
+               big_members >= 0 ? (uint32_t)big_members : 0xFFFFFFFFu, runaware ? 1 : 0, (uint8_t *)ea.s_fl, sinfo, cnt2, gqf, gql, d_hard + 1, (const EBT *)EB, (const EBT *)d_tot, big_rows);
     EBT tot = 0; unsigned long long hardrows = 0, hh[2] = {0, 0};
     PFP_HIP(c, hipMemcpyAsync(hh, d_hard, 16, hipMemcpyDeviceToHost, c->stream));
     PFP_HIP(c, hipMemcpyAsync(&tot, d_tot, sizeof(EBT), hipMemcpyDeviceToHost, c->stream));

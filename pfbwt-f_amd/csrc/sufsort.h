@@ -112,10 +112,14 @@ __global__ __launch_bounds__(BLOCK) void k_ss_runend_marks(const uint8_t *D, uin
 __global__ __launch_bounds__(BLOCK) void k_max_run_length(const uint32_t *M, uint64_t N, uint32_t *out)
 {
     __shared__ uint32_t red[4];
-    const uint64_t ip = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    // 16 positions per thread; a workgroup touches the result only when it would raise it (one atomic per workgroup on one address cost
+    // 150 ms over the 3.4 G positions of S-3G)
+    const uint64_t i0 = ((uint64_t)blockIdx.x * BLOCK + threadIdx.x) * 16;
+    uint32_t mx = 0;
+    for (int k = 0; k < 16; ++k) { const uint64_t ip = i0 + k; if (ip < N) { const uint32_t d = (uint32_t)ip - M[ip] + 1u; mx = d > mx ? d : mx; } }
     uint32_t tot;
-    (void)block_incl_max(ip < N ? (uint32_t)ip - M[ip] + 1u : 0u, red, &tot);
-    if (threadIdx.x == 0) atomicMax(out, tot);
+    (void)block_incl_max(mx, red, &tot);
+    if (threadIdx.x == 0 && tot > *(volatile uint32_t *)out) atomicMax(out, tot);
 }
 constexpr uint32_t RUN_ROUND_MIN_RUN = 256;      // a run of d equal bytes costs ~log2(d / 16) extra doubling rounds for its few suffixes; the run round costs one K = 1 round for ALL
 
@@ -719,7 +723,7 @@ template <bool DICT> inline int suffix_sort_doubling(pfp_ctx *c, uint64_t N, uin
             PFP_TRY((device_scan<uint32_t, 1>(c, b.M, b.M, N, nullptr)));
             uint32_t maxrun = 0;
             PFP_HIP(c, hipMemsetAsync(b.d_cnt + 1, 0, 4, c->stream));
-            PFP_LAUNCH(c, K_SS_MAKE_KEYS, N * 4, k_max_run_length, gN, (const uint32_t *)b.M, N, b.d_cnt + 1);
+            PFP_LAUNCH(c, K_SS_MAKE_KEYS, N * 4, k_max_run_length, nblocks(N, 16 * BLOCK), (const uint32_t *)b.M, N, b.d_cnt + 1);
             PFP_TRY(d2h_u32(c, b.d_cnt + 1, &maxrun));
             if (maxrun < RUN_ROUND_MIN_RUN && !c->tun.force_run_round) b.M = nullptr;      // no run round
         }
