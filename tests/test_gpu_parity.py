@@ -173,6 +173,29 @@ def test_chr22_full_size_vs_oracle(gpu_ctx_factory):
     c.close()
 
 
+def test_text_range_grows_and_moves(gpu_ctx_factory):
+    """A text fed record by record without an announced size outgrows its first address range (64 MiB) and is MOVED to a larger
+    one (ensure_text, csrc/pfbwt_hip.hip): eight records of 9 Mbase, a panel of one sequence with variants; -r outputs == the oracle's.
+    (The move path is not reachable by the small inputs of the other tests.)"""
+    import hashlib, sys
+    sys.path.insert(0, ROOT)
+    import bench
+    seqs = bench.synth_seqs(9_000_000, 8, 4242, (0, 0, 0, 0))
+    _, dig = bench.cpu_baseline(seqs, 10, 100, True, mode=("-r",))
+    c = gpu_ctx_factory(w=10, p=100, u64=True, sai=True)
+    c.feed(b"ACGT" * 5, True)          # a first feed of a few bytes: the range starts at its minimum size
+    c.reset()
+    for s in seqs:
+        c.feed(s, True)
+    c.finalize(); c.parse_bwt(); c.bwt_build(sa=False, rssa=True)
+    o = c.bwt_get()
+    for k in ("bwt", "ssa", "esa"):
+        assert hashlib.sha256(o[k].tobytes()).hexdigest() == dig[k], k
+    chk = c.check_sample_order()
+    assert chk["order_violations"] == 0 and chk["rows_not_adjacent"] == 0, chk
+    c.close()
+
+
 def test_sample_order_check_detects_disorder(gpu_ctx_factory):
     """the device-side order check is not vacuous: the same samples checked against a DIFFERENT text (same length) report violations"""
     seqs = synth(77, 300_000, 3)
