@@ -160,6 +160,7 @@ struct EmitArgs {
     const uint4 *prec;      // nullable: per dictionary offset { unused, first ilist index of its word, occ of its word, suffix length | code of the preceding byte << 26 | whole word << 30 | inside a word << 31 }
     const uint32_t *wordid; // per dictionary offset: word id
     int use_prec;
+    int use_e0;             // full SA wanted, positions fit 32 bits: prec.x = bwsai of a word's occurrence where the word occurs once (carried to the rows through s_g0 / sinfo.z)
     const uint4 *winfo;     // per word id: { first byte, offset of its EndOfWord, first ilist index F[rank], occ[rank] }
     const uint8_t *bwlast;
     const uint8_t *bwl_il;  // nullable: bwlast in ilist order
@@ -199,7 +200,7 @@ struct EmitArgs {
     uint32_t *lglist; unsigned long long *lgcount; uint64_t lgcap; int qpasses /*8-bit digits that hold a parse row*/;   // groups of more rows than a batch holds, taken one per workgroup by k_emit_groups_large (heads as indices of special slots)
     unsigned long long *gstat;   // PFP_VERBOSE: rows left to k_emit by reason [0] whole-word member, [1] sort route, [2] too many rows, [3] too many slots; [4..11] rows of left groups by log4 of the group's rows
 };
-constexpr uint8_t SF_MULTI = 1, SF_FULL = 2, SF_BIG = 4, SF_GFULL = 8, SF_NONUNI = 16;   // GFULL: some member of the group is a whole word; NONUNI: members with different preceding bytes
+constexpr uint8_t SF_MULTI = 1, SF_FULL = 2, SF_BIG = 4, SF_GFULL = 8, SF_NONUNI = 16, SF_E0 = 32;   // E0: a one-member slot of a word that occurs once -- s_g0 / sinfo.z hold bwsai of that occurrence (texts < 2^32), not a head slot   // GFULL: some member of the group is a whole word; NONUNI: members with different preceding bytes
 __device__ __forceinline__ bool slot_is_special(uint32_t fl) { return (fl & (SF_FULL | SF_GFULL | SF_NONUNI)) != 0; }
 constexpr uint32_t BIG_GROUP_MEMBERS = 64;  // groups with more members than this take the sort route (measured: below ~64 ranking is faster)
 // posinfo[x] = { word id of dictionary offset x | 4-bit code of D[x-1] << 28 , class-head slot of x }: one 8-byte
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(BLOCK) void k_pack_posinfo(const uint8_t *D, const 
 // winfo[word of x]) -- on a non-repetitive text (S-3G: 3.4 G slots) that chain was 166 ms.  Suffix lengths must fit 26 bits
 // (words of 64 Mbase and more: the caller keeps the two-gather route).
 constexpr uint32_t PREC_SL_BITS = 26, PREC_FULL = 1u << 30, PREC_VALID = 1u << 31;
-__global__ __launch_bounds__(BLOCK) void k_pack_prec(const uint8_t *D, const uint32_t *wordid, const uint4 *winfo, uint64_t dsize, uint32_t dwords, uint4 *prec)
+__global__ __launch_bounds__(BLOCK) void k_pack_prec(const uint8_t *D, const uint32_t *wordid, const uint4 *winfo, uint64_t dsize, uint32_t dwords, uint4 *prec, const tpos_t *bwsai_il /*nullable*/)
 {
     const uint64_t x = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (x >= dsize) return;
@@ -238,6 +239,7 @@ __global__ __launch_bounds__(BLOCK) void k_pack_prec(const uint8_t *D, const uin
         if ((uint32_t)x == W.x) full = PREC_FULL;
         else { code = dict_code4(D[x - 1]); if (code == Dollar && (uint32_t)x - 1u == W.x) code = 0; }      // pfbwt.hpp:132 "gsa[i]-1 ? dict[..] : 0"
         R.y = W.z; R.z = W.w; R.w = (W.y - (uint32_t)x) | (code << PREC_SL_BITS) | full | PREC_VALID;
+        if (bwsai_il && W.w == 1u) R.x = (uint32_t)bwsai_il[W.z];      // the word occurs once: the text position its rows' SA values count from (one read per word: consecutive offsets share it)
     }
     prec[x] = R;
 }
@@ -306,6 +308,7 @@ template <typename EBT> __global__ __launch_bounds__(BLOCK) void k_emit_slots(Em
                 c = R.z; fb = R.y;
                 if (!hd[threadIdx.x] || (i + 1 < a.dsize && !hd[threadIdx.x + 1])) fl |= SF_MULTI;   // group of >= 2 equal suffixes (pfbwt.hpp:137)
                 if (R.w & PREC_FULL) fl |= SF_FULL; else pc = dict_byte4((R.w >> PREC_SL_BITS) & 15u);
+                if (a.use_e0 && c == 1u && !(fl & SF_MULTI)) { fl |= SF_E0; P.y = R.x; }      // s_g0 of such a slot is never asked for a head
             }
         }
     } else {
@@ -517,7 +520,7 @@ template <typename EBT> __device__ __forceinline__ uint64_t multi_group_pos(cons
     uint64_t before = 0;
     uint32_t first_rk = rk, first_before = 0, first_occ = a.winfo[idi].w; bool first_full = self_full;
     for (uint32_t s = g0; s < a.dsize; ++s) {
-        if (a.s_g0[s] != g0) break;
+        if (!(a.s_fl[s] & SF_MULTI) || a.s_g0[s] != g0) break;      // (s_g0 of a one-member slot may hold a text position, SF_E0)
         if (s == i) continue;
         const uint32_t xs = a.SA[s];
         const uint32_t ids = a.wordid[xs];
@@ -661,7 +664,7 @@ template <typename SAT, typename EBT> __global__ __launch_bounds__(BLOCK) void k
             q[u] = needq ? a.ilist[S[u].x + r[u]] : 0u;
         }
 #pragma unroll
-        for (int u = 0; u < EMIT_ROWS_IN_FLIGHT; ++u) sv[u] = (sa && on[u] && !(fl[u] & SF_BIG)) ? (a.bwsai_il ? (uint64_t)a.bwsai_il[S[u].x + r[u]] : (uint64_t)a.bwsai[q[u]]) : 0ULL;
+        for (int u = 0; u < EMIT_ROWS_IN_FLIGHT; ++u) sv[u] = (sa && on[u] && !(fl[u] & SF_BIG)) ? ((fl[u] & SF_E0) ? (uint64_t)S[u].z : a.bwsai_il ? (uint64_t)a.bwsai_il[S[u].x + r[u]] : (uint64_t)a.bwsai[q[u]]) : 0ULL;
         // rows in ordinary multi-member groups: the bisections of all rows in flight run in one loop (EMIT_RANK_W lists per
         // row at a time), so that a thread has EMIT_ROWS_IN_FLIGHT * EMIT_RANK_W dependent-load chains going instead of one
         uint32_t before[EMIT_ROWS_IN_FLIGHT], gk_[EMIT_ROWS_IN_FLIGHT], maxk = 0;
@@ -1000,13 +1003,13 @@ template <typename EBT> __global__ __launch_bounds__(BLOCK) void k_slice_bounds(
     const EBT *EB = reinterpret_cast<const EBT *>(a.EB);
     const EBT *ENB = reinterpret_cast<const EBT *>(a.ENB);
     const uint32_t il = slot_of_row<EBT>(a, lo);
-    const uint32_t gh = a.s_g0[il];
+    const uint32_t gh = (a.s_fl[il] & SF_MULTI) ? a.s_g0[il] : il;
     out[0] = EB[gh];
     out[2] = a.special ? (unsigned long long)ENB[a.cpos[gh]] : 0ULL;      // the same range in the enumeration of the special rows
     if (hi >= a.nout) { out[1] = a.nout; out[3] = a.special ? (unsigned long long)ENB[a.ecount] : 0ULL; return; }
     uint32_t s = slot_of_row<EBT>(a, hi - 1);
-    const uint32_t g = a.s_g0[s];
-    while (s < a.dsize && a.s_g0[s] == g) ++s;
+    if (a.s_fl[s] & SF_MULTI) { const uint32_t g = a.s_g0[s]; while (s < a.dsize && (a.s_fl[s] & SF_MULTI) && a.s_g0[s] == g) ++s; }
+    else ++s;
     {   // first slot at or behind s whose rows start at or behind hi: EB never decreases (slots that produce no rows -- dictionary
         // suffixes of length <= w come in clusters of millions -- repeat the next one's value), so this is a bisection, not a walk
         uint64_t lo_ = s, hi_ = a.dsize;

@@ -1483,12 +1483,6 @@ template <typename SAT, typename EBT> static int emit_and_sample(pfp_ctx *c, Emi
     const bool keep_sa = want_sa;                          // a full SA array for this slice lives in the arena
     SAT *sabuf = nullptr;
     if (keep_sa) PFP_ALLOC_LO(c, sabuf, SAT, nrows + lead);
-    ea.bwsai_il = nullptr;
-    if (keep_sa && c->d_bwsai && c->nrows) {      // bwsai in ilist order: one gather per parse row here instead of a second dependent gather per OUTPUT row
-        tpos_t *E; PFP_ALLOC_HI(c, E, tpos_t, c->nrows);
-        PFP_LAUNCH(c, K_MISC, c->nrows * 20, k_bwsai_by_ilist, nblocks(c->nrows, BLOCK), (const uint32_t *)c->d_ilist, (const tpos_t *)c->d_bwsai, c->nrows, E);
-        ea.bwsai_il = E;
-    }
     c->d_sa = sabuf ? sabuf + lead : nullptr;
     c->d_ssa = c->d_esa = nullptr;
     unsigned long long *d_b; PFP_ALLOC_HI(c, d_b, unsigned long long, 6);
@@ -1742,7 +1736,7 @@ template <typename EBT> static int emit_stage(pfp_ctx *c, EmitArgs ea, int want_
         const size_t mkp = c->arena.mark_hi();
         if (ea.use_prec) {
             uint4 *prec; PFP_ALLOC_HI(c, prec, uint4, dsize);
-            PFP_LAUNCH(c, K_EMIT_COUNT, dsize * 29, k_pack_prec, nblocks(dsize, BLOCK), ea.D, ea.wordid, ea.winfo, dsize, ea.dwords, prec);
+            PFP_LAUNCH(c, K_EMIT_COUNT, dsize * 29, k_pack_prec, nblocks(dsize, BLOCK), ea.D, ea.wordid, ea.winfo, dsize, ea.dwords, prec, ea.use_e0 ? ea.bwsai_il : (const tpos_t *)nullptr);
             ea.prec = prec;
         } else {
             uint2 *posinfo; PFP_ALLOC_HI(c, posinfo, uint2, dsize);
@@ -1878,6 +1872,13 @@ static int bwt_build_body(pfp_ctx *c, int want_sa, int want_rssa, int slice, int
         PFP_HIP(c, hipMemsetAsync(d_ml, 0, 4, c->stream));
         PFP_LAUNCH(c, K_MISC, dwords * 4, k_max_word_length, nblocks(dwords, BLOCK), (const uint32_t *)c->d_ws, dwords, d_ml);
         PFP_TRY(d2h_u32(c, d_ml, &maxlen));
+    }
+    ea.bwsai_il = nullptr; ea.use_e0 = 0;
+    if (want_sa && c->d_bwsai && c->nrows) {      // bwsai in ilist order: one gather per parse row here instead of a second dependent gather per OUTPUT row
+        tpos_t *E; PFP_ALLOC_HI(c, E, tpos_t, c->nrows);
+        PFP_LAUNCH(c, K_MISC, c->nrows * 20, k_bwsai_by_ilist, nblocks(c->nrows, BLOCK), (const uint32_t *)c->d_ilist, (const tpos_t *)c->d_bwsai, c->nrows, E);
+        ea.bwsai_il = E;
+        ea.use_e0 = (c->n != 0 && c->n + (uint64_t)c->w + 2 < 0xFFFFFFFFULL && !c->tun.no_slot_records) ? 1 : 0;      // positions fit the 32 bits of prec.x / s_g0
     }
     ea.posinfo = nullptr; ea.prec = nullptr; ea.wordid = c->d_wordid; ea.use_prec = (maxlen < (1u << PREC_SL_BITS) && !c->tun.no_slot_records) ? 1 : 0;
     ea.EB = nullptr; ea.s_sl = s_sl; ea.s_fb = s_fb; ea.s_fl = s_fl; ea.s_pc = s_pc; ea.nout = 0; ea.n = 0; ea.e0 = ea.e1 = ea.w0 = ea.w1 = 0;
