@@ -20,13 +20,13 @@ __device__ __forceinline__ uint32_t dict_code(uint32_t c)
     return c <= 2 ? c : (c == '-') ? 3u : (c == 'A') ? 4u : (c == 'C') ? 5u : (c == 'G') ? 6u : (c == 'N') ? 7u : 8u;
 }
 
-constexpr int DK_CHARS = 16;          // characters per initial key
+constexpr int DK_CHARS = 17;          // characters per initial key: 9^17 < 2^54 still sorts in seven 8-bit passes (round 3; 16 before: on a random-like text of 3.4 G positions 18 % instead of 55 % of the suffixes share their key with another and enter the first round)
 constexpr int DK_PER_THREAD = 16;     // suffixes per thread
 constexpr int DK_TILE = BLOCK * DK_PER_THREAD;
 
-// keys[x] = the first 16 characters of suffix x read as a 16-digit base-9 number (digits = dict_code, 0 after
-// the terminator): order-preserving like 4-bit packing, but 9^16 < 2^51, i.e. 7 radix passes instead of 8.
-constexpr int DK_KEY_BITS = 51;
+// keys[x] = the first DK_CHARS characters of suffix x read as a base-9 number (digits = dict_code, 0 after
+// the terminator): order-preserving like 4-bit packing, but 9^17 < 2^54, i.e. 7 radix passes for 17 characters (4-bit codes: 16 in 8).
+constexpr int DK_KEY_BITS = 54;
 __global__ __launch_bounds__(BLOCK) void k_dict_init_keys(const uint8_t *D, uint64_t dsize, uint64_t *keys, uint32_t *vals)
 {
     __shared__ uint8_t tile[DK_TILE + DK_CHARS];
