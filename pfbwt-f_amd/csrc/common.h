@@ -90,7 +90,7 @@ struct Tunables {
     uint32_t class_sort_maxrange = 0;  // smaller LDS class-sort ranges (reaches the large-class route on small inputs)
     int dedup_table_log2 = 0;          // a first phrase table that overflows
     int no_trigger_table = 0;          // trigger test by hashing every window
-    uint64_t emit_chunk_rows = 1ULL << 30;
+    uint64_t emit_chunk_rows = 3ULL << 30;   // rows per emission window (32-bit offsets inside a window: < 2^32 with room for a straddling group).  2^30 until round 3: every window pays ~0.5 ms of small launches and host round trips (S-32G: 30 windows 96.8 ms, 15 windows 87.1, 8 windows 82.0)
     uint32_t fill_subs = 2;            // super-tiles (4 x 4096 rows) per workgroup of k_fill
     uint64_t sample_cap = ~0ULL;       // cap of the one-pass run-sample arrays (forces the two-pass fallback)
     int no_runaware = 0;               // -r with every row enumerated, as with a full SA

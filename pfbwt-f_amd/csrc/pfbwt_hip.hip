@@ -108,7 +108,7 @@ static int set_tunable(pfp_ctx *c, const char *key, long long v)
     else if (!strcmp(key, "class_sort_maxrange")) t.class_sort_maxrange = (uint32_t)v;
     else if (!strcmp(key, "dedup_table_log2")) t.dedup_table_log2 = (int)v;
     else if (!strcmp(key, "no_trigger_table")) t.no_trigger_table = (int)v;
-    else if (!strcmp(key, "emit_chunk_rows")) t.emit_chunk_rows = v > 0 ? (uint64_t)v : (1ULL << 30);
+    else if (!strcmp(key, "emit_chunk_rows")) t.emit_chunk_rows = v > 0 ? (uint64_t)v : (3ULL << 30);
     else if (!strcmp(key, "fill_subs")) t.fill_subs = (uint32_t)v;
     else if (!strcmp(key, "sample_cap")) t.sample_cap = v < 0 ? ~0ULL : (uint64_t)v;
     else if (!strcmp(key, "no_runaware")) t.no_runaware = (int)v;
@@ -1472,7 +1472,7 @@ template <typename SAT, typename EBT> static int emit_and_sample(pfp_ctx *c, Emi
     const uint64_t lead = s0 ? 1 : 0;                     // the row in front of the slice (run detection needs its BWT byte)
     const uint64_t nrows = s1 - s0;
     c->slice_begin = s0; c->slice_rows = nrows;
-    const uint64_t chunk_rows = c->tun.emit_chunk_rows ? c->tun.emit_chunk_rows : (1ULL << 30);
+    const uint64_t chunk_rows = c->tun.emit_chunk_rows ? c->tun.emit_chunk_rows : (3ULL << 30);
     const uint64_t nchunks = (nrows + chunk_rows - 1) / chunk_rows;
     const bool windowed = nslices > 1 || nchunks > 1;
     const bool runaware = ea.special != 0;

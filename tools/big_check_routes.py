@@ -2,7 +2,7 @@
 """Full-size cross-check of the routes that round 3 added against the routes they replace (validated at full size in round 2):
 a bench workload is built with the default switches and again with the old routes forced -- row-wise emission of the special rows
 (emit_group_rows = 0), two-gather slot fields (no_slot_records = 1), rank-based dictionary sort (dict_text_rounds = 0), two parse
-symbols in the initial key, run round always -- and the position-weighted device checksums (pfp_debug_checksum) of every output
+symbols in the initial key, run round always, emission windows of 2^30 rows -- and the position-weighted device checksums (pfp_debug_checksum) of every output
 (.bwt, .sa if the workload has one, .ssa, .esa) and r must be equal.  Nothing leaves the device; no oracle is involved: small
 inputs are compared with the oracle by the test suite under the same switches.
 usage: python tools/big_check_routes.py [--workload S-32G | S-3G | S-50G | S-chr22]"""
@@ -21,7 +21,7 @@ U = 8 if u64 else 4
 h_all = torch.empty((H, Lb), dtype=torch.uint8, pin_memory=True)
 bench.synth_seqs(Lb, H, seed, nruns, out=h_all.numpy())
 d_all = h_all.to("cuda"); del h_all
-OLD = dict(emit_group_rows=0, no_slot_records=1, dict_text_rounds=0, int_key_symbols=2, force_run_round=1)
+OLD = dict(emit_group_rows=0, no_slot_records=1, dict_text_rounds=0, int_key_symbols=2, force_run_round=1, emit_chunk_rows=1 << 30)
 
 
 def build(switches):
