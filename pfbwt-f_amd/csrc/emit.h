@@ -193,7 +193,7 @@ struct EmitArgs {
     const uint32_t *gqf, *gql;   // per head slot of a uniform multi-member group: parse row of its first / last output row
     // group-stationary route of the special rows (k_emit_groups): what it leaves to k_emit -- gleft[j] != 0: the group whose head is
     // the j-th special slot; tile_left[t] != 0: enumeration tile t of this launch holds rows of such a group.  nullptr: k_emit walks everything
-    uint8_t *gleft, *tile_left; uint32_t group_rows_cap;
+    uint8_t *gleft, *tile_left; uint32_t group_rows_cap; uint32_t rank_members_max;   // groups of more members are not ranked by bisection inside a batch: they go to the LDS sort
     const uint4 *cinfo;          // per special slot j (k_special_pack): { first ilist index, members of its group, its index inside the group, preceding byte | SF_* flags << 8 }
     const unsigned long long *cgb;   // per special slot: output row of the first row of its group
     const uint32_t *town;        // per enumeration tile t: head (index of special slots) of the first group that starts at or behind row t * EMIT_TILE
@@ -202,6 +202,7 @@ struct EmitArgs {
 };
 constexpr uint8_t SF_MULTI = 1, SF_FULL = 2, SF_BIG = 4, SF_GFULL = 8, SF_NONUNI = 16, SF_E0 = 32;   // E0: a one-member slot of a word that occurs once -- s_g0 / sinfo.z hold bwsai of that occurrence (texts < 2^32), not a head slot   // GFULL: some member of the group is a whole word; NONUNI: members with different preceding bytes
 __device__ __forceinline__ bool slot_is_special(uint32_t fl) { return (fl & (SF_FULL | SF_GFULL | SF_NONUNI)) != 0; }
+constexpr int EG_SLOTS = 2 * BLOCK;          // slots (members) a batch / an LDS-sorted group may have (k_emit_groups)
 constexpr uint32_t BIG_GROUP_MEMBERS = 64;  // groups with more members than this take the sort route (measured: below ~64 ranking is faster)
 // posinfo[x] = { word id of dictionary offset x | 4-bit code of D[x-1] << 28 , class-head slot of x }: one 8-byte
 // gather per slot instead of three separate random reads (wordid, grank, D[x-1])
@@ -355,7 +356,7 @@ __device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t *a, uint32_t 
 // the group.  Groups with a whole-word member keep the ranking route (reference quirk handling lives there).
 template <typename EBT> __global__ __launch_bounds__(BLOCK) void k_big_mark(const EBT *cnt, const uint32_t *s_g0, const uint32_t *gk, const uint8_t *gfl, const uint8_t *gnu, const uint32_t *s_fb, const uint32_t *ilist, uint64_t dsize, uint32_t min_members,
                                                                             int runaware, uint8_t *s_fl, uint4 *sinfo, EBT *cnt2 /*runaware: rows of the special slots*/, uint32_t *gqf, uint32_t *gql, unsigned long long *big_rows,
-                                                                            const EBT *EB /*exclusive scan of cnt*/, const EBT *total, uint32_t max_rows /*0: no limit; else groups of more rows take the sort route*/)
+                                                                            const EBT *EB /*exclusive scan of cnt*/, const EBT *total, uint32_t max_rows /*0: no limit; else groups of more rows take the sort route*/, int many_in_lds)
 {
     __shared__ unsigned long long red[4];
     const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -372,9 +373,10 @@ template <typename EBT> __global__ __launch_bounds__(BLOCK) void k_big_mark(cons
                 if (gnu[g0]) fl |= SF_NONUNI;
                 // without a full SA only the groups that are not one run of a byte are merged at all
                 bool big = k > min_members;
-                if (!big && max_rows && (fl & SF_NONUNI)) {
+                if (max_rows && (fl & SF_NONUNI)) {
                     const uint64_t grows = (uint64_t)(g0 + k < dsize ? EB[g0 + k] : *total) - (uint64_t)EB[g0];
-                    big = grows > (uint64_t)max_rows;
+                    if (!big) big = grows > (uint64_t)max_rows;
+                    else if (many_in_lds && k <= (uint32_t)EG_SLOTS && grows <= (uint64_t)max_rows) big = false;      // many members, but the group fits the LDS sort of k_emit_groups_large, which does not care how many lists it merges
                 }
                 if (big && (!runaware || (fl & SF_NONUNI))) { fl |= SF_BIG; mine = (unsigned long long)cnt[i]; }
             }
@@ -737,7 +739,7 @@ template <typename SAT, typename EBT> __global__ __launch_bounds__(BLOCK) void k
 // are bwlast[q]: the one random gather left).  Groups that do not fit a batch, groups with a whole-word member (reference quirk,
 // multi_group_pos) and sort-route groups are left to k_emit: their heads are marked in gleft[], the enumeration tiles their rows
 // touch in tile_left[].
-constexpr int EG_BUF = 4096, EG_SLOTS = 2 * BLOCK, EG_PER_THREAD = EG_BUF / BLOCK;
+constexpr int EG_BUF = 4096, EG_PER_THREAD = EG_BUF / BLOCK;
 constexpr int EG1_BUF = 8192, EG2_BUF = 16384;              // rows of a group k_emit_groups_large holds in LDS (S-32G: 349 M special rows sit in groups of 4-16 K rows, 8-63 members)
 __device__ __forceinline__ uint32_t group_members(const EmitArgs &a, const uint4 &S) { const uint32_t k = S.w & 0xFFFFFFu; return k == 0xFFFFFFu ? a.gk[S.z] : k; }
 // what a batch needs of a special slot, gathered once per build (the chain elist -> sinfo -> s_pc / EB costs a workgroup three
@@ -811,7 +813,7 @@ template <typename EBT> __global__ __launch_bounds__(BLOCK) void k_emit_groups(E
                 if (s + 1 == nload) s_eb[nload] = e1 < 0xFFFFFFFFull ? (uint32_t)e1 : 0xFFFFFFFFu;
                 s_fb[s] = ci.x; s_kf[s] = (k < 0xFFFFFFu ? k : 0xFFFFFFu) | (fl << 24); s_dl[s] = dl; s_pc[s] = (uint8_t)ci.w;
                 s_ob[s] = (uint64_t)a.cgb[j + s];
-                if ((fl & (SF_GFULL | SF_BIG)) && s < bad) bad = s;
+                if (((fl & (SF_GFULL | SF_BIG)) || k > a.rank_members_max) && s < bad) bad = s;
                 if (dl + 1u == k && e1 <= (uint64_t)cap) cand[t] = s + 1u;       // a batch may end behind this slot
             }
         }

@@ -1514,7 +1514,7 @@ template <typename SAT, typename EBT> static int emit_and_sample(pfp_ctx *c, Emi
     }
     ea.big_keys = bk0; ea.big_vals = bv0; ea.big_count = d_b + 4; ea.big_cap = ea.big_total;
     // group-stationary route of the special rows (k_emit_groups); what it leaves behind is marked for k_emit
-    ea.gleft = ea.tile_left = nullptr; ea.group_rows_cap = c->tun.emit_group_rows;
+    ea.gleft = ea.tile_left = nullptr; ea.group_rows_cap = c->tun.emit_group_rows; ea.rank_members_max = c->tun.big_group_members != -2 ? 0xFFFFFFFFu : c->tun.emit_group_rows >= (uint32_t)EG_BUF ? BIG_GROUP_MEMBERS : 3u;      // (tests with small batches: groups of more than three members through the LDS sort)
     const uint64_t max_etiles = maxq / EMIT_TILE + 3;
     if (runaware && ea.group_rows_cap && tot2 && ea.cinfo) {
         PFP_ALLOC_HI(c, ea.gleft, uint8_t, (size_t)ea.ecount + 1); PFP_ALLOC_HI(c, ea.tile_left, uint8_t, max_etiles);
@@ -1754,7 +1754,7 @@ template <typename EBT> static int emit_stage(pfp_ctx *c, EmitArgs ea, int want_
     // rows and ~100 members were ranked row by row in memory by k_emit: 9 ms)
     const uint32_t big_rows = !(runaware && big_members >= 0 && c->tun.emit_group_rows) ? 0u : c->tun.emit_group_rows >= (uint32_t)EG_BUF ? (uint32_t)EG2_BUF : 4u * c->tun.emit_group_rows;      // (tests: small batches -> small limit)
     PFP_LAUNCH(c, K_EMIT_COUNT, dsize * 14, (k_big_mark<EBT>), nblocks(dsize, BLOCK), (const EBT *)cnt, (const uint32_t *)s_g0, (const uint32_t *)gk, (const uint8_t *)gfl, (const uint8_t *)gnu, (const uint32_t *)ea.s_fb, ea.ilist, dsize,
-               big_members >= 0 ? (uint32_t)big_members : 0xFFFFFFFFu, runaware ? 1 : 0, (uint8_t *)ea.s_fl, sinfo, cnt2, gqf, gql, d_hard + 1, (const EBT *)EB, (const EBT *)d_tot, big_rows);
+               big_members >= 0 ? (uint32_t)big_members : 0xFFFFFFFFu, runaware ? 1 : 0, (uint8_t *)ea.s_fl, sinfo, cnt2, gqf, gql, d_hard + 1, (const EBT *)EB, (const EBT *)d_tot, big_rows, (big_rows && c->tun.big_group_members == -2) ? 1 : 0);
     EBT tot = 0; unsigned long long hardrows = 0, hh[2] = {0, 0};
     PFP_HIP(c, hipMemcpyAsync(hh, d_hard, 16, hipMemcpyDeviceToHost, c->stream));
     PFP_HIP(c, hipMemcpyAsync(&tot, d_tot, sizeof(EBT), hipMemcpyDeviceToHost, c->stream));
