@@ -27,14 +27,14 @@ enum KernelId {
     K_TRIGGER_SCAN, K_PHRASE_ENDS, K_PHRASE_HASH, K_PHRASE_HASH_LONG, K_DEDUP_HEADS, K_DEDUP_LONG,
     K_DICT_BUILD, K_RADIX_HIST, K_RADIX_SCATTER, K_SCAN_REDUCE, K_SCAN_SPINE, K_SCAN_APPLY,
     K_SS_INIT_KEYS, K_SS_HEADS, K_SS_MAKE_KEYS, K_SS_WRITE_RANK, K_SS_FLAG_ACTIVE, K_COMPACT,
-    K_WORD_RANK, K_PARSE_RANKS, K_DICT_SORTED, K_PBWT_ROWS, K_EMIT_COUNT, K_EMIT, K_RUNS, K_SAMPLES, K_MISC, K_EMIT_BIG, K_FILL, K_CLASS_SORT, K_FASTA, K_EMIT_LARGE,
+    K_WORD_RANK, K_PARSE_RANKS, K_DICT_SORTED, K_PBWT_ROWS, K_EMIT_COUNT, K_EMIT, K_RUNS, K_SAMPLES, K_MISC, K_EMIT_BIG, K_FILL, K_CLASS_SORT, K_FASTA, K_EMIT_LARGE, K_REC_PARSE, K_REC_DEDUP, K_REC_ASSEMBLE,
     K_COUNT_
 };
 static const char *const kernel_names[K_COUNT_] = {
     "trigger_scan", "phrase_ends", "phrase_hash", "phrase_hash_long", "dedup_heads", "dedup_long",
     "dict_build", "radix_hist", "radix_scatter", "scan_reduce", "scan_spine", "scan_apply",
     "ss_init_keys", "ss_heads", "ss_make_keys", "ss_write_rank", "ss_flag_active", "compact",
-    "word_rank", "parse_ranks", "dict_sorted", "pbwt_rows", "emit_count", "emit", "runs", "samples", "misc", "emit_big", "fill", "class_sort", "fasta_strip", "emit_large"};
+    "word_rank", "parse_ranks", "dict_sorted", "pbwt_rows", "emit_count", "emit", "runs", "samples", "misc", "emit_big", "fill", "class_sort", "fasta_strip", "emit_large", "rec_parse", "rec_dedup", "rec_assemble"};
 
 struct ProfRec { uint64_t launches = 0; double ms = 0, bytes = 0; };
 
@@ -103,6 +103,12 @@ struct Tunables {
     int int_key_symbols = 3;           // symbols of the parse in the initial sort key: 3 where 3 x symbol bits <= 64 (S-32G: 21-bit symbols, 8 radix passes instead of 6, one refinement round less to pay for: parse BWT 135.7 -> 131.9 ms), else 2
     int no_slot_records = 0;           // k_emit_slots by two gathers (word id | preceding byte, then the word record): the route of dictionaries with words of 64 Mbase and more
     uint64_t fasta_chunk_bytes = 0;    // size of the raw-FASTA device buffers (0: 1 MiB ... 256 MiB by the size of the first call)
+    int parse_rec = -1;                // suffix sort of the parse through a level-2 prefix-free parse (recsort.h): -1 = when the parse is long and repetitive, 0 never, 1 wherever the route can run
+    int parse_rec_p2 = 4;              // its modulus: one symbol in p2 ends a level-2 phrase
+    uint64_t parse_rec_min = 1u << 21; // shortest parse that takes it (below: launch latencies, not data, bound either route)
+    int parse_rec_depth = 1;           // levels (the names of one level are as long as a second level's dictionary on the collections measured)
+    uint32_t parse_rec_tile_rows = 0;  // rows per assembly batch (0: a full LDS tile; smaller: reaches the large-class route on small inputs)
+    int parse_rec_table_log2 = 0;      // log2 of the level-2 phrase table (tests: a table that overflows -> doubling route)
 };
 
 } // namespace pfp
@@ -216,8 +222,10 @@ struct ProfScope {
 #define PFP_LAUNCH(ctx, id, bytes, kernel, grid, ...)                                             \
     do {                                                                                          \
         pfp::ProfScope ps_((ctx), (id), (double)(bytes));                                         \
+        if ((ctx)->tun.verbose >= 3) { fprintf(stderr, "[pfbwt_hip] launch %s grid %u\n", #kernel, (unsigned)(grid)); fflush(stderr); } \
         hipLaunchKernelGGL(kernel, dim3((unsigned)(grid)), dim3(pfp::BLOCK), 0, (ctx)->stream, __VA_ARGS__); \
         hipError_t le_ = hipGetLastError();            /* a rejected launch (grid, LDS size) must not pass as stale output */ \
+        if ((ctx)->tun.verbose >= 3 && le_ == hipSuccess) le_ = hipStreamSynchronize((ctx)->stream);   /* fault hunting: one kernel at a time */ \
         if (le_ != hipSuccess) { (ctx)->hip_err = (int)le_; (ctx)->err_ch = (int)le_;                 \
             fprintf(stderr, "[pfbwt_hip] launch of %s failed: %s (%s:%d)\n", #kernel, hipGetErrorString(le_), __FILE__, __LINE__); \
             return PFP_E_HIP; }                                                                       \

@@ -6,6 +6,7 @@
 #include "parse.h"
 #include "fasta.h"
 #include "sufsort.h"
+#include "recsort.h"
 #include "emit.h"
 #include "markers.h"
 #include <map>
@@ -96,7 +97,8 @@ static void reset_results(pfp_ctx *c)
 
 // ---- route / tuning switches (pfbwt_hip_dev.h) -----------------------------------------------------
 static const char *const tunable_names[] = {"verbose", "seg_grid", "seg_stage", "sort_k", "sort_no_table", "class_sort_maxrange", "dedup_table_log2", "no_trigger_table",
-                                            "emit_chunk_rows", "fill_subs", "sample_cap", "no_runaware", "big_group_members", "force_wide_rows", "fasta_chunk_bytes", "ingest_block_bytes", "emit_group_rows", "no_slot_records", "dict_text_rounds", "int_key_symbols", "force_run_round"};
+                                            "emit_chunk_rows", "fill_subs", "sample_cap", "no_runaware", "big_group_members", "force_wide_rows", "fasta_chunk_bytes", "ingest_block_bytes", "emit_group_rows", "no_slot_records", "dict_text_rounds", "int_key_symbols", "force_run_round",
+                                            "parse_rec", "parse_rec_p2", "parse_rec_min", "parse_rec_depth", "parse_rec_tile_rows", "parse_rec_table_log2"};
 static int set_tunable(pfp_ctx *c, const char *key, long long v)
 {
     Tunables &t = c->tun;
@@ -121,6 +123,12 @@ static int set_tunable(pfp_ctx *c, const char *key, long long v)
     else if (!strcmp(key, "dict_text_rounds")) t.dict_text_rounds = (int)v;
     else if (!strcmp(key, "int_key_symbols")) t.int_key_symbols = (int)v;
     else if (!strcmp(key, "force_run_round")) t.force_run_round = (int)v;
+    else if (!strcmp(key, "parse_rec")) t.parse_rec = (int)v;
+    else if (!strcmp(key, "parse_rec_p2")) t.parse_rec_p2 = (int)v;
+    else if (!strcmp(key, "parse_rec_min")) t.parse_rec_min = v > 0 ? (uint64_t)v : 0;
+    else if (!strcmp(key, "parse_rec_depth")) t.parse_rec_depth = (int)v;
+    else if (!strcmp(key, "parse_rec_tile_rows")) t.parse_rec_tile_rows = v > 0 ? (uint32_t)v : 0u;
+    else if (!strcmp(key, "parse_rec_table_log2")) t.parse_rec_table_log2 = (int)v;
     else return PFP_E_ARG;
     return PFP_OK;
 }
@@ -1274,22 +1282,6 @@ int pfp_parse_get(pfp_ctx *c, uint8_t *dict, void *occ, uint32_t *parse, uint8_t
     return PFP_OK;
 }
 
-// suffix array of S[0..N) (S[N-1] == 0 unique smallest), integer alphabet with values <= maxsym
-static int sort_int_suffixes(pfp_ctx *c, const uint32_t *dS, uint64_t N, uint64_t maxsym, uint32_t *SA, uint32_t *rank, int *rounds)
-{
-    const size_t mk = c->arena.mark_hi();
-    uint64_t *k0, *k1; uint32_t *v0, *v1;
-    PFP_ALLOC_HI(c, k0, uint64_t, N); PFP_ALLOC_HI(c, k1, uint64_t, N);
-    PFP_ALLOC_HI(c, v0, uint32_t, N); PFP_ALLOC_HI(c, v1, uint32_t, N);
-    const int sb = bits_for(maxsym);
-    const int nsym = (c->tun.int_key_symbols == 3 && 3 * sb <= 64) ? 3 : 2;
-    PFP_LAUNCH(c, K_SS_INIT_KEYS, N * 16, k_int_init_keys, nblocks(N, BLOCK), dS, N, sb, nsym, k0, v0);
-    BitRange rr = {0, nsym * sb};
-    PFP_TRY(suffix_sort_doubling<false>(c, N, k0, v0, k1, v1, &rr, 1, (uint32_t)nsym, (const uint8_t *)nullptr, SA, rank, (uint2 *)nullptr, rounds));
-    c->arena.release_hi(mk);
-    return PFP_OK;
-}
-
 static int parse_bwt_impl(pfp_ctx *c);
 int pfp_parse_bwt(pfp_ctx *c)
 {
@@ -1322,7 +1314,7 @@ static int parse_bwt_impl(pfp_ctx *c)
     PFP_ALLOC_HI(c, W, uint32_t, N); PFP_ALLOC_HI(c, rowid, uint32_t, N);
     PFP_ALLOC_HI(c, W2, uint32_t, N); PFP_ALLOC_HI(c, rowid2, uint32_t, N);
     int rounds = 0;
-    PFP_TRY(sort_int_suffixes(c, c->d_parse, N, c->dwords, SAP, rk, &rounds));   // sacak_int, :425
+    PFP_TRY(sort_int_suffixes(c, c->d_parse, N, c->dwords, SAP, rk, &rounds, 0, false));   // sacak_int, :425 (recsort.h; the ranks are not asked for)
     {
         uint4 *rec; PFP_ALLOC_HI(c, rec, uint4, m);
         PFP_LAUNCH(c, K_PBWT_ROWS, m * 29, k_pbwt_pack, nblocks(m, BLOCK), (const uint32_t *)c->d_parse, (const uint8_t *)c->d_last, sai ? (const tpos_t *)c->d_ye : (const tpos_t *)nullptr, m, rec);

@@ -265,7 +265,15 @@ static inline hipError_t hipMemAddressReserve(void **p, size_t size, size_t alig
 static inline hipError_t hipMemAddressFree(void *p, size_t size) { munmap(p, size); return hipSuccess; }
 static inline hipError_t hipMemCreate(hipMemGenericAllocationHandle_t *h, size_t size, const hipMemAllocationProp *, unsigned long long) { *h = new emu_memhandle_s{size}; return hipSuccess; }
 static inline hipError_t hipMemRelease(hipMemGenericAllocationHandle_t h) { delete h; return hipSuccess; }
-static inline hipError_t hipMemMap(void *p, size_t size, size_t, hipMemGenericAllocationHandle_t, unsigned long long) { return mprotect(p, size, PROT_READ | PROT_WRITE) == 0 ? hipSuccess : hipErrorInvalidValue; }
+// PFP_EMU_POISON=1: freshly mapped memory is filled with 0xA5 (the card hands out whatever the last owner left; anonymous pages are
+// zero): a read of memory no kernel wrote then yields wild indices here too instead of benign zeros
+static inline hipError_t hipMemMap(void *p, size_t size, size_t, hipMemGenericAllocationHandle_t, unsigned long long)
+{
+    if (mprotect(p, size, PROT_READ | PROT_WRITE) != 0) return hipErrorInvalidValue;
+    static const bool poison = getenv("PFP_EMU_POISON") != nullptr;
+    if (poison) memset(p, 0xA5, size);
+    return hipSuccess;
+}
 static inline hipError_t hipMemUnmap(void *p, size_t size)
 { return mmap(p, size, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE | MAP_FIXED, -1, 0) == p ? hipSuccess : hipErrorInvalidValue; }
 static inline hipError_t hipMemSetAccess(void *, size_t, const hipMemAccessDesc *, size_t) { return hipSuccess; }
