@@ -143,10 +143,10 @@ __global__ __launch_bounds__(BLOCK) void k_rs_assign_ids(const uint32_t *sorted_
     slot2id[eid[j]] = (uint32_t)i; wrep[i] = j;
     wlen1[i] = ps[j + 1] - ps[j] + 2u;                      // symbols + separator
 }
-__global__ __launch_bounds__(BLOCK) void k_rs_wid(const uint32_t *eid, const uint32_t *slot2id, uint64_t k, uint32_t *wid, uint32_t *idx)
+__global__ __launch_bounds__(BLOCK) void k_rs_wid(const uint32_t *eid, const uint32_t *slot2id, uint64_t k, uint32_t *wid, uint32_t *wid_keep, uint32_t *idx)
 {
     const uint64_t j = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (j < k) { wid[j] = slot2id[eid[j]]; if (idx) idx[j] = (uint32_t)j; }
+    if (j < k) { const uint32_t id = slot2id[eid[j]]; wid[j] = id; wid_keep[j] = id; idx[j] = (uint32_t)j; }      // (wid is the sort's input; wid_keep stays in phrase order for the names)
 }
 // D2 = the words in id order, symbols + 2, each followed by the separator 1 (the last one, which ends in S's own 0, by the final 0):
 // strings compare before any separator is reached (prefix-free), a separator is below every symbol, so the suffixes with ONE string
@@ -198,14 +198,14 @@ __global__ __launch_bounds__(BLOCK) void k_rs_list_payload(const uint32_t *inv, 
     ikey[e] = R2[j + 1]; ipos[e] = ps[j];
 }
 // valid slots (v = index in the compacted list): head of a class iff the string differs from the previous valid slot's
-__global__ __launch_bounds__(BLOCK) void k_rs_heads(const uint32_t *D, const uint32_t *SAD, const uint32_t *vlist, const uint32_t *rowoff, uint64_t nv, uint32_t *head, uint32_t *hrow)
+__global__ __launch_bounds__(BLOCK) void k_rs_heads(const uint32_t *D, const uint32_t *SAD, const uint32_t *vlist, uint64_t nv, uint32_t *head)
 {
     const uint64_t v = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (v >= nv) return;
     // (everything that depends on s is loaded before the loop: hipcc 7.2 -O3 lost s across it for the lanes that skip the loop --
-    //  the copy it keeps around the loop body is only written inside -- and the row offset was read at a wild address: the one GPU
-    //  fault of this file's first run on the card, invisible to the CPU interpreter)
-    const uint32_t s = vlist[v], ro = rowoff[s];
+    //  the copy it keeps around the loop body is only written inside -- and a row offset was read at a wild address behind it: the one
+    //  GPU fault of this file's first run on the card, invisible to the CPU interpreter)
+    const uint32_t s = vlist[v];
     const uint32_t sp = v ? vlist[v - 1] : 0u;
     uint32_t hd = (v == 0 || sp + 1u != s) ? 1u : 0u;
     uint32_t x = SAD[s], y = SAD[s ? s - 1 : 0];
@@ -217,16 +217,15 @@ __global__ __launch_bounds__(BLOCK) void k_rs_heads(const uint32_t *D, const uin
         }
     }
     head[v] = hd;
-    hrow[v] = hd ? ro : 0u;
 }
-// srec[v] = { first row, first list entry of its word, offset of the string in the word, first row of its class }
-__global__ __launch_bounds__(BLOCK) void k_rs_slot_records(const uint32_t *SAD, const uint32_t *vlist, const uint32_t *rowoff, const uint32_t *hrow /*max-scanned*/, const uint32_t *wd, const uint32_t *wstart,
+// srec[v] = { first row, first list entry of its word, offset of the string in the word, index of its class }
+__global__ __launch_bounds__(BLOCK) void k_rs_slot_records(const uint32_t *SAD, const uint32_t *vlist, const uint32_t *rowoff, const uint32_t *head, const uint32_t *hpos /*heads in front of v*/, const uint32_t *wd, const uint32_t *wstart,
                                                             const uint32_t *woff, uint64_t nv, uint4 *srec)
 {
     const uint64_t v = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (v >= nv) return;
     const uint32_t s = vlist[v], x = SAD[s], i = wd[x];
-    srec[v] = make_uint4(rowoff[s], woff[i], x - wstart[i], hrow[v]);
+    srec[v] = make_uint4(rowoff[s], woff[i], x - wstart[i], hpos[v] + head[v] - 1u);
 }
 __global__ __launch_bounds__(BLOCK) void k_rs_class_rows(const uint32_t *chead, const uint4 *srec, uint64_t nc, uint64_t nv, uint64_t R, uint32_t *crow, uint32_t *chead_end)
 {
@@ -242,18 +241,31 @@ __device__ __forceinline__ uint32_t rs_lower_bound(const uint32_t *a, uint32_t l
     return lo;
 }
 
+// lanes of the wave that hold the same NB-bit digit as this one (prims.h: same_digit_lanes is the 8-bit form)
+template <int NB> __device__ __forceinline__ void rs_same_digit_lanes(uint32_t d, uint32_t &plo, uint32_t &phi)
+{
+#pragma unroll
+    for (int bb = 0; bb < NB; ++bb) {
+        const uint32_t neg = (uint32_t)(((int32_t)(d << (31 - bb))) >> 31);
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(neg != 0u);
+        plo &= ~((uint32_t)m ^ neg); phi &= ~((uint32_t)(m >> 32) ^ neg);
+    }
+}
+
 // Assembly.  Workgroup b owns the classes whose first row lies in [b*STEP, (b+1)*STEP); it takes them in batches of whole classes
 // of at most tile_rows rows: the rows (list entries of the member words) are gathered into LDS, sorted there by
-// (first row of the class, rank of the sampled suffix behind the occurrence) -- LSD passes of 8 bits, the same pass as the class
-// sort of sufsort.h -- and stored: SA[1 + row] = text position (row 0 is the final 0).  A class with more rows than a tile is
-// appended to `bigc` (global sort route).
+// (index of the class in the batch, rank of the sampled suffix behind the occurrence) -- stable LSD passes over 9-bit digits with
+// wave-ballot ranking, the pass of the class sort of sufsort.h with a wider digit: S-32G has 27 key bits and ~125 classes per batch,
+// 35 bits = 4 passes (8-bit digits and the class's first row as high part: 6 passes, 13.1 ms) -- and stored: SA[1 + row] = text
+// position (row 0 is the final 0).  A class with more rows than a tile is appended to `bigc` (global sort route).
+constexpr int RA_DB = 9, RA_RADIX = 1 << RA_DB;
 template <bool RANK> __global__ __launch_bounds__(BLOCK) void k_rs_assemble(const uint4 *srec, const uint32_t *chead /*nc + 1*/, const uint32_t *crow /*nc + 1*/, uint32_t nc,
                                                                             const uint32_t *ikey, const uint32_t *ipos, int keybits, uint32_t tile_rows, uint32_t *SA, uint32_t *rank,
                                                                             uint32_t *bigc, uint32_t *nbig)
 {
     constexpr int ITEMS = RS_ITEMS, TILE = RS_TILE;
     constexpr uint32_t STEP = TILE / 2;
-    __shared__ uint32_t wh[BLOCK / WAVE][RS_RADIX];
+    __shared__ uint32_t wh[BLOCK / WAVE][RA_RADIX];
     __shared__ uint64_t skeys[TILE];
     __shared__ uint16_t sidx[TILE];
     __shared__ uint16_t srow[TILE + 1];
@@ -294,54 +306,56 @@ template <bool RANK> __global__ __launch_bounds__(BLOCK) void k_rs_assemble(cons
                 const uint4 rec = srec[v0 + lo];
                 const uint32_t e = rec.y + (i - (rec.x - r0));
                 xi[it] = ipos[e] + rec.z;
-                skeys[i] = ((uint64_t)(rec.w - r0) << keybits) | ikey[e];
+                skeys[i] = ((uint64_t)(rec.w - ci) << keybits) | ikey[e];
                 sidx[i] = (uint16_t)i;
             }
         }
         for (uint32_t i = n + threadIdx.x; i < nit * BLOCK; i += BLOCK) { skeys[i] = ~0ULL; sidx[i] = (uint16_t)i; }
         __syncthreads();
-        const uint32_t hspan = crow[cj - 1] - r0;             // largest class part
-        const int nlo = (keybits + 7) / 8;
-        int nhi = 0; while (nhi < 4 && (hspan >> (8 * nhi))) ++nhi;
+        int tbits = keybits;                                   // key bits + bits of the largest class index of the batch
+        for (uint32_t hs = cj - 1 - ci; hs; hs >>= 1) ++tbits;
+        const int npass = (tbits + RA_DB - 1) / RA_DB;
         const uint32_t base = (uint32_t)wave * (nit * WAVE) + lane;
-        for (int p = 0; p < nlo + nhi; ++p) {
-            const int sh = p < nlo ? 8 * p : keybits + 8 * (p - nlo);
-            const uint32_t dmask = (p < nlo && keybits - 8 * p < 8) ? ((1u << (keybits - 8 * p)) - 1u) : 255u;
+        for (int p = 0; p < npass; ++p) {
+            const int sh = RA_DB * p;
             uint64_t kk[ITEMS]; uint16_t vv[ITEMS]; unsigned dg[ITEMS];
 #pragma unroll
-            for (int w = 0; w < BLOCK / WAVE; ++w) wh[w][threadIdx.x] = 0;
+            for (int w = 0; w < BLOCK / WAVE; ++w) { wh[w][threadIdx.x] = 0; wh[w][threadIdx.x + BLOCK] = 0; }
             __syncthreads();
 #pragma unroll
             for (int it = 0; it < ITEMS; ++it) {
                 if ((uint32_t)it < nit) {
                     const uint32_t i = base + (uint32_t)it * WAVE;
                     kk[it] = skeys[i]; vv[it] = sidx[i];
-                    const uint32_t d = (uint32_t)(kk[it] >> sh) & dmask;
+                    const uint32_t d = (uint32_t)(kk[it] >> sh) & (RA_RADIX - 1);
                     uint32_t plo = 0xFFFFFFFFu, phi = 0xFFFFFFFFu;
-                    same_digit_lanes(d, plo, phi);
+                    rs_same_digit_lanes<RA_DB>(d, plo, phi);
                     const int leader = plo ? __builtin_ctz(plo) : 32 + __builtin_ctz(phi);
                     uint32_t old = 0;
                     if (lane == leader) { old = wh[wave][d]; wh[wave][d] = old + (uint32_t)__builtin_popcount(plo) + (uint32_t)__builtin_popcount(phi); }
                     old = __shfl(old, leader);
-                    dg[it] = d | ((old + __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u))) << 8);
+                    dg[it] = d | ((old + __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u))) << RA_DB);
                 }
             }
             __syncthreads();
-            {
-                const unsigned d = threadIdx.x;
-                uint32_t cw[BLOCK / WAVE]; uint32_t total = 0;
+            {   // thread t owns the digits 2t and 2t + 1
+                const unsigned d0 = 2u * threadIdx.x;
+                uint32_t c0[BLOCK / WAVE], c1[BLOCK / WAVE]; uint32_t total = 0;
 #pragma unroll
-                for (int w = 0; w < BLOCK / WAVE; ++w) { cw[w] = wh[w][d]; total += cw[w]; }
+                for (int w = 0; w < BLOCK / WAVE; ++w) { const uint2 q = *reinterpret_cast<const uint2 *>(&wh[w][d0]); c0[w] = q.x; c1[w] = q.y; total += q.x + q.y; }
                 uint32_t tt;
                 uint32_t run = block_excl_sum(total, red, &tt);
+                uint32_t o0[BLOCK / WAVE];
 #pragma unroll
-                for (int w = 0; w < BLOCK / WAVE; ++w) { wh[w][d] = run; run += cw[w]; }
+                for (int w = 0; w < BLOCK / WAVE; ++w) { o0[w] = run; run += c0[w]; }
+#pragma unroll
+                for (int w = 0; w < BLOCK / WAVE; ++w) { *reinterpret_cast<uint2 *>(&wh[w][d0]) = make_uint2(o0[w], run); run += c1[w]; }
             }
             __syncthreads();
 #pragma unroll
             for (int it = 0; it < ITEMS; ++it) {
                 if ((uint32_t)it < nit) {
-                    const uint32_t li = wh[wave][dg[it] & 255u] + (dg[it] >> 8);
+                    const uint32_t li = wh[wave][dg[it] & (RA_RADIX - 1)] + (dg[it] >> RA_DB);
                     skeys[li] = kk[it]; sidx[li] = vv[it];
                 }
             }
@@ -480,7 +494,7 @@ inline int suffix_sort_pfp(pfp_ctx *c, const uint32_t *dS, uint64_t N, uint64_t 
     if (verbose) fprintf(stderr, "[pfbwt_hip] recursive parse sort (depth %d): N=%llu -> %llu phrases (longest %u), %llu distinct, D2=%llu symbols (%.1f ms so far)\n", depth, (unsigned long long)N,
                          (unsigned long long)k, maxlen, (unsigned long long)nw, (unsigned long long)ND, tm.ms());
     if (!forced && (ND + k) * 10 > N * 6) { c->arena.release_hi(mk); return PFP_OK; }      // does not shrink enough to pay for the assembly
-    PFP_LAUNCH(c, K_REC_DEDUP, k * 16, k_rs_wid, nblocks(k, BLOCK), (const uint32_t *)eid, (const uint32_t *)slot2id, k, wid, inv0);
+    PFP_LAUNCH(c, K_REC_DEDUP, k * 16, k_rs_wid, nblocks(k, BLOCK), (const uint32_t *)eid, (const uint32_t *)slot2id, k, wid, eid /*in place: the entry index is not needed any more*/, inv0);
     // inverted lists: phrases grouped by word (stable: ascending inside a word)
     uint32_t *swid, *inv;
     {
@@ -488,9 +502,7 @@ inline int suffix_sort_pfp(pfp_ctx *c, const uint32_t *dS, uint64_t N, uint64_t 
         PFP_TRY(radix_sort_pairs<uint32_t>(c, wid, inv0, wid1, inv1, k, &wr, 1, &swid, &inv));
         PFP_LAUNCH(c, K_REC_PARSE, k * 4, k_rs_list_bounds, nblocks(k, BLOCK), (const uint32_t *)swid, k, nw, woff);
     }
-    // wid in phrase order is needed again for the names: the sort may have left it in either buffer -- recompute (one gather)
-    uint32_t *widp = swid == wid ? wid1 : wid;
-    PFP_LAUNCH(c, K_REC_DEDUP, k * 16, k_rs_wid, nblocks(k, BLOCK), (const uint32_t *)eid, (const uint32_t *)slot2id, k, widp, (uint32_t *)nullptr);
+    const uint32_t *widp = eid;                                // word ids in phrase order (the sort consumed its own copy)
     // ---- D2 and its suffix array
     uint32_t *D, *wd, *SAD;
     PFP_ALLOC_HI(c, D, uint32_t, ND + 4); PFP_ALLOC_HI(c, wd, uint32_t, ND); PFP_ALLOC_HI(c, SAD, uint32_t, ND);
@@ -510,7 +522,7 @@ inline int suffix_sort_pfp(pfp_ctx *c, const uint32_t *dS, uint64_t N, uint64_t 
     PFP_LAUNCH(c, K_REC_PARSE, ND * 28, k_rs_slots, nblocks(ND, BLOCK), (const uint32_t *)SAD, (const uint32_t *)wd, (const uint32_t *)wstart, (const uint32_t *)woff, ND, rows, whole, valid);
     PFP_TRY((device_scan<uint32_t, 0>(c, whole, wposs, ND, nullptr)));
     PFP_LAUNCH(c, K_REC_PARSE, ND * 16, k_rs_word_ranks, nblocks(ND, BLOCK), (const uint32_t *)SAD, (const uint32_t *)wd, (const uint32_t *)whole, (const uint32_t *)wposs, ND, wrank);
-    PFP_LAUNCH(c, K_REC_PARSE, k * 12, k_rs_names, nblocks(k + 1, BLOCK), (const uint32_t *)widp, (const uint32_t *)wrank, k, P2);
+    PFP_LAUNCH(c, K_REC_PARSE, k * 12, k_rs_names, nblocks(k + 1, BLOCK), widp, (const uint32_t *)wrank, k, P2);
     {
         int r2 = 0;
         PFP_TRY(sort_int_suffixes(c, P2, k + 1, nw, SA2, R2, &r2, depth + 1, true));
@@ -522,18 +534,17 @@ inline int suffix_sort_pfp(pfp_ctx *c, const uint32_t *dS, uint64_t N, uint64_t 
     PFP_TRY((device_scan<uint32_t, 0>(c, rows, rowoff, ND, d_cnt + 6)));
     uint32_t R32 = 0; PFP_TRY(d2h_u32(c, d_cnt + 6, &R32));
     if ((uint64_t)R32 != N - 1) { c->arena.release_hi(mk); return PFP_E_CORRUPT; }
-    uint32_t *vlist, *head, *hrow, *chead, *crow;
-    PFP_ALLOC_HI(c, vlist, uint32_t, ND); PFP_ALLOC_HI(c, head, uint32_t, ND); PFP_ALLOC_HI(c, hrow, uint32_t, ND); PFP_ALLOC_HI(c, chead, uint32_t, ND + 1); PFP_ALLOC_HI(c, crow, uint32_t, ND + 1);
+    uint32_t *vlist, *head, *chead, *crow;
+    PFP_ALLOC_HI(c, vlist, uint32_t, ND); PFP_ALLOC_HI(c, head, uint32_t, ND); PFP_ALLOC_HI(c, chead, uint32_t, ND + 1); PFP_ALLOC_HI(c, crow, uint32_t, ND + 1);
     PFP_TRY(device_compact(c, nullptr, valid, ND, vlist, wposs, d_cnt + 7));               // the slots that stand for a string
     uint32_t nv32 = 0; PFP_TRY(d2h_u32(c, d_cnt + 7, &nv32));
     const uint64_t nv = nv32;
     uint4 *srec; PFP_ALLOC_HI(c, srec, uint4, nv);
-    PFP_LAUNCH(c, K_REC_PARSE, nv * 40, k_rs_heads, nblocks(nv, BLOCK), (const uint32_t *)D, (const uint32_t *)SAD, (const uint32_t *)vlist, (const uint32_t *)rowoff, nv, head, hrow);
-    PFP_TRY((device_scan<uint32_t, 1>(c, hrow, hrow, nv, nullptr)));
-    PFP_LAUNCH(c, K_REC_PARSE, nv * 44, k_rs_slot_records, nblocks(nv, BLOCK), (const uint32_t *)SAD, (const uint32_t *)vlist, (const uint32_t *)rowoff, (const uint32_t *)hrow, (const uint32_t *)wd,
-               (const uint32_t *)wstart, (const uint32_t *)woff, nv, srec);
+    PFP_LAUNCH(c, K_REC_PARSE, nv * 40, k_rs_heads, nblocks(nv, BLOCK), (const uint32_t *)D, (const uint32_t *)SAD, (const uint32_t *)vlist, nv, head);
     PFP_HIP(c, hipMemsetAsync(d_cnt, 0, 32, c->stream));
-    PFP_TRY(device_compact(c, nullptr, head, nv, chead, wposs, d_cnt));
+    PFP_TRY(device_compact(c, nullptr, head, nv, chead, wposs, d_cnt));                    // wposs[v] = heads in front of v
+    PFP_LAUNCH(c, K_REC_PARSE, nv * 44, k_rs_slot_records, nblocks(nv, BLOCK), (const uint32_t *)SAD, (const uint32_t *)vlist, (const uint32_t *)rowoff, (const uint32_t *)head, (const uint32_t *)wposs, (const uint32_t *)wd,
+               (const uint32_t *)wstart, (const uint32_t *)woff, nv, srec);
     uint32_t nc32 = 0; PFP_TRY(d2h_u32(c, d_cnt, &nc32));
     const uint64_t nc = nc32;
     PFP_LAUNCH(c, K_REC_PARSE, nc * 24, k_rs_class_rows, nblocks(nc + 1, BLOCK), (const uint32_t *)chead, (const uint4 *)srec, nc, nv, N - 1, crow, chead + nc);
