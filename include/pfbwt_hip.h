@@ -117,8 +117,8 @@ int pfp_parse_feed_fasta_file(pfp_ctx *ctx, const char *path, unsigned flags, pf
 int pfp_parse_docs(pfp_ctx *ctx, uint64_t *count);
 int pfp_parse_doc_get(pfp_ctx *ctx, uint64_t i, const char **name, uint64_t *start);   /* valid until the next pfp_parse_feed_fasta_file */
 /* Announce the size of the text that is going to be fed (e.g. the size of the FASTA file): sizes the ADDRESS range of the text
- * buffer -- HBM itself is committed as the text grows (never re-allocated or copied).  Optional; without it the range is as
- * large as the card, which limits a process to a few hundred live contexts. */
+ * buffer -- HBM itself is committed as the text grows.  Optional; without it the range is four times what the first feed needs
+ * (at least 64 MiB) and doubles when the text outgrows it (the text is then moved once: a device-to-device copy). */
 int pfp_parse_reserve(pfp_ctx *ctx, uint64_t text_bytes);
 /* Back to feeding with the text kept: after pfp_parse_finalize the (normalised) text is still on the device, more
  * records can be appended and pfp_parse_finalize run again -- what PfParser::operator+= (pfparser.hpp:194-263) needs

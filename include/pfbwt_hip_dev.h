@@ -48,6 +48,16 @@ int pfp_debug_checksum(pfp_ctx *ctx, const void *d_buf, uint64_t bytes, uint64_t
  * holds its text.  out[0] pairs checked, out[1] order violations, out[2] pairs whose rows are not adjacent, out[3] longest and
  * out[4] sum of the common prefixes. */
 int pfp_debug_check_sample_order(pfp_ctx *ctx, uint64_t out[5]);
+/* Properties of the full suffix array of the last pfp_bwt_build(want_sa = 1) against the resident text, at any size, without moving
+ * it off the device: out[0] rows checked; out[1] values above n; out[2] values that occur twice (with out[1] = 0 and n + 1 rows: the
+ * array is a permutation of [0, n]); out[3] rows whose BWT byte is not the text byte in front of SA[row] (0x00 in front of the whole
+ * text; row 0 must hold n); out[4] 0x00 bytes in the BWT (must be 1).  What scripts/generate_truth_set.py:92-100 of the reference
+ * states about its golden files, checked for a text of any length. */
+int pfp_debug_check_sa(pfp_ctx *ctx, uint64_t out[5]);
+/* The run samples of a build with want_sa = want_rssa = 1 against its own .bwt and .sa, on the device: run k starts where the BWT
+ * byte changes, ends in front of the next start, and carries the SA values of its first and last row (src/pfbwt-f.cpp:304-315, 325-328).
+ * out[0] runs checked, out[1] runs with a wrong row, out[2] runs with a wrong value. */
+int pfp_debug_check_samples(pfp_ctx *ctx, uint64_t out[3]);
 /* sum of the 64-bit little-endian words of a device buffer (out[0]) and of word * (word index + 1) (out[1]), modulo 2^64; a
  * trailing partial word is zero-padded.  bench.py checks the outputs that were streamed to host memory against the
  * device-resident ones with it. */

@@ -221,6 +221,7 @@ static int ingest_file(pfp_ctx *c, const char *path, unsigned flags, IngestStats
         st->mode = parallel ? 1 : 2;
     }
     if (gzf) gzclose(gzf); else if (!is_stdin) close(fd);
+    if (rc != PFP_OK) { if (f.copy_ready) (void)hipStreamSynchronize(f.copy); (void)hipStreamSynchronize(c->stream); }      // no upload of a ring block is left in flight behind an error return
     st->total_ms = timer.ms();
     return rc;
 }
@@ -235,7 +236,11 @@ static int write_device_to_fd(pfp_ctx *c, const void *d_src, uint64_t bytes, int
     PFP_TRY(ensure_copy_stream(c));
     constexpr int NB = ING_RING;
     const off_t base = lseek(fd, 0, SEEK_CUR);
-    const bool seekable = base != (off_t)-1;
+    // pwrite at computed offsets only where offsets mean something: a regular file that was not opened for appending (Linux ignores
+    // pwrite's offset on an O_APPEND descriptor: `pfbwt-f -c bwt ... >> out` would get its blocks in completion order; the reference
+    // writes sequentially with fwrite, src/pfbwt-f.cpp:298-328) -- everything else gets ONE in-order writer
+    struct stat st; const int fl = fcntl(fd, F_GETFL);
+    const bool seekable = base != (off_t)-1 && fl != -1 && !(fl & O_APPEND) && fstat(fd, &st) == 0 && S_ISREG(st.st_mode);
     const int nw = seekable ? 4 : 1;      // (measured on a memory-resident file system: 4 writers 6 GB/s, 8 writers 4.3 GB/s -- page allocation, not the copy, bounds a pwrite)
     for (int k = 0; k < NB; ++k) if (!c->ing_buf[k]) PFP_HIP(c, hipHostMalloc((void **)&c->ing_buf[k], ING_BLOCK, hipHostMallocDefault));
     hipEvent_t ev[NB];

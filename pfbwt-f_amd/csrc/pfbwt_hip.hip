@@ -463,6 +463,7 @@ static int fa_process(pfp_ctx *c, uint64_t len, int slot, bool want_recs, uint64
     if (n_new + 2 * w + 64 >= limit) return PFP_E_TOO_LARGE;                      // pfparser.hpp:326-331
     PFP_TRY(ensure_text(c, n_new + 2 * w));
     uint64_t *d_rr = nullptr, *d_rp = nullptr;
+    struct DevFree { uint64_t *&p; ~DevFree() { if (p) (void)hipFree(p); } } rr_guard{d_rr};      // freed on every path out of this function
     if (want_recs && hdr) { PFP_HIP(c, hipMalloc((void **)&d_rr, hdr * 16)); d_rp = d_rr + hdr; }
     PFP_LAUNCH(c, K_FASTA, 2 * len, k_fa_compact, t.T, (const uint8_t *)f.raw[slot], len, t, c->tb + 16, tbase, rec0, c->w, d_rr, d_rp, (uint32_t *)(f.d_tot + 4));
     PFP_HIP(c, hipEventRecord(f.ev_free[slot], c->stream)); f.used[slot] = true;
@@ -472,7 +473,6 @@ static int fa_process(pfp_ctx *c, uint64_t len, int slot, bool want_recs, uint64
         PFP_HIP(c, hipMemcpyAsync(f.rec_raw.data() + b, d_rr, hdr * 8, hipMemcpyDeviceToHost, c->stream));      // (the context's stream does not synchronise with the null stream)
         PFP_HIP(c, hipMemcpyAsync(f.rec_pos.data() + b, d_rp, hdr * 8, hipMemcpyDeviceToHost, c->stream));
         PFP_HIP(c, hipStreamSynchronize(c->stream));
-        PFP_HIP(c, hipFree(d_rr));
         for (size_t i = b; i < b + hdr; ++i) f.rec_raw[i] += rec_base;
     }
     c->n = n_new; c->tb_n = c->n; f.records = rec0 + hdr; f.state = (uint32_t)f.h_tot[2];
@@ -495,7 +495,18 @@ static int fa_finish_stream(pfp_ctx *c)
     if (fl & 1u) { c->err_ch = '+'; return PFP_E_ARG; }                             // a FASTQ quality section: not handled on the device
     return PFP_OK;
 }
+static int feed_fasta_pieces(pfp_ctx *c, const uint8_t *raw, uint64_t len, unsigned flags, uint64_t *nrec);
+// The header promises that the caller's buffer may be reused (freed, unregistered) when the call returns.  On the good path every
+// piece's upload has completed by then (fa_process waits for the piece's totals, which wait for its upload); on an error return the
+// upload of piece k + 1 may still be reading the buffer -- PFP_E_TOO_LARGE / PFP_E_NOMEM of piece k come after it was issued --
+// so every error path drains both streams first.
 static int feed_fasta_impl(pfp_ctx *c, const uint8_t *raw, uint64_t len, unsigned flags, uint64_t *nrec)
+{
+    const int rc = feed_fasta_pieces(c, raw, len, flags, nrec);
+    if (rc != PFP_OK) { if (c->fa.copy_ready) (void)hipStreamSynchronize(c->fa.copy); (void)hipStreamSynchronize(c->stream); }
+    return rc;
+}
+static int feed_fasta_pieces(pfp_ctx *c, const uint8_t *raw, uint64_t len, unsigned flags, uint64_t *nrec)
 {
     auto &f = c->fa;
     const bool want_recs = (flags & PFP_FASTA_RECORDS) != 0;
@@ -1579,16 +1590,22 @@ template <typename SAT, typename EBT> static int emit_and_sample(pfp_ctx *c, Emi
         return PFP_OK;
     };
     auto bwt_of = [&](const Win &wn) -> uint8_t * { return bwtbuf + (wn.cs - wn.cl - (s0 - lead)); };   // position cs - cl
-    // pfp_bwt_build_stream: the rows of a finished window start their way to the host while the next window is emitted
+    // pfp_bwt_build_stream: the rows of a finished window start their way to the host while the next window is emitted.  Window k + 1
+    // WRITES row cs - 1, the last row of window k, once more (k_fill puts a slot's placeholder byte there before k_emit_groups / k_emit
+    // restore the true one; run detection needs that row): a copy of window k that included it could deliver the placeholder.
+    // So every window sends its rows shifted by one -- [cs - cl, ce - 1), the last window up to ce -- and no row is in flight while a
+    // later window's kernels can still store to it.  (The row in front of a slice belongs to the neighbouring slice's buffers.)
     std::vector<hipEvent_t> wev;
     auto stream_out = [&](const Win &wn) -> int {
         if (!c->h_bwt && !c->h_sa) return PFP_OK;
+        const uint64_t r0 = wn.cs - wn.cl < s0 ? s0 : wn.cs - wn.cl, r1 = wn.ce == s1 ? wn.ce : wn.ce - 1;
+        if (r1 <= r0) return PFP_OK;
         hipEvent_t e; PFP_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); wev.push_back(e);
         PFP_HIP(c, hipEventRecord(e, c->stream));
         PFP_HIP(c, hipStreamWaitEvent(c->fa.copy, e, 0));
-        const uint64_t rows = wn.ce - wn.cs;
-        if (c->h_bwt) PFP_HIP(c, hipMemcpyAsync(c->h_bwt + (wn.cs - s0), bwt_of(wn) + wn.cl, (size_t)rows, hipMemcpyDeviceToHost, c->fa.copy));
-        if (c->h_sa && sabuf) PFP_HIP(c, hipMemcpyAsync((char *)c->h_sa + (wn.cs - s0) * sizeof(SAT), sabuf + (wn.cs - (s0 - lead)), (size_t)rows * sizeof(SAT), hipMemcpyDeviceToHost, c->fa.copy));
+        const uint64_t rows = r1 - r0;
+        if (c->h_bwt) PFP_HIP(c, hipMemcpyAsync(c->h_bwt + (r0 - s0), bwtbuf + (r0 - (s0 - lead)), (size_t)rows, hipMemcpyDeviceToHost, c->fa.copy));
+        if (c->h_sa && sabuf) PFP_HIP(c, hipMemcpyAsync((char *)c->h_sa + (r0 - s0) * sizeof(SAT), sabuf + (r0 - (s0 - lead)), (size_t)rows * sizeof(SAT), hipMemcpyDeviceToHost, c->fa.copy));
         return PFP_OK;
     };
     struct EvGuard { std::vector<hipEvent_t> &v; ~EvGuard() { for (auto e : v) (void)hipEventDestroy(e); } } evguard{wev};
@@ -2151,6 +2168,80 @@ int pfp_debug_check_sample_order(pfp_ctx *c, uint64_t out[5])
     PFP_HIP(c, hipStreamSynchronize(c->stream));
     PFP_HIP(c, hipFree(d_out));
     for (int i = 0; i < 5; ++i) out[i] = h[i];
+    return PFP_OK;
+}
+// Properties of a full suffix array at any size, on the device (the host-side version, tools/big_check.py, needs minutes and
+// 10 bytes of host memory per base): every value of [0, n] occurs exactly once (bitmap + atomicOr), row 0 holds n, BWT[row] is the
+// text byte in front of SA[row] (0x00 for the one row whose suffix is the whole text).  out: rows checked, values out of range,
+// values seen twice, rows with a wrong BWT byte, 0x00 bytes in the BWT.
+extern "C++" {
+template <typename SAT> __global__ __launch_bounds__(BLOCK) void k_check_sa(const uint8_t *X, uint64_t n, const SAT *sa, const uint8_t *bwt, uint64_t rows, uint32_t *seen, unsigned long long *out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= rows) return;
+    const uint64_t v = sa[i];
+    if (v > n) { atomicAdd(&out[1], 1ULL); return; }
+    const uint32_t bit = 1u << (v & 31);
+    if (atomicOr(&seen[v >> 5], bit) & bit) atomicAdd(&out[2], 1ULL);
+    const uint8_t want = v == 0 ? (uint8_t)0 : X[v - 1];
+    if (bwt[i] != want || (i == 0 && v != n)) atomicAdd(&out[3], 1ULL);
+    if (bwt[i] == 0) atomicAdd(&out[4], 1ULL);
+}
+}
+int pfp_debug_check_sa(pfp_ctx *c, uint64_t out[5])
+{
+    if (!c || !out) return PFP_E_ARG;
+    if (c->stage < 3 || !c->d_sa || !c->have_sa || !c->d_bwt || !c->tb || c->tb_n != c->n || c->slice_rows != c->nout) return PFP_E_STATE;      // needs the text and the whole SA
+    PFP_HIP(c, hipSetDevice(c->device));
+    const uint64_t rows = c->nout, words = (c->n + 32) / 32 + 1;
+    unsigned long long *d_out; uint32_t *seen;
+    PFP_HIP(c, hipMalloc((void **)&d_out, 40)); PFP_HIP(c, hipMalloc((void **)&seen, words * 4));
+    PFP_HIP(c, hipMemsetAsync(d_out, 0, 40, c->stream)); PFP_HIP(c, hipMemsetAsync(seen, 0, words * 4, c->stream));
+    if (c->flags & PFP_FLAG_U64) PFP_LAUNCH(c, K_MISC, rows * 10, (k_check_sa<uint64_t>), nblocks(rows, BLOCK), (const uint8_t *)c->tb + 16, c->n, (const uint64_t *)c->d_sa, (const uint8_t *)c->d_bwt, rows, seen, d_out);
+    else PFP_LAUNCH(c, K_MISC, rows * 6, (k_check_sa<uint32_t>), nblocks(rows, BLOCK), (const uint8_t *)c->tb + 16, c->n, (const uint32_t *)c->d_sa, (const uint8_t *)c->d_bwt, rows, seen, d_out);
+    unsigned long long h[5];
+    PFP_HIP(c, hipMemcpyAsync(h, d_out, 40, hipMemcpyDeviceToHost, c->stream));
+    PFP_HIP(c, hipStreamSynchronize(c->stream));
+    PFP_HIP(c, hipFree(d_out)); PFP_HIP(c, hipFree(seen));
+    out[0] = rows; for (int i = 1; i < 5; ++i) out[i] = h[i];
+    return PFP_OK;
+}
+// The run samples of a -s -r build against its own full outputs, on the device (S-3G: 2.3 G runs = 74 GB of samples, not something
+// a test moves to the host): run k starts at row ssa[k].row, a position where the BWT byte changes (or row 0), and ends at
+// esa[k].row = ssa[k + 1].row - 1 (the last one at the last row); the values are the SA entries of those rows (src/pfbwt-f.cpp:304-315,
+// 325-328).  r itself is the engine's count of byte changes, so r distinct change positions are all of them.
+// out: runs checked, runs with a wrong row, runs with a wrong value.
+extern "C++" {
+template <typename SAT> __global__ __launch_bounds__(BLOCK) void k_check_samples(const SAT *ssa, const SAT *esa, uint64_t r, const SAT *sa, const uint8_t *bwt, uint64_t rows, unsigned long long *out)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (k >= r) return;
+    const uint64_t rs = ssa[2 * k], vs = ssa[2 * k + 1], re = esa[2 * k], ve = esa[2 * k + 1];
+    bool row_ok = rs < rows && re < rows && rs <= re;
+    if (row_ok) {
+        row_ok = (k == 0 ? rs == 0 : bwt[rs] != bwt[rs - 1]) && (k + 1 == r ? re + 1 == rows : (uint64_t)ssa[2 * k + 2] == re + 1) && bwt[rs] == bwt[re];
+    }
+    if (!row_ok) { atomicAdd(&out[1], 1ULL); return; }
+    if ((uint64_t)sa[rs] != vs || (uint64_t)sa[re] != ve) atomicAdd(&out[2], 1ULL);
+}
+}
+int pfp_debug_check_samples(pfp_ctx *c, uint64_t out[3])
+{
+    if (!c || !out) return PFP_E_ARG;
+    if (c->stage < 3 || !c->d_sa || !c->have_sa || !c->have_rssa || !c->d_ssa || !c->d_esa || c->slice_rows != c->nout || c->esa_pairs != c->runs) return PFP_E_STATE;
+    PFP_HIP(c, hipSetDevice(c->device));
+    unsigned long long *d_out; PFP_HIP(c, hipMalloc((void **)&d_out, 24));
+    PFP_HIP(c, hipMemsetAsync(d_out, 0, 24, c->stream));
+    const uint64_t r = c->runs;
+    if (r) {
+        if (c->flags & PFP_FLAG_U64) PFP_LAUNCH(c, K_MISC, r * 50, (k_check_samples<uint64_t>), nblocks(r, BLOCK), (const uint64_t *)c->d_ssa, (const uint64_t *)c->d_esa, r, (const uint64_t *)c->d_sa, (const uint8_t *)c->d_bwt, c->nout, d_out);
+        else PFP_LAUNCH(c, K_MISC, r * 30, (k_check_samples<uint32_t>), nblocks(r, BLOCK), (const uint32_t *)c->d_ssa, (const uint32_t *)c->d_esa, r, (const uint32_t *)c->d_sa, (const uint8_t *)c->d_bwt, c->nout, d_out);
+    }
+    unsigned long long h[3];
+    PFP_HIP(c, hipMemcpyAsync(h, d_out, 24, hipMemcpyDeviceToHost, c->stream));
+    PFP_HIP(c, hipStreamSynchronize(c->stream));
+    PFP_HIP(c, hipFree(d_out));
+    out[0] = r; out[1] = h[1]; out[2] = h[2];
     return PFP_OK;
 }
 // page-locked host memory for the callers of pfp_bwt_build_stream / pfp_parse_feed_fasta (they need not link the HIP runtime)

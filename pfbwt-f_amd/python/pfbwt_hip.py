@@ -111,6 +111,8 @@ def load_library(path=None):
     L.pfp_host_unregister.argtypes = [vp]
     L.pfp_debug_wordsum.argtypes = [vp, vp, u64, C.POINTER(u64)]
     L.pfp_debug_check_sample_order.argtypes = [vp, C.POINTER(u64)]
+    L.pfp_debug_check_sa.argtypes = [vp, C.POINTER(u64)]
+    L.pfp_debug_check_samples.argtypes = [vp, C.POINTER(u64)]
     L.pfp_parse_docs.argtypes = [vp, C.POINTER(u64)]
     L.pfp_parse_doc_get.argtypes = [vp, u64, C.POINTER(C.c_char_p), C.POINTER(u64)]
     _libs[path] = L
@@ -204,6 +206,18 @@ class PfpContext:
         o = (C.c_uint64 * 5)()
         self._check(self.L.pfp_debug_check_sample_order(self.h, o))
         return {"pairs": int(o[0]), "order_violations": int(o[1]), "rows_not_adjacent": int(o[2]), "max_lcp": int(o[3]), "mean_lcp": (int(o[4]) / int(o[0])) if o[0] else 0.0}
+
+    def check_sa(self):
+        """permutation / T[SA-1] == BWT / one EOS byte, checked on the device against the resident text (include/pfbwt_hip_dev.h)"""
+        o = (C.c_uint64 * 5)()
+        self._check(self.L.pfp_debug_check_sa(self.h, o))
+        return {"rows": int(o[0]), "out_of_range": int(o[1]), "duplicates": int(o[2]), "bwt_mismatches": int(o[3]), "eos_bytes": int(o[4])}
+
+    def check_samples(self):
+        """the run samples of a -s -r build against its own .bwt / .sa, on the device (include/pfbwt_hip_dev.h)"""
+        o = (C.c_uint64 * 3)()
+        self._check(self.L.pfp_debug_check_samples(self.h, o))
+        return {"runs": int(o[0]), "row_errors": int(o[1]), "value_errors": int(o[2])}
 
     def bwt_get_expanded(self, host_bwt_ptr, ssa=None, threads=16):
         """.bwt into host memory from its run-length form (one byte per run over PCIe, host threads write the runs)"""

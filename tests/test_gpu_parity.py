@@ -173,6 +173,72 @@ def test_chr22_full_size_vs_oracle(gpu_ctx_factory):
     c.close()
 
 
+def test_medium_panel_default_routes_vs_oracle(gpu_ctx_factory):
+    """220 haplotypes x 1 Mbase with the DEFAULT switches against the oracle: the shape of the headline collection at a size the
+    oracle finishes in seconds.  Groups of hundreds of rows with dozens of members reach the LDS-sorting group kernel
+    (k_emit_groups_large) un-forced, the parse (2.2 M phrases) takes the recursive suffix sort (recsort.h) by itself; -r outputs
+    (.bwt .ssa .esa) and, in a second build, the full .sa"""
+    import hashlib, sys
+    sys.path.insert(0, ROOT)
+    import bench
+    seqs = bench.synth_seqs(1_000_000, 220, 1000, (0, 0, 0, 0))
+    _, dig = bench.cpu_baseline(seqs, 10, 100, True, mode=("-s", "-r"))
+    c = gpu_ctx_factory(w=10, p=100, u64=True, sai=True)
+    for sa, names in ((False, ("bwt", "ssa", "esa")), (True, ("bwt", "sa", "ssa", "esa"))):
+        c.reset()
+        for s in seqs:
+            c.feed(s, True)
+        sz = c.finalize(); c.parse_bwt(); c.bwt_build(sa=sa, rssa=True)
+        assert sz.m > (1 << 21)                                  # long enough for the recursive parse sort with the default switches
+        o = c.bwt_get()
+        for k in names:
+            assert hashlib.sha256(o[k].tobytes()).hexdigest() == dig[k], (sa, k)
+        chk = c.check_sample_order()
+        assert chk["order_violations"] == 0 and chk["rows_not_adjacent"] == 0, chk
+        if sa:      # the device-side property checks the S-3G test rests on, here next to the oracle's verdict on the same outputs
+            cs = c.check_sa()
+            assert cs["rows"] == sz.n + 1 and cs["out_of_range"] == 0 and cs["duplicates"] == 0 and cs["bwt_mismatches"] == 0 and cs["eos_bytes"] == 1, cs
+            smp = c.check_samples()
+            assert smp["row_errors"] == 0 and smp["value_errors"] == 0, smp
+    c.close()
+
+
+def test_s3g_full_size(gpu_ctx_factory):
+    """configs[2] of BASELINE.json at its full size inside the driver's own test run: S-3G (3.1 Gbase, 35 Mbp of N in two runs, -s -r,
+    64-bit uint_t).  The oracle cannot sort 3.1 G suffixes inside a unit test, so: (1) size-independent properties of the whole
+    output on the device -- SA is a permutation of [0, n], BWT[row] == T[SA[row] - 1], one EOS byte (pfp_debug_check_sa); all
+    adjacent run-boundary rows ordered, suffix against suffix on the text (pfp_debug_check_sample_order: r - 1 pairs, r = 0.74 n);
+    every run sample names a row where the BWT byte changes and carries that row's SA value (pfp_debug_check_samples); (2) sha256 of
+    .bwt .sa .ssa .esa == oracle/pfbwt_oracle on the first 100 Mbase of the same sequence."""
+    import hashlib, sys
+    sys.path.insert(0, ROOT)
+    import bench
+    L, H, seed, nruns, w, p, u64 = bench.WORKLOADS["S-3G"]
+    seqs = bench.synth_seqs(L, H, seed, nruns)
+    c = gpu_ctx_factory(w=w, p=p, u64=u64, sai=True)
+    for s in seqs:
+        c.feed(s, True)
+    sz = c.finalize(); c.parse_bwt(); b = c.bwt_build(sa=True, rssa=True)
+    assert sz.n == L + w and b.nout == sz.n + 1
+    cs = c.check_sa()
+    assert cs["rows"] == sz.n + 1 and cs["out_of_range"] == 0 and cs["duplicates"] == 0 and cs["bwt_mismatches"] == 0 and cs["eos_bytes"] == 1, cs
+    chk = c.check_sample_order()
+    assert chk["pairs"] == b.r - 1 and chk["order_violations"] == 0 and chk["rows_not_adjacent"] == 0, chk
+    smp = c.check_samples()
+    assert smp["runs"] == b.r and smp["row_errors"] == 0 and smp["value_errors"] == 0, smp
+    c.close()
+    # (2) the first 100 Mbase against the oracle
+    sub = [seqs[0][:100_000_000]]
+    _, dig = bench.cpu_baseline(sub, w, p, u64, mode=("-s", "-r"))
+    c = gpu_ctx_factory(w=w, p=p, u64=u64, sai=True)
+    c.feed(sub[0], True)
+    c.finalize(); c.parse_bwt(); c.bwt_build(sa=True, rssa=True)
+    o = c.bwt_get()
+    for k in ("bwt", "sa", "ssa", "esa"):
+        assert hashlib.sha256(o[k].tobytes()).hexdigest() == dig[k], k
+    c.close()
+
+
 def test_text_range_grows_and_moves(gpu_ctx_factory):
     """A text fed record by record without an announced size outgrows its first address range (64 MiB) and is MOVED to a larger
     one (ensure_text, csrc/pfbwt_hip.hip): eight records of 9 Mbase, a panel of one sequence with variants; -r outputs == the oracle's.

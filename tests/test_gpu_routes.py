@@ -31,6 +31,21 @@ for ci, (seqs, w, p) in enumerate(cases):
             names = ["bwt"] + (["sa"] if sa else []) + (["ssa", "esa"] if rssa else [])
             bad = compare(res, ref, U, names=tuple(names))
             assert bad == [] and res["r"] == ref["r"], (ci, U, sa, rssa, bad)
+        # streamed build (pfp_bwt_build_stream): every window's rows leave for host memory while the next window is emitted; a window
+        # re-writes the last row of its predecessor, so the copies are shifted by one row (ADVICE r3) -- with the forced window sizes of
+        # these environments (1 000 ... 100 000 rows) groups straddle most window boundaries
+        for sa, rssa in ((False, True), (True, False), (False, False)):
+            c = F(w=w, p=p, u64=(U == 8), sai=True)
+            for s in seqs: c.feed(s, True)
+            c.finalize(); c.parse_bwt()
+            hb = np.full(ref["n"] + 1, 0xEE, np.uint8); hs = np.full(ref["n"] + 1, 0xEEEEEEEE, np.uint64 if U == 8 else np.uint32)
+            b = c.bwt_build_stream(hb.ctypes.data, hs.ctypes.data if sa else None, rssa=rssa)
+            assert np.array_equal(hb, ref["bwt"]) and b.r == ref["r"], (ci, U, sa, rssa, "streamed bwt")
+            if sa: assert np.array_equal(hs.astype(np.uint64), ref["sa"]), (ci, U, "streamed sa")
+            if rssa:
+                ssa, esa = c.samples_get()
+                assert np.array_equal(ssa.astype(np.uint64), ref["ssa"]) and np.array_equal(esa.astype(np.uint64), ref["esa"]), (ci, U, sa, "streamed samples")
+            c.close()
         # sliced mode (multi-GPU emission): concatenated slices == the single-context output
         for ns, sa in ((3, True), (5, False)):
             parts = {"bwt": [], "sa": [], "ssa": [], "esa": []}; r = 0
@@ -63,6 +78,8 @@ ENVS = [
     {"PFP_DICT_TEXT_ROUNDS": "0", "PFP_INT_KEY_SYMBOLS": "2", "PFP_FORCE_RUN_ROUND": "1"},                                  # dictionary suffix sort: rank-based rounds only
     {"PFP_DICT_TEXT_ROUNDS": "1", "PFP_CLASS_SORT_MAXRANGE": "150"},   # text rounds forced (given up on repetitive inputs: second sort), large classes through the global sort   # special rows: all through the row-wise kernel (the group-stationary kernel off)
     {"PFP_EMIT_GROUP_ROWS": "40", "PFP_EMIT_CHUNK_ROWS": "20000", "PFP_FORCE_WIDE_ROWS": "1"},   # batches of at most 40 rows: most groups are left to the row-wise kernel, the rest goes through LDS
+    {"PFP_PARSE_REC": "1"},                                                                      # suffix sort of the parse through its own level-2 prefix-free parse (recsort.h), the route S-32G takes by itself
+    {"PFP_PARSE_REC": "1", "PFP_PARSE_REC_P2": "3", "PFP_PARSE_REC_TILE_ROWS": "40", "PFP_PARSE_REC_DEPTH": "2", "PFP_FORCE_WIDE_ROWS": "1"},   # two levels, assembly batches of 40 rows, larger classes through the global sort
 ]
 
 

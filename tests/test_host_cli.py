@@ -29,11 +29,11 @@ def bins(kind):
     if kind == "emu":
         subprocess.run(["make", "-C", os.path.join(ROOT, "pfbwt-f_amd"), "emu-host"], check=True, stdout=subprocess.DEVNULL)
         d = os.path.join(ROOT, "tests", "emu", "build")
-        return {"pfbwt-f": os.path.join(d, "pfbwt-f-emu"), "pfbwt-f64": os.path.join(d, "pfbwt-f64-emu"), "merge_pfp": os.path.join(d, "merge_pfp-emu")}
+        return {"pfbwt-f": os.path.join(d, "pfbwt-f-emu"), "pfbwt-f64": os.path.join(d, "pfbwt-f64-emu"), "merge_pfp": os.path.join(d, "merge_pfp-emu"), "mps_to_ma": os.path.join(d, "mps_to_ma-emu")}
     d = os.path.join(ROOT, "pfbwt-f_amd", "bin")
     for b in ("pfbwt-f", "pfbwt-f64", "merge_pfp"):
         assert os.path.exists(os.path.join(d, b)), "product binaries missing: make -C pfbwt-f_amd"
-    return {b: os.path.join(d, b) for b in ("pfbwt-f", "pfbwt-f64", "merge_pfp")}
+    return {b: os.path.join(d, b) for b in ("pfbwt-f", "pfbwt-f64", "merge_pfp", "mps_to_ma")}
 
 
 def manifest(name):
@@ -140,10 +140,62 @@ def check_stages_and_merge(B, tmp, merge_from_files=True):
     assert pr.returncode == 1 and "window size w must be < 32!" in pr.stderr
 
 
+def check_chained_recipe(B, tmp, case="mult_chroms"):
+    """The command recipe of the reference's driver, vcf_to_bwt.py:118-131, 174-181, 236-285 (configs[4] of BASELINE.json), as ONE
+    chain: every haplotype through `pfbwt-f64 --non-acgt-to-a --parse-only --print-docs -s` (one from stdin, as behind vcf_scan),
+    `merge_pfp -w W -s --parse-bwt --docs -t T` over the saved parses, `pfbwt-f64 --pfbwt-only --print-docs -w W -m MOD --stdout sa
+    -s -r` piped through `tee O.sa` into `mps_to_ma -o O.ma O.mps -`; .bwt and .sa are diffed with the reference's OWN goldens
+    (tests/data/*.bwt, *.sa -- what tests/vcf_to_bwt_test.sh:23-37 diffs), the marker array with the stream that
+    tests/test_markers.py pins to the reference's golden .markers.  The haplotypes are the golden text cut at its w-'A' pads
+    (vcf_scan / consensus and merge_mps -- the VCF front end -- are out of scope: the merged marker positions are a fixture)."""
+    import numpy as np
+    man = manifest(case); w = man["w"]
+    recs = fasta_records(input_fa(case, tmp))
+    text = b"".join(s for _, s in recs) + b"A" * w                      # the golden text: every sequence + w 'A's
+    hl = 10000 + w
+    assert len(text) == man["n"] and len(text) % hl == 0
+    haps = [text[i:i + hl - w] for i in range(0, len(text), hl)]
+    assert all(text[i + hl - w:i + hl] == b"A" * w for i in range(0, len(text), hl))
+    O = os.path.join(tmp, "chain_" + case)
+    prefixes = []
+    for h, seq in enumerate(haps):
+        pre = "%s.h%d" % (O, h); prefixes.append(pre)
+        fa = pre + ".fa"
+        open(fa, "wb").write(b">hap%d\n" % h + seq + b"\n")
+        cmd = [B["pfbwt-f64"], "--non-acgt-to-a", "--parse-only", "--print-docs", "-s", "-o", pre]
+        if h % 2:                                                          # vcf_scan --stdout | pfbwt-f64 ... (no input name: stdin)
+            with open(fa, "rb") as fi:
+                pr = subprocess.run(cmd, stdin=fi, capture_output=True, text=True)
+        else:
+            pr = subprocess.run(cmd + [fa], capture_output=True, text=True)
+        assert pr.returncode == 0, pr.stderr[-2000:]
+        os.remove(fa)                                                      # merge_pfp must load the saved .dict / .parse
+    run([B["merge_pfp"], "-w", str(w), "-s", "--parse-bwt", "--docs", "-o", O, "-t", "3"] + prefixes)
+    mps = os.path.join(GOLDEN, case, "markers.mps")
+    p1 = subprocess.Popen([B["pfbwt-f64"], "--pfbwt-only", "--print-docs", "-o", O, "-w", str(w), "-m", "100", "--stdout", "sa", "-s", "-r"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    p2 = subprocess.Popen(["tee", O + ".sa"], stdin=p1.stdout, stdout=subprocess.PIPE)
+    p3 = subprocess.run([B["mps_to_ma"], "-o", O + ".ma", mps, "-"], stdin=p2.stdout, capture_output=True, text=True)
+    p2.wait(); err1 = p1.stderr.read().decode(); p1.wait()
+    assert p1.returncode == 0 and p2.returncode == 0 and p3.returncode == 0, err1[-1500:] + p3.stderr[-1500:]
+    d = os.path.join(GOLDEN, case)
+    assert open(O + ".bwt", "rb").read() == gzip.open(os.path.join(d, "reference_golden.bwt.gz")).read()
+    assert open(O + ".sa", "rb").read() == gzip.open(os.path.join(d, "reference_golden.sa.u64.gz")).read()
+    meta = json.load(open(os.path.join(d, "markers.json")))
+    assert sha_f(O + ".ma") == meta["ma_sha256"]
+    assert "n: %d" % man["n"] in err1 and "r: %d" % man["r"] in err1
+    mf = man["files"]["u64"]
+    for e in ("ssa", "esa"):
+        assert sha_f(O + "." + e) == mf[e]["sha256"], e
+
+
 def test_cli_emu(tmp_path):
     B = bins("emu")
     check_cli(B, str(tmp_path), [("edge", "pfbwt-f64", 8), ("mult_chroms_fa", "pfbwt-f", 4)])
     check_stages_and_merge(B, str(tmp_path))
+
+
+def test_chained_recipe_emu(tmp_path):
+    check_chained_recipe(bins("emu"), str(tmp_path))
 
 
 def test_cli_asan_ubsan(tmp_path, monkeypatch):
@@ -165,6 +217,13 @@ def test_cli_gpu(tmp_path):
     B = bins("gpu")
     check_cli(B, str(tmp_path), [(n, exe, U) for n in ("edge", "w4p7", "mult_chroms_fa", "single_chrom", "mult_chroms", "panel8") for exe, U in (("pfbwt-f64", 8), ("pfbwt-f", 4))])
     check_stages_and_merge(B, str(tmp_path))
+
+
+@pytest.mark.gpu
+def test_chained_recipe_gpu(tmp_path):
+    B = bins("gpu")
+    for case in ("mult_chroms", "single_chrom"):
+        check_chained_recipe(B, str(tmp_path), case)
 
 
 # ---- the drop-in claim itself: the reference's UNCHANGED src/pfbwt-f.cpp and src/merge_pfp.cpp on top of the mirror ----
