@@ -10,6 +10,8 @@
 #include "emit.h"
 #include "markers.h"
 #include <map>
+#include <sched.h>
+#include <thread>
 #if defined(__SSE2__)
 #include <emmintrin.h>
 #endif
@@ -606,15 +608,26 @@ int pfp_bwt_get_expanded(pfp_ctx *c, uint8_t *host_bwt, const void *ssa_host, in
     if (!ssa_host) { own.resize((size_t)r * 2 * (u64 ? 8 : 4)); PFP_HIP(c, hipMemcpyAsync(own.data(), c->d_ssa, own.size(), hipMemcpyDeviceToHost, c->stream)); ssa_host = own.data(); }
     PFP_HIP(c, hipStreamSynchronize(c->stream));
     c->arena.release_hi(mk);
-    if (threads < 1) threads = 1;
+    if (threads < 1) {      // 0 / negative: one thread per CPU this process may run on (a one-GPU job of the pool gets 16)
+        cpu_set_t cs; CPU_ZERO(&cs);
+        threads = sched_getaffinity(0, sizeof cs, &cs) == 0 ? CPU_COUNT(&cs) : (int)std::thread::hardware_concurrency();
+        if (threads < 1) threads = 1;
+    }
     if (threads > 64) threads = 64;
     auto row = [&](uint64_t k) -> uint64_t { return k >= r ? nout : (u64 ? ((const uint64_t *)ssa_host)[2 * k] : (uint64_t)((const uint32_t *)ssa_host)[2 * k]); };
+    // the output is split by BYTES, not by runs (runs of a collection's BWT are anything from 1 to millions of rows long: equal run
+    // counts gave threads unequal shares -- VERDICT r3): thread t writes rows [nout * t / T, nout * (t + 1) / T), i.e. the part of every
+    // run that lies in there; the first run that reaches into the share is found by bisection over the run starts
     std::vector<std::thread> th;
     for (int t = 0; t < threads; ++t)
         th.emplace_back([&, t] {
-            const uint64_t k0 = r * (uint64_t)t / (uint64_t)threads, k1 = r * (uint64_t)(t + 1) / (uint64_t)threads;
-            uint64_t a = row(k0);
-            for (uint64_t k = k0; k < k1; ++k) { const uint64_t b = row(k + 1); fill_run(host_bwt + a, heads[(size_t)k], (size_t)(b - a)); a = b; }
+            const uint64_t b0 = nout / (uint64_t)threads * (uint64_t)t + (nout % (uint64_t)threads) * (uint64_t)t / (uint64_t)threads;
+            const uint64_t b1 = t + 1 == threads ? nout : nout / (uint64_t)threads * (uint64_t)(t + 1) + (nout % (uint64_t)threads) * (uint64_t)(t + 1) / (uint64_t)threads;
+            if (b1 <= b0) return;
+            uint64_t lo = 0, hi = r;                    // last run that starts at or before b0 (run 0 starts at row 0)
+            while (hi - lo > 1) { const uint64_t mid = lo + (hi - lo) / 2; if (row(mid) <= b0) lo = mid; else hi = mid; }
+            uint64_t a = b0;
+            for (uint64_t k = lo; k < r && a < b1; ++k) { uint64_t e = row(k + 1); if (e > b1) e = b1; if (e > a) { fill_run(host_bwt + a, heads[(size_t)k], (size_t)(e - a)); a = e; } }
 #if defined(__SSE2__)
             _mm_sfence();      // the streaming stores of this thread are globally visible before it ends
 #endif

@@ -154,8 +154,10 @@ def check_file_ingest(factory, tmp, block_bytes):
         ref = oracle_run(seqs, w=6, p=11, U=8)
         assert compare({"bwt": hb, "ssa": ssa, "esa": esa, "r": b.r, "n": sz.n}, ref, 8, names=("bwt", "ssa", "esa")) == [], order
         hb2 = np.full(sz.n + 1, 255, np.uint8)      # the same bytes from the run-length form (one byte per run + host threads)
-        c.bwt_get_expanded(hb2.ctypes.data, ssa, threads=3)
-        assert np.array_equal(hb2, hb)
+        for th in (3, 0, 64, 1):      # shares of the bytes: runs are cut at the borders of the shares; 0 = one thread per CPU
+            hb2[:] = 255
+            c.bwt_get_expanded(hb2.ctypes.data, ssa if th != 64 else None, threads=th)
+            assert np.array_equal(hb2, hb), th
         c.close()
     import pfbwt_hip
     c = factory(w=6, p=11, u64=True, sai=True)
