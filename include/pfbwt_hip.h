@@ -175,6 +175,30 @@ int pfp_shard_view_get(pfp_ctx *ctx, pfp_shard_view *view);
 int pfp_device_copy(pfp_ctx *ctx, void *d_dst, const void *d_src, uint64_t bytes);
 int pfp_merge_shards(pfp_ctx *ctx, int nshards, const pfp_shard_view *views, pfp_parse_sizes *out);
 
+/* ---- multi-GPU from ONE process: N devices, N host threads, RCCL called directly ------------------------------------------------
+ * The reference's only parallelism has this shape: src/merge_pfp.cpp:131-152 gives every std::thread its own PfParser over a
+ * contiguous slice of the inputs and folds the per-thread parsers with PfParser::operator+= (include/pfparser.hpp:194-263).  Here
+ * rank r owns device devices[r] (NULL: 0 .. ndev-1): the caller feeds rank r's run of whole sequences into pfp_sharded_ctx(s, r) with
+ * any pfp_parse_feed* call (the w 'A's that end the previous run are already in front of it, pfparser.hpp:335-337; ranks may be fed
+ * from different threads), then ONE call builds everything: every rank finalizes its shard (pfp_parse_finalize_shard), the ranks
+ * exchange {dictionary, word starts, phrase ids} in one ncclAllGather over xGMI (ncclCommInitAll at creation; librccl.so is loaded
+ * at run time, only when distinct devices have to talk -- ranks that share a device, a rehearsal of the protocol on one card,
+ * copy device to device), every rank merges (pfp_merge_shards), sorts dictionary and parse, and emits slice r of the output rows
+ * (pfp_bwt_build_slice).  Afterwards pfp_bwt_get / pfp_bwt_device_ptrs / pfp_bwt_write of rank r's context deliver slice r; the
+ * slices in rank order are the reference's .bwt / .sa / .ssa / .esa.  psz: sizes of the whole collection's parse; bsz / slice_begin /
+ * slice_rows / esa_pairs: ndev entries each (NULL skips).  A failing rank (an invalid character in its shard, ...) makes every rank
+ * give up before the collective; pfp_sharded_error names it (every rank needs at least one sequence: PFP_E_ARG otherwise).
+ * pfp_sharded_reset: all ranks ready for the next collection. */
+typedef struct pfp_sharded pfp_sharded;
+pfp_sharded *pfp_sharded_create(int w, uint64_t p, unsigned flags, int ndev, const int *devices, uint64_t workspace_bytes, int *status);
+void pfp_sharded_destroy(pfp_sharded *s);
+int pfp_sharded_ranks(pfp_sharded *s);
+pfp_ctx *pfp_sharded_ctx(pfp_sharded *s, int rank);
+int pfp_sharded_build(pfp_sharded *s, int want_sa, int want_rssa, pfp_parse_sizes *psz, pfp_bwt_sizes *bsz,
+                      uint64_t *slice_begin, uint64_t *slice_rows, uint64_t *esa_pairs);
+int pfp_sharded_reset(pfp_sharded *s);
+const char *pfp_sharded_error(pfp_sharded *s);
+
 /* ---- stage 2: BWT / SA ------------------------------------------------------------------------- */
 /* PrefixFreeBWT ctor pfbwt.hpp:64-81, for --pfbwt-only: upload .dict .occ .bwlast .ilist [.bwsai]
  * images (host memory).  Not needed when pfp_parse_finalize + pfp_parse_bwt ran in this context.

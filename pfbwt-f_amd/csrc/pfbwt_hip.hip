@@ -2450,3 +2450,5 @@ int pfp_sacak_int_u32(const uint32_t *s, uint32_t *SA, uint32_t n, uint32_t k) {
 int pfp_sacak_int_u64(const uint32_t *s, uint64_t *SA, uint64_t n, uint64_t k) { return sacak_int_impl(s, SA, n, k, true); }
 
 } // extern "C"
+
+#include "sharded.h"

@@ -113,6 +113,14 @@ def load_library(path=None):
     L.pfp_debug_check_sample_order.argtypes = [vp, C.POINTER(u64)]
     L.pfp_debug_check_sa.argtypes = [vp, C.POINTER(u64)]
     L.pfp_debug_check_samples.argtypes = [vp, C.POINTER(u64)]
+    L.pfp_sharded_create.restype = vp
+    L.pfp_sharded_create.argtypes = [i32, u64, C.c_uint, i32, C.POINTER(i32), u64, C.POINTER(i32)]
+    L.pfp_sharded_destroy.argtypes = [vp]; L.pfp_sharded_destroy.restype = None
+    L.pfp_sharded_ctx.restype = vp; L.pfp_sharded_ctx.argtypes = [vp, i32]
+    L.pfp_sharded_ranks.argtypes = [vp]
+    L.pfp_sharded_build.argtypes = [vp, i32, i32, vp, vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
+    L.pfp_sharded_reset.argtypes = [vp]
+    L.pfp_sharded_error.restype = C.c_char_p; L.pfp_sharded_error.argtypes = [vp]
     L.pfp_parse_docs.argtypes = [vp, C.POINTER(u64)]
     L.pfp_parse_doc_get.argtypes = [vp, u64, C.POINTER(C.c_char_p), C.POINTER(u64)]
     _libs[path] = L
@@ -146,7 +154,8 @@ class PfpContext:
 
     def close(self):
         if getattr(self, "h", None):
-            self.L.pfp_destroy(self.h)
+            if not getattr(self, "_borrowed", False):      # (the contexts of a ShardedBuild belong to its handle)
+                self.L.pfp_destroy(self.h)
             self.h = None
 
     def __del__(self):
@@ -376,6 +385,62 @@ class PfpContext:
 
     def backend(self):
         return self.L.pfp_backend().decode()
+
+
+class ShardedBuild:
+    """N devices driven from one process (include/pfbwt_hip.h: pfp_sharded_*): rank r's run of whole sequences is fed into
+    self.rank(r) (a PfpContext view of the library-owned context), build() makes every rank parse, exchange (RCCL between distinct
+    devices), merge, sort and emit its slice; self.rank(r).bwt_get() then returns slice r."""
+
+    def __init__(self, ndev, devices=None, w=10, p=100, u64=True, non_acgt_to_a=False, sai=True, workspace_bytes=0, lib=None):
+        self.L = load_library(lib)
+        flags = (FLAG_U64 if u64 else 0) | (FLAG_NON_ACGT_TO_A if non_acgt_to_a else 0) | (FLAG_SAI if sai else 0)
+        st = C.c_int(0)
+        dv = (C.c_int * ndev)(*devices) if devices is not None else None
+        self.h = self.L.pfp_sharded_create(int(w), int(p), flags, int(ndev), dv, int(workspace_bytes), C.byref(st))
+        if not self.h:
+            raise PfpError(st.value, self.L.pfp_strerror(st.value).decode())
+        self.ndev = ndev
+        self._ranks = []
+        for r in range(ndev):      # views of the library-owned contexts (closing them is the sharded handle's business)
+            c = PfpContext.__new__(PfpContext)
+            c.L, c.u64, c.udt, c.sai, c.sizes, c.bsizes = self.L, bool(u64), (np.uint64 if u64 else np.uint32), bool(sai), None, None
+            c.h = self.L.pfp_sharded_ctx(self.h, r); c._borrowed = True
+            self._ranks.append(c)
+
+    def rank(self, r):
+        return self._ranks[r]
+
+    def build(self, sa=True, rssa=False):
+        """returns (parse sizes of the whole collection, [(BwtSizes, first row, rows) per rank])"""
+        n = self.ndev
+        ps = ParseSizes(); bs = (BwtSizes * n)(); beg = (C.c_uint64 * n)(); rows = (C.c_uint64 * n)(); ep = (C.c_uint64 * n)()
+        st = self.L.pfp_sharded_build(self.h, 1 if sa else 0, 1 if rssa else 0, C.byref(ps), bs, beg, rows, ep)
+        if st != PFP_OK:
+            raise PfpError(st, self.L.pfp_strerror(st).decode() + " [" + self.L.pfp_sharded_error(self.h).decode() + "]")
+        out = []
+        for r, c in enumerate(self._ranks):
+            b = BwtSizes(); C.memmove(C.byref(b), C.byref(bs[r]), C.sizeof(BwtSizes))
+            c.bsizes, c._want, c._rows, c.esa_pairs = b, (bool(sa), bool(rssa)), int(rows[r]), int(ep[r])
+            out.append((b, int(beg[r]), int(rows[r])))
+        return ps, out
+
+    def reset(self):
+        st = self.L.pfp_sharded_reset(self.h)
+        if st != PFP_OK:
+            raise PfpError(st, self.L.pfp_strerror(st).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            for c in self._ranks:
+                c.h = None
+            self.L.pfp_sharded_destroy(self.h); self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def sacak_int(s, k, u64=False, lib=None):

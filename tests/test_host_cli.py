@@ -188,6 +188,21 @@ def check_chained_recipe(B, tmp, case="mult_chroms"):
         assert sha_f(O + "." + e) == mf[e]["sha256"], e
 
 
+def check_cli_gpus(B, tmp, cases):
+    """--gpus N (extension): records sharded over N ranks -- here N contexts on device 0, the rehearsal of the multi-GPU protocol on
+    one card -- must write the single-device files"""
+    for name, exe, U, ng in cases:
+        man = manifest(name); mf = man["files"]["u%d" % (U * 8)]
+        pref = os.path.join(tmp, "g_%s%d_%d" % (name, U, ng))
+        pr = run([B[exe], "-s", "-r", "--gpus", str(ng), "--devices", ",".join(["0"] * ng), "-w", str(man["w"]), "-p", str(man["p"]), "-o", pref, input_fa(name, tmp)])
+        for e in ("bwt", "sa", "ssa", "esa"):
+            assert sha_f(pref + "." + e) == mf[e]["sha256"], (name, ng, e)
+        assert "n: %d" % man["n"] in pr.stderr and "r: %d" % man["r"] in pr.stderr
+        pr = run([B[exe], "-r", "--gpus", str(ng), "--devices", ",".join(["0"] * ng), "-w", str(man["w"]), "-p", str(man["p"]), "-o", pref + "r", input_fa(name, tmp)])
+        for e in ("bwt", "ssa", "esa"):
+            assert sha_f(pref + "r." + e) == mf[e]["sha256"], (name, ng, e)
+
+
 def test_cli_emu(tmp_path):
     B = bins("emu")
     check_cli(B, str(tmp_path), [("edge", "pfbwt-f64", 8), ("mult_chroms_fa", "pfbwt-f", 4)])
@@ -196,6 +211,10 @@ def test_cli_emu(tmp_path):
 
 def test_chained_recipe_emu(tmp_path):
     check_chained_recipe(bins("emu"), str(tmp_path))
+
+
+def test_cli_gpus_emu(tmp_path):
+    check_cli_gpus(bins("emu"), str(tmp_path), [("mult_chroms_fa", "pfbwt-f64", 8, 3), ("mult_chroms_fa", "pfbwt-f", 4, 2), ("edge", "pfbwt-f64", 8, 2)])
 
 
 def test_cli_asan_ubsan(tmp_path, monkeypatch):
@@ -217,6 +236,17 @@ def test_cli_gpu(tmp_path):
     B = bins("gpu")
     check_cli(B, str(tmp_path), [(n, exe, U) for n in ("edge", "w4p7", "mult_chroms_fa", "single_chrom", "mult_chroms", "panel8") for exe, U in (("pfbwt-f64", 8), ("pfbwt-f", 4))])
     check_stages_and_merge(B, str(tmp_path))
+
+
+@pytest.mark.gpu
+def test_cli_gpus_gpu(tmp_path):
+    B = bins("gpu")
+    check_cli_gpus(B, str(tmp_path), [("mult_chroms_fa", "pfbwt-f64", 8, 3), ("panel8", "pfbwt-f64", 8, 4), ("panel8", "pfbwt-f", 4, 2), ("edge", "pfbwt-f64", 8, 2)])
+    man = manifest("panel8"); mf = man["files"]["u64"]      # one rank: the library talks to RCCL (world size 1)
+    pref = os.path.join(str(tmp_path), "g1")
+    run([B["pfbwt-f64"], "-s", "-r", "--gpus", "1", "-w", str(man["w"]), "-p", str(man["p"]), "-o", pref, input_fa("panel8", str(tmp_path))])
+    for e in ("bwt", "sa", "ssa", "esa"):
+        assert sha_f(pref + "." + e) == mf[e]["sha256"], e
 
 
 @pytest.mark.gpu

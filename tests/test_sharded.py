@@ -65,6 +65,53 @@ def test_sharded_merge_emu(emu_factory):
         assert compare(sharded_single_process(emu_factory, seqs, shards, w, p, 4, compact=True), ref, 4) == []
 
 
+def sharded_c_api(lib, seqs, shards, w, p, U, devices, sa=True):
+    """pfp_sharded_* (one process, N ranks): the slices in rank order == the single build"""
+    import pfbwt_hip
+    sb = pfbwt_hip.ShardedBuild(len(shards), devices=devices, w=w, p=p, u64=(U == 8), lib=lib)
+    res = None
+    for attempt in range(2):      # the handle is reusable: reset + feed again
+        for r, grp in enumerate(shards):
+            for i in grp:
+                sb.rank(r).feed(seqs[i], True)
+        ps, slices = sb.build(sa=sa, rssa=True)
+        parts = {"bwt": [], "sa": [], "ssa": [], "esa": []}; r_tot = 0; pos = 0
+        for r, (b, beg, rows) in enumerate(slices):
+            assert beg == pos; pos += rows
+            o = sb.rank(r).bwt_get()
+            for k in parts:
+                if o.get(k) is not None: parts[k].append(o[k])
+            r_tot += b.r
+        res = {k: np.concatenate(v) for k, v in parts.items() if v}
+        res.update(r=r_tot, n=ps.n, m=ps.m, dwords=ps.dwords, dsize=ps.dsize)
+        assert pos == ps.n + 1
+        if attempt == 0: sb.reset()
+    sb.close()
+    return res
+
+
+def test_sharded_c_api_emu(emu_factory):
+    """the C-level sharded build on the CPU interpreter: 3 and 2 ranks (unequal shards), -s -r and -r, two builds per handle; a failing
+    rank stops every rank in front of the exchange"""
+    import pfbwt_hip
+    seqs = synth(5, 4000, 5)
+    for w, p, shards, sa in ((10, 100, [[0], [1, 2], [3, 4]], True), (4, 7, [[0, 1, 2, 3], [4]], False)):
+        ref = oracle_run(seqs, w=w, p=p, U=8)
+        res = sharded_c_api(EMU_SO, seqs, shards, w, p, 8, [0] * len(shards), sa=sa)
+        assert compare(res, ref, 8, names=("bwt", "sa", "ssa", "esa") if sa else ("bwt", "ssa", "esa")) == [] and res["r"] == ref["r"]
+        assert (res["n"], res["m"], res["dwords"], res["dsize"]) == (ref["n"], ref["m"], ref["dwords"], ref["dsize"])
+    sb = pfbwt_hip.ShardedBuild(2, devices=[0, 0], w=10, p=100, lib=EMU_SO)
+    sb.rank(0).feed(seqs[0], True); sb.rank(1).feed(b"ACGTRACGT" * 50, True)
+    with pytest.raises(pfbwt_hip.PfpError) as e:
+        sb.build()
+    assert e.value.status == -2 and "rank 1" in str(e.value)
+    sb.reset()
+    sb.rank(0).feed(seqs[0], True); sb.rank(1).feed(seqs[1], True)
+    ps, _ = sb.build(sa=False, rssa=True)
+    assert ps.n == 2 * (4000 + 10)
+    sb.close()
+
+
 def seam_trigger_seqs():
     """sequences whose first w windows hold triggers for (w, p) = (4, 3) and (6, 2): a stand-alone parse cannot cut there"""
     rng = np.random.default_rng(17)
@@ -385,3 +432,16 @@ def test_sharded_build_rccl_world1(tmp_path):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29653", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     pr = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, env=env, timeout=600)
     assert pr.returncode == 0 and "nccl world-1 ok" in pr.stdout, pr.stdout[-2000:] + pr.stderr[-3000:]
+
+
+@pytest.mark.gpu
+def test_sharded_c_api_gpu():
+    """pfp_sharded_* on the MI355X: one rank through RCCL (ncclCommInitAll + ncclAllGather called by the library, world size 1),
+    and the N-rank protocol rehearsed with three ranks on the one card (device-to-device exchange, N host threads)"""
+    import pfbwt_hip
+    assert pfbwt_hip.load_library().pfp_backend().decode() == "hip-gfx950"
+    seqs = synth(9, 60000, 6)
+    ref = oracle_run(seqs, w=10, p=100, U=8)
+    for shards, devices in (([[0, 1, 2, 3, 4, 5]], None), ([[0, 1], [2], [3, 4, 5]], [0, 0, 0])):
+        res = sharded_c_api(None, seqs, shards, 10, 100, 8, devices)
+        assert compare(res, ref, 8, names=("bwt", "sa", "ssa", "esa")) == [] and res["r"] == ref["r"], devices
