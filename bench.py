@@ -421,7 +421,12 @@ def main():
     dev = torch.device("cuda", lrank)
 
     def feed_local(c):
-        c.feed_device_batch(d_all.data_ptr(), d_all.shape[0], d_all.shape[1], d_all.stride(0))
+        # the haplotype rows are resident in HBM (d_all) and stay there for the whole run: the engine reads them in place (the trigger
+        # scan of finalize writes the text); a shard with left context is fed by copy (a view must be a parse's whole text)
+        if world == 1 and not forced:
+            c.feed_device_view(d_all.data_ptr(), d_all.shape[0], d_all.shape[1], d_all.stride(0))
+        else:
+            c.feed_device_batch(d_all.data_ptr(), d_all.shape[0], d_all.shape[1], d_all.stride(0))
 
     def step():
         if world == 1 and not forced:

@@ -89,6 +89,12 @@ int pfp_parse_feed_device(pfp_ctx *ctx, const void *d_bases, uint64_t len, int e
 /* `count` records of `len` bytes each, record k at d_bases + k*stride (device memory): the same as `count` calls of
  * pfp_parse_feed_device(.., len, 1), done as one strided copy (a collection of equal-length haplotypes) */
 int pfp_parse_feed_device_batch(pfp_ctx *ctx, const void *d_bases, uint64_t count, uint64_t len, uint64_t stride);
+/* The same rows WITHOUT the copy: the caller's buffer becomes the text of this parse -- it must be the first and only feed, and the
+ * rows must stay valid and unchanged until pfp_parse_finalize returns.  The trigger scan of pfp_parse_finalize reads the rows where
+ * they are and writes the normalised text (with the w 'A's behind every row) into the context's own buffer, which the later stages
+ * use: one pass over the input instead of a copy pass and a scan pass (S-32G: 11 ms of 300).  Any other call that appends to or hands
+ * out the text first materialises the rows like pfp_parse_feed_device_batch would have.  PFP_E_STATE: the context already holds text. */
+int pfp_parse_feed_device_view(pfp_ctx *ctx, const void *d_bases, uint64_t count, uint64_t len, uint64_t stride);
 /* FASTA ingest on the device: RAW file bytes -- header lines, newlines and all -- in any chunking (host memory;
  * page-locked memory is read by DMA in place).  Stands in for kseq_read as PfParser::add_fasta drives it, include/kseq.h:178-228,
  * include/pfparser.hpp:300-337: bytes in front of the first '>' / '@' are skipped, a line that starts with '>' or '@' is a header

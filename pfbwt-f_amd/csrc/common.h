@@ -123,6 +123,7 @@ struct pfp_ctx {
     // --- text staging (device): tb = 16 guard bytes (tb[15] = Dollar) + X + w Dollars + slack
     pfp::VmRegion text;          // address range of tb; committed as the text grows (never re-allocated, never copied)
     uint8_t *tb = nullptr; size_t tb_cap = 0; uint64_t n = 0; uint64_t text_hint = 0;
+    struct RowViewPending { const uint8_t *src = nullptr; uint64_t count = 0, len = 0, stride = 0; } view;      // pfp_parse_feed_device_view: the text is still the caller's rows (read in place by the trigger scan of pfp_parse_finalize)
     uint64_t left_ctx = 0;       // bytes of left context fed in front of this shard's text (pfp_parse_feed_left_context)
     uint64_t tb_n = 0;           // bytes of tb that hold the text of the current parse (0: none -- merged or loaded state)
     // --- parse results (device, arena low end)

@@ -200,8 +200,27 @@ __global__ __launch_bounds__(BLOCK) void k_trigger_table(int w, DivTest p, uint3
     for (uint32_t b = 0; b < 32; ++b) { const uint64_t km = (uint64_t)i * 32 + b; if (km < (1ULL << (2 * w)) && divisible(wang_hash(km), p)) m |= 1u << b; }
     tab[i] = m;
 }
-__global__ __launch_bounds__(TS_THREADS) void k_trigger_scan_tab(uint8_t *X, uint64_t n, int w, const uint32_t *tab, uint32_t tabwords, uint32_t kmask, int ntoa, uint32_t tiles_per_wg,
-                                                                   uint64_t nthreads_total, uint16_t *mask16, uint64_t *blockcnt /*zeroed*/, unsigned long long *err_pos)
+// VIEW: the text is not in X yet -- it is `count` rows of `len` bytes, `stride` apart, in the caller's device memory
+// (pfp_parse_feed_device_view), each followed by the w 'A's of pfparser.hpp:335-337 that exist nowhere: the scan reads the rows where
+// they are and WRITES the normalised text (pads included) to X, which the later stages read.  Until round 4 a copy kernel laid the rows
+// out in X first (k_feed_batch: 32 GB read + 32 GB written, 11.4 ms on S-32G) and the scan read X again.
+struct RowView { const uint8_t *src; uint64_t count, len, stride, rowlen /*len + w*/; };
+// 16 text bytes that start at offset o of row r (o may run past the row: the pad, then the next rows)
+__device__ __forceinline__ uint4 view_load16(const RowView &v, uint64_t r, uint64_t o)
+{
+    while (o >= v.rowlen) { o -= v.rowlen; ++r; }
+    if (r < v.count && o + 16 <= v.len) { uint4 q; __builtin_memcpy(&q, v.src + r * v.stride + o, 16); return q; }
+    uint32_t a[4] = {0u, 0u, 0u, 0u};
+    for (int k = 0; k < 16; ++k) {
+        uint64_t oo = o + (uint64_t)k, rr = r;
+        while (oo >= v.rowlen) { oo -= v.rowlen; ++rr; }
+        const uint32_t b = rr >= v.count ? 0u : (oo < v.len ? (uint32_t)v.src[rr * v.stride + oo] : (uint32_t)'A');
+        a[k >> 2] |= b << (8 * (k & 3));
+    }
+    return make_uint4(a[0], a[1], a[2], a[3]);
+}
+template <bool VIEW> __global__ __launch_bounds__(TS_THREADS) void k_trigger_scan_tab(uint8_t *X, uint64_t n, int w, const uint32_t *tab, uint32_t tabwords, uint32_t kmask, int ntoa, uint32_t tiles_per_wg,
+                                                                   uint64_t nthreads_total, uint16_t *mask16, uint64_t *blockcnt /*zeroed*/, unsigned long long *err_pos, RowView rv)
 {
     __shared__ uint32_t stab[TS_TAB_WORDS];
     __shared__ uint32_t pk[2][TS_THREADS + 2];                     // packed bases of the tile, [0..1] = the 32 bases in front; two tiles alternate
@@ -211,24 +230,29 @@ __global__ __launch_bounds__(TS_THREADS) void k_trigger_scan_tab(uint8_t *X, uin
     // software pipeline: the 16 bytes of tile k + 1 are requested before tile k is processed (one workgroup per CU runs
     // its waves in step -- nothing else would hide the load latency)
     uint4 qn = make_uint4(0, 0, 0, 0);
-    if ((tile0 * TS_THREADS + threadIdx.x) * 16 < n) qn = *reinterpret_cast<const uint4 *>(X + (tile0 * TS_THREADS + threadIdx.x) * 16);
+    uint64_t vrow = 0, vo = 0;                                     // VIEW: row and offset in it of the current tile's first base (uniform)
+    if (VIEW) { const uint64_t p0 = tile0 * TS_THREADS * 16; vrow = p0 / rv.rowlen; vo = p0 - vrow * rv.rowlen; }
+    if ((tile0 * TS_THREADS + threadIdx.x) * 16 < n) qn = VIEW ? view_load16(rv, vrow, vo + 16u * threadIdx.x) : *reinterpret_cast<const uint4 *>(X + (tile0 * TS_THREADS + threadIdx.x) * 16);
     for (uint32_t tl = 0; tl < tiles_per_wg; ++tl) {
         const uint64_t first = (tile0 + tl) * TS_THREADS;          // in units of 16 bases
         if (first >= nthreads_total) break;                        // uniform
         const uint64_t t = first + threadIdx.x;
         const uint64_t base = t * 16;
         const uint4 q = qn;
-        if (tl + 1 < tiles_per_wg && base + (uint64_t)TS_THREADS * 16 < n) qn = *reinterpret_cast<const uint4 *>(X + base + (uint64_t)TS_THREADS * 16); else qn = make_uint4(0, 0, 0, 0);
+        if (VIEW) { vo += (uint64_t)TS_THREADS * 16; while (vo >= rv.rowlen) { vo -= rv.rowlen; ++vrow; } }      // (now of the NEXT tile)
+        if (tl + 1 < tiles_per_wg && base + (uint64_t)TS_THREADS * 16 < n) qn = VIEW ? view_load16(rv, vrow, vo + 16u * threadIdx.x) : *reinterpret_cast<const uint4 *>(X + base + (uint64_t)TS_THREADS * 16);
+        else qn = make_uint4(0, 0, 0, 0);
         uint4 nq; uint32_t bad = 0;
         const uint32_t mine = pack16(q, ntoa != 0, &bad, &nq);
         if (base < n) {
             const uint32_t live = (n - base >= 16) ? 0xffffu : ((1u << (unsigned)(n - base)) - 1u);
             if (live != 0xffffu) { // keep bytes beyond n untouched
-                uint32_t a[4] = {q.x, q.y, q.z, q.w}, b[4] = {nq.x, nq.y, nq.z, nq.w};
+                const uint4 keep = VIEW ? *reinterpret_cast<const uint4 *>(X + base) : q;
+                uint32_t a[4] = {keep.x, keep.y, keep.z, keep.w}, b[4] = {nq.x, nq.y, nq.z, nq.w};
                 for (int i = 0; i < 16; ++i) if (!((live >> i) & 1)) { b[i >> 2] = (b[i >> 2] & ~(0xffu << (8 * (i & 3)))) | (a[i >> 2] & (0xffu << (8 * (i & 3)))); }
                 nq = make_uint4(b[0], b[1], b[2], b[3]);
             }
-            if (nq.x != q.x || nq.y != q.y || nq.z != q.z || nq.w != q.w) *reinterpret_cast<uint4 *>(X + base) = nq;
+            if (VIEW || nq.x != q.x || nq.y != q.y || nq.z != q.z || nq.w != q.w) *reinterpret_cast<uint4 *>(X + base) = nq;
             bad &= live;
             if (bad) atomicMin(err_pos, (unsigned long long)(base + (uint64_t)(__ffs((int)bad) - 1)));
         }
@@ -240,7 +264,8 @@ __global__ __launch_bounds__(TS_THREADS) void k_trigger_scan_tab(uint8_t *X, uin
             if (tl) hv = oth[TS_THREADS + threadIdx.x];
             else if (first + threadIdx.x >= 2) {
                 uint32_t hb;
-                uint4 hq = *reinterpret_cast<const uint4 *>(X + (first + threadIdx.x - 2) * 16);
+                const uint64_t hp = (first + threadIdx.x - 2) * 16;      // (VIEW: the neighbouring workgroup may not have written X yet -- from the rows)
+                uint4 hq = VIEW ? view_load16(rv, hp / rv.rowlen, hp % rv.rowlen) : *reinterpret_cast<const uint4 *>(X + hp);
                 hv = pack16(hq, ntoa != 0, &hb, nullptr);
             }
             cur[threadIdx.x] = hv;

@@ -87,7 +87,7 @@ static int ensure_text(pfp_ctx *c, uint64_t need_n)
 
 static void reset_results(pfp_ctx *c)
 {
-    c->stage = 0; c->n = 0; c->tb_n = 0; c->left_ctx = 0; c->m = c->dwords = c->dsize = 0; c->nrows = 0; c->nout = c->runs = c->esa_pairs = 0;
+    c->stage = 0; c->n = 0; c->tb_n = 0; c->left_ctx = 0; c->view.src = nullptr; c->m = c->dwords = c->dsize = 0; c->nrows = 0; c->nout = c->runs = c->esa_pairs = 0;
     c->gsa_valid = false; c->d_wrank = nullptr; c->d_bwt = nullptr; c->d_sa = c->d_ssa = c->d_esa = nullptr;
     c->d_bwlast = nullptr; c->d_ilist = nullptr; c->d_bwsai = nullptr; c->d_bwl_il = nullptr;
     c->d_ma = nullptr; c->ma_words = 0; c->ma_lo_mark = (size_t)-1;
@@ -323,9 +323,11 @@ int pfp_parse_reopen(pfp_ctx *c)
     c->n = c->tb_n = n;                                         // the (normalised) text is still in place; more can be appended
     return PFP_OK;
 }
+static int flush_view(pfp_ctx *c);
 int pfp_text_view(pfp_ctx *c, const uint8_t **d_text, uint64_t *n)
 {
     if (!c || !d_text || !n) return PFP_E_ARG;
+    PFP_TRY(flush_view(c));
     if (!c->tb || c->tb_n != c->n) { *d_text = nullptr; *n = 0; return PFP_OK; }
     PFP_HIP(c, hipSetDevice(c->device));
     PFP_HIP(c, hipStreamSynchronize(c->stream));
@@ -342,12 +344,39 @@ int pfp_parse_feed_left_context(pfp_ctx *c)
     c->left_ctx = (uint64_t)c->w;
     return PFP_OK;
 }
-int pfp_parse_feed(pfp_ctx *c, const uint8_t *bases, uint64_t len, int end_of_seq) { return feed_common(c, bases, len, end_of_seq, hipMemcpyHostToDevice); }
-int pfp_parse_feed_device(pfp_ctx *c, const void *d_bases, uint64_t len, int end_of_seq) { return feed_common(c, d_bases, len, end_of_seq, hipMemcpyDeviceToDevice); }
+// a pending row view (pfp_parse_feed_device_view) becomes text in X: what every entry point that appends to or hands out the text
+// does first (the fused scan of pfp_parse_finalize is the one consumer that does not need it)
+static int flush_view(pfp_ctx *c)
+{
+    if (!c->view.src) return PFP_OK;
+    const uint64_t count = c->view.count, len = c->view.len;
+    const uint64_t blocks_per_row = ((len + 15) / 16 + BLOCK - 1) / BLOCK;
+    PFP_LAUNCH(c, K_MISC, 2 * count * len, k_feed_batch, count * blocks_per_row, c->view.src, count, len, c->view.stride, c->w, c->tb + 16);
+    c->view.src = nullptr;
+    return PFP_OK;
+}
+int pfp_parse_feed_device_view(pfp_ctx *c, const void *d_bases, uint64_t count, uint64_t len, uint64_t stride)
+{
+    if (!c || !d_bases || !count || !len || stride < len) return PFP_E_ARG;
+    PFP_HIP(c, hipSetDevice(c->device));
+    if (c->stage != 0) reset_results(c);
+    if (c->n != 0) return PFP_E_STATE;                                   // the view is the whole text of a parse
+    const uint64_t pitch = len + (uint64_t)c->w, add = count * pitch;
+    if (add + (uint64_t)c->w + 64 >= ((c->flags & PFP_FLAG_U64) ? (1ULL << 40) : 0xFFFFFFFFULL)) return PFP_E_TOO_LARGE;
+    const uint64_t blocks_per_row = ((len + 15) / 16 + BLOCK - 1) / BLOCK;
+    if (count * blocks_per_row >= 0x7FFFFFFFULL) return PFP_E_TOO_LARGE;
+    PFP_TRY(ensure_text(c, add + (uint64_t)c->w));
+    c->view.src = (const uint8_t *)d_bases; c->view.count = count; c->view.len = len; c->view.stride = stride;
+    c->n = add; c->tb_n = c->n;
+    return PFP_OK;
+}
+int pfp_parse_feed(pfp_ctx *c, const uint8_t *bases, uint64_t len, int end_of_seq) { if (c) PFP_TRY(flush_view(c)); return feed_common(c, bases, len, end_of_seq, hipMemcpyHostToDevice); }
+int pfp_parse_feed_device(pfp_ctx *c, const void *d_bases, uint64_t len, int end_of_seq) { if (c) PFP_TRY(flush_view(c)); return feed_common(c, d_bases, len, end_of_seq, hipMemcpyDeviceToDevice); }
 int pfp_parse_feed_device_batch(pfp_ctx *c, const void *d_bases, uint64_t count, uint64_t len, uint64_t stride)
 {
     if (!c || (!d_bases && count && len) || stride < len) return PFP_E_ARG;
     if (!count) return PFP_OK;
+    PFP_TRY(flush_view(c));
     if (!len) { for (uint64_t k = 0; k < count; ++k) PFP_TRY(feed_common(c, nullptr, 0, 1, hipMemcpyDeviceToDevice)); return PFP_OK; }
     PFP_HIP(c, hipSetDevice(c->device));
     if (c->stage != 0) reset_results(c);
@@ -366,6 +395,7 @@ int pfp_parse_feed_batch(pfp_ctx *c, const uint8_t *bases, uint64_t count, uint6
 {
     if (!c || (!bases && count && len) || stride < len) return PFP_E_ARG;
     if (!count) return PFP_OK;
+    PFP_TRY(flush_view(c));
     if (!len || !host_pointer_is_pinned(bases)) {      // pageable memory: record by record through the staging ring
         for (uint64_t k = 0; k < count; ++k) PFP_TRY(feed_common(c, bases + k * stride, len, 1, hipMemcpyHostToDevice));
         return PFP_OK;
@@ -504,6 +534,7 @@ static int feed_fasta_pieces(pfp_ctx *c, const uint8_t *raw, uint64_t len, unsig
 // so every error path drains both streams first.
 static int feed_fasta_impl(pfp_ctx *c, const uint8_t *raw, uint64_t len, unsigned flags, uint64_t *nrec)
 {
+    PFP_TRY(flush_view(c));
     const int rc = feed_fasta_pieces(c, raw, len, flags, nrec);
     if (rc != PFP_OK) { if (c->fa.copy_ready) (void)hipStreamSynchronize(c->fa.copy); (void)hipStreamSynchronize(c->stream); }
     return rc;
@@ -872,6 +903,7 @@ static int parse_finalize_impl(pfp_ctx *c, pfp_parse_sizes *out, bool shard_only
     PFP_HIP(c, hipMemsetAsync(d_u32, 0, 32, c->stream));
     const uint64_t kmask = (w == 32) ? 0ULL : ((1ULL << (2 * w)) - 1ULL);   // hash.hpp:26 (w == 32: observed x86 value)
     const bool no_trigtab = c->tun.no_trigger_table != 0;      // tests / measurements: the hash evaluated per base
+    if (c->view.src && !(w <= TS_MAX_W && !no_trigtab)) PFP_TRY(flush_view(c));      // the hash-per-window scan reads the text from X
     if (w <= TS_MAX_W && !no_trigtab) {
         const uint32_t tabwords = (1u << (2 * w)) >= 32u ? (1u << (2 * w)) / 32u : 1u;
         if (!c->d_trigtab) {      // w and p are fixed for the life of a context
@@ -882,8 +914,14 @@ static int parse_finalize_impl(pfp_ctx *c, pfp_parse_sizes *out, bool shard_only
         const uint64_t tiles = (nthreads_total + TS_THREADS - 1) / TS_THREADS;
         uint32_t tpw = (uint32_t)(tiles / 1024); if (tpw < 1) tpw = 1; if (tpw > 64) tpw = 64;      // enough workgroups to fill 256 CUs, the table load amortised
         PFP_HIP(c, hipMemsetAsync(blockcnt, 0, ((size_t)gts + 1) * 8, c->stream));
-        PFP_LAUNCH_B(c, K_TRIGGER_SCAN, n + n / 8, k_trigger_scan_tab, (tiles + tpw - 1) / tpw, TS_THREADS, X, n, w, (const uint32_t *)c->d_trigtab, tabwords, (uint32_t)kmask,
-                     (int)((c->flags & PFP_FLAG_NON_ACGT_TO_A) != 0), tpw, nthreads_total, mask16, blockcnt, d_err);
+        if (c->view.src) {      // the rows of pfp_parse_feed_device_view are read where they are; the scan writes the text (2 B per base instead of 1 + a copy pass)
+            const RowView rv = {c->view.src, c->view.count, c->view.len, c->view.stride, c->view.len + (uint64_t)w};
+            PFP_LAUNCH_B(c, K_TRIGGER_SCAN, 2 * n + n / 8, (k_trigger_scan_tab<true>), (tiles + tpw - 1) / tpw, TS_THREADS, X, n, w, (const uint32_t *)c->d_trigtab, tabwords, (uint32_t)kmask,
+                         (int)((c->flags & PFP_FLAG_NON_ACGT_TO_A) != 0), tpw, nthreads_total, mask16, blockcnt, d_err, rv);
+            c->view.src = nullptr;      // X holds the text from here on
+        } else
+        PFP_LAUNCH_B(c, K_TRIGGER_SCAN, n + n / 8, (k_trigger_scan_tab<false>), (tiles + tpw - 1) / tpw, TS_THREADS, X, n, w, (const uint32_t *)c->d_trigtab, tabwords, (uint32_t)kmask,
+                     (int)((c->flags & PFP_FLAG_NON_ACGT_TO_A) != 0), tpw, nthreads_total, mask16, blockcnt, d_err, RowView{nullptr, 0, 0, 0, 1});
     } else
     PFP_LAUNCH(c, K_TRIGGER_SCAN, n * 2 + n / 8, k_trigger_scan, gts, X, n, w, make_divtest(c->p), kmask, (int)((c->flags & PFP_FLAG_NON_ACGT_TO_A) != 0), mask16, blockcnt, d_err);
     PFP_TRY((device_scan<uint64_t, 0>(c, blockcnt, blockcnt, gts, blockcnt + gts)));

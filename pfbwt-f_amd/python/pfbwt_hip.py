@@ -112,6 +112,7 @@ def load_library(path=None):
     L.pfp_debug_wordsum.argtypes = [vp, vp, u64, C.POINTER(u64)]
     L.pfp_debug_check_sample_order.argtypes = [vp, C.POINTER(u64)]
     L.pfp_debug_check_sa.argtypes = [vp, C.POINTER(u64)]
+    L.pfp_parse_feed_device_view.argtypes = [vp, vp, u64, u64, u64]
     L.pfp_debug_check_samples.argtypes = [vp, C.POINTER(u64)]
     L.pfp_sharded_create.restype = vp
     L.pfp_sharded_create.argtypes = [i32, u64, C.c_uint, i32, C.POINTER(i32), u64, C.POINTER(i32)]
@@ -242,6 +243,11 @@ class PfpContext:
     def feed_host_batch(self, host_ptr, count, length, stride):
         """`count` equal-length records in host memory (pinned: one strided DMA transfer; pageable: staging ring)"""
         self._check(self.L.pfp_parse_feed_batch(self.h, C.c_void_p(int(host_ptr)), int(count), int(length), int(stride)))
+
+    def feed_device_view(self, dptr, count, length, stride):
+        """`count` equal-length records in device memory become the text of this parse WITHOUT a copy (they must stay valid until
+        finalize returns): pfp_parse_feed_device_view"""
+        self._check(self.L.pfp_parse_feed_device_view(self.h, C.c_void_p(int(dptr)), int(count), int(length), int(stride)))
 
     def feed_device(self, dptr, nbytes, end_of_seq=True):
         self._check(self.L.pfp_parse_feed_device(self.h, C.c_void_p(int(dptr)), int(nbytes), 1 if end_of_seq else 0))

@@ -1,6 +1,7 @@
 """CPU tests of the host orchestration and kernel logic through tests/emu (a fiber interpreter of the
 HIP execution model -- a debugging harness for a container without a GPU, NOT a backend: the product
 never loads it and no parity claim rests on it; the parity tests proper are tests/test_gpu_parity.py)."""
+import ctypes as C
 import os
 import subprocess
 import numpy as np
@@ -57,6 +58,59 @@ def test_emu_feed_device_batch(emu_factory):
     pa, pb = a.parse_get(), b.parse_get()
     assert all(np.array_equal(pa[k], pb[k]) for k in pa)
     a.close(); b.close()
+
+
+def check_feed_device_view(factory, to_dev=None):
+    """pfp_parse_feed_device_view (the rows stay where they are, the trigger scan of finalize reads them in place and writes the text)
+    == pfp_parse_feed_device_batch, for rows shorter than a load, rows that are no multiple of 16, lower case / N / IUPAC, the
+    hash-per-window scan (w > 10: the rows are materialised first), a view followed by another feed or a text view (materialised),
+    and the error position of an invalid character"""
+    import pfbwt_hip
+    rng = np.random.default_rng(12)
+    keep = []
+    def dev(a, length=None):      # -> (device pointer, stride)
+        if to_dev is None: return a.ctypes.data, a.shape[1]
+        ptr, stride, owner = to_dev(a, a.shape[1] if length is None else length); keep.append(owner); return ptr, stride
+    for (count, length, stride, w, p, alphabet, ntoa) in ((5, 3000, 3100, 6, 13, b"ACGT", False), (40, 7, 7, 4, 3, b"ACGT", False), (3, 16384 + 5, 16400, 10, 100, b"ACGTacgtNn", False),
+                                                          (9, 1000, 1024, 12, 50, b"ACGT", False), (4, 2500, 2500, 8, 20, b"ACGTRYKM", True), (1, 50000, 50000, 10, 100, b"ACGT", False)):
+        rows = np.zeros((count, stride), np.uint8)
+        base = rng.choice(list(alphabet), length).astype(np.uint8)
+        for h in range(count):
+            rows[h, :length] = base
+            rows[h, rng.integers(0, length, max(1, length // 100))] = rng.choice(list(alphabet), max(1, length // 100))
+        dp, stride = dev(rows, length)
+        res = []
+        for mode in ("view", "batch", "view+feed", "view+textview"):
+            c = factory(w=w, p=p, sai=True, non_acgt_to_a=ntoa)
+            if mode == "batch": c.feed_device_batch(dp, count, length, stride)
+            else: c.feed_device_view(dp, count, length, stride)
+            if mode == "view+feed": c.feed(bytes(base[:50]), True)
+            if mode == "view+textview":
+                tv = (C.c_void_p(), C.c_uint64()); c._check(c.L.pfp_text_view(c.h, C.byref(tv[0]), C.byref(tv[1]))); assert tv[1].value == count * (length + w)
+            sz = c.finalize(); c.parse_bwt(); b = c.bwt_build(sa=True, rssa=True)
+            out = c.bwt_get(); out.update(c.parse_get()); out["sizes"] = (sz.n, sz.m, sz.dwords, sz.dsize, b.r)
+            res.append(out); c.close()
+        for k in res[0]:
+            if k == "sizes": assert res[0][k] == res[1][k] == res[3][k], (count, length, k)
+            else: assert np.array_equal(res[0][k], res[1][k]) and np.array_equal(res[0][k], res[3][k]), (count, length, k)
+        assert res[2]["sizes"][0] == res[0]["sizes"][0] + min(50, length) + w
+    # an invalid character inside a viewed row: the reference's error, position and byte (hash.hpp:31)
+    rows = np.frombuffer(b"ACGT" * 500, np.uint8).copy().reshape(2, 1000); rows[1, 321] = ord("R")
+    dp, st = dev(rows)
+    c = factory(w=10, p=100); c.feed_device_view(dp, 2, 1000, st)
+    with pytest.raises(pfbwt_hip.PfpError) as e:
+        c.finalize()
+    assert e.value.status == -2 and e.value.pos == 1010 + 321 and e.value.ch == ord("R")
+    c.close()
+    c = factory(w=10, p=100); c.feed(b"ACGT" * 10, True)      # a view must be the whole text
+    with pytest.raises(pfbwt_hip.PfpError) as e:
+        c.feed_device_view(dp, 2, 1000, st)
+    assert e.value.status == -7
+    c.close()
+
+
+def test_emu_feed_device_view(emu_factory):
+    check_feed_device_view(emu_factory)
 
 
 def test_emu_pfbwt_only_path(emu_factory):

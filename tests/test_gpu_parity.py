@@ -104,6 +104,21 @@ def test_engine_pfbwt_only_path(gpu_ctx_factory):
         assert np.array_equal(out[k].astype(np.uint64), ref[k]), k
 
 
+def test_feed_device_view_gpu(gpu_ctx_factory):
+    """the fused feed + trigger scan on the MI355X (rows read in place by pfp_parse_finalize), cases of tests/test_emu_pipeline.py"""
+    from test_emu_pipeline import check_feed_device_view
+
+    def to_dev(rows, length):      # device memory without another runtime in the process: the (raw, never finalized) text of a second context
+        owner = gpu_ctx_factory(w=3, p=100)
+        for h in range(rows.shape[0]):
+            owner.feed(bytes(rows[h, :length]), True)
+        ptr, n = C.c_void_p(), C.c_uint64()
+        owner._check(owner.L.pfp_text_view(owner.h, C.byref(ptr), C.byref(n)))
+        assert n.value == rows.shape[0] * (length + 3)
+        return ptr.value, length + 3, owner
+    check_feed_device_view(gpu_ctx_factory, to_dev=to_dev)
+
+
 def test_sacak_int_dropin(gpu_ctx_factory):
     import pfbwt_hip
     from pfp_testlib import oracle
