@@ -11,6 +11,7 @@
 #include <condition_variable>
 #include <fcntl.h>
 #include <mutex>
+#include <sched.h>
 #include <string>
 #include <sys/stat.h>
 #include <thread>
@@ -20,8 +21,15 @@
 namespace pfp {
 
 constexpr size_t ING_BLOCK = (size_t)64 << 20;
-constexpr int ING_RING = 16, ING_READERS = 8;      // the ring is a multiple of the readers: a slot is always filled by the same thread
-static_assert(ING_RING % ING_READERS == 0, "ring slots per reader");
+constexpr int ING_RING = 16;      // the ring is a multiple of the readers (4, 8 or 16): a slot is always filled by the same thread
+// readers of a plain file: one per CPU the process may run on, at most 16 (a pread from the page cache is a copy at ~5 GB/s per thread: eight
+// threads gave 35 GB/s on the driver's box where the link does 57 -- VERDICT r3)
+inline int ingest_readers(const pfp_ctx *c)
+{
+    int want = c->tun.ingest_readers;
+    if (want <= 0) { cpu_set_t cs; CPU_ZERO(&cs); want = sched_getaffinity(0, sizeof cs, &cs) == 0 ? CPU_COUNT(&cs) : 8; }
+    return want >= 16 ? 16 : want >= 8 ? 8 : 4;
+}
 
 struct IngestStats { uint64_t raw_bytes = 0, records = 0; double read_wait_ms = 0, total_ms = 0; int mode = 0; };
 
@@ -136,7 +144,7 @@ static int ingest_file(pfp_ctx *c, const char *path, unsigned flags, IngestStats
         ring.len[slot] = got;
         return true;
     };
-    const int nreaders = parallel ? ING_READERS : 1;
+    const int nreaders = parallel ? ingest_readers(c) : 1;
     auto reader = [&](int tid) {
         for (uint64_t b = (uint64_t)tid;; b += (uint64_t)nreaders) {
             const int slot = (int)(b % ING_RING);

@@ -232,7 +232,12 @@ template <bool VIEW> __global__ __launch_bounds__(TS_THREADS) void k_trigger_sca
     uint4 qn = make_uint4(0, 0, 0, 0);
     uint64_t vrow = 0, vo = 0;                                     // VIEW: row and offset in it of the current tile's first base (uniform)
     if (VIEW) { const uint64_t p0 = tile0 * TS_THREADS * 16; vrow = p0 / rv.rowlen; vo = p0 - vrow * rv.rowlen; }
-    if ((tile0 * TS_THREADS + threadIdx.x) * 16 < n) qn = VIEW ? view_load16(rv, vrow, vo + 16u * threadIdx.x) : *reinterpret_cast<const uint4 *>(X + (tile0 * TS_THREADS + threadIdx.x) * 16);
+    // (a tile that lies inside one row -- all but one tile in two thousand on S-32G -- is a uniform test and one address per thread)
+    auto view_tile = [&](uint64_t row, uint64_t o) -> uint4 {
+        if (row < rv.count && o + (uint64_t)TS_THREADS * 16 <= rv.len) { uint4 q; __builtin_memcpy(&q, rv.src + row * rv.stride + o + 16u * threadIdx.x, 16); return q; }
+        return view_load16(rv, row, o + 16u * threadIdx.x);
+    };
+    if ((tile0 * TS_THREADS + threadIdx.x) * 16 < n) qn = VIEW ? view_tile(vrow, vo) : *reinterpret_cast<const uint4 *>(X + (tile0 * TS_THREADS + threadIdx.x) * 16);
     for (uint32_t tl = 0; tl < tiles_per_wg; ++tl) {
         const uint64_t first = (tile0 + tl) * TS_THREADS;          // in units of 16 bases
         if (first >= nthreads_total) break;                        // uniform
@@ -240,7 +245,7 @@ template <bool VIEW> __global__ __launch_bounds__(TS_THREADS) void k_trigger_sca
         const uint64_t base = t * 16;
         const uint4 q = qn;
         if (VIEW) { vo += (uint64_t)TS_THREADS * 16; while (vo >= rv.rowlen) { vo -= rv.rowlen; ++vrow; } }      // (now of the NEXT tile)
-        if (tl + 1 < tiles_per_wg && base + (uint64_t)TS_THREADS * 16 < n) qn = VIEW ? view_load16(rv, vrow, vo + 16u * threadIdx.x) : *reinterpret_cast<const uint4 *>(X + base + (uint64_t)TS_THREADS * 16);
+        if (tl + 1 < tiles_per_wg && base + (uint64_t)TS_THREADS * 16 < n) qn = VIEW ? view_tile(vrow, vo) : *reinterpret_cast<const uint4 *>(X + base + (uint64_t)TS_THREADS * 16);
         else qn = make_uint4(0, 0, 0, 0);
         uint4 nq; uint32_t bad = 0;
         const uint32_t mine = pack16(q, ntoa != 0, &bad, &nq);

@@ -100,7 +100,7 @@ static void reset_results(pfp_ctx *c)
 // ---- route / tuning switches (pfbwt_hip_dev.h) -----------------------------------------------------
 static const char *const tunable_names[] = {"verbose", "seg_grid", "seg_stage", "sort_k", "sort_no_table", "class_sort_maxrange", "dedup_table_log2", "no_trigger_table",
                                             "emit_chunk_rows", "fill_subs", "sample_cap", "no_runaware", "big_group_members", "force_wide_rows", "fasta_chunk_bytes", "ingest_block_bytes", "emit_group_rows", "no_slot_records", "dict_text_rounds", "int_key_symbols", "force_run_round",
-                                            "parse_rec", "parse_rec_p2", "parse_rec_min", "parse_rec_depth", "parse_rec_tile_rows", "parse_rec_table_log2"};
+                                            "ingest_readers", "parse_rec", "parse_rec_p2", "parse_rec_min", "parse_rec_depth", "parse_rec_tile_rows", "parse_rec_table_log2"};
 static int set_tunable(pfp_ctx *c, const char *key, long long v)
 {
     Tunables &t = c->tun;
@@ -125,6 +125,7 @@ static int set_tunable(pfp_ctx *c, const char *key, long long v)
     else if (!strcmp(key, "dict_text_rounds")) t.dict_text_rounds = (int)v;
     else if (!strcmp(key, "int_key_symbols")) t.int_key_symbols = (int)v;
     else if (!strcmp(key, "force_run_round")) t.force_run_round = (int)v;
+    else if (!strcmp(key, "ingest_readers")) t.ingest_readers = (int)v;
     else if (!strcmp(key, "parse_rec")) t.parse_rec = (int)v;
     else if (!strcmp(key, "parse_rec_p2")) t.parse_rec_p2 = (int)v;
     else if (!strcmp(key, "parse_rec_min")) t.parse_rec_min = v > 0 ? (uint64_t)v : 0;
