@@ -316,7 +316,7 @@ def e2e_child(a):
         runs.append({"ms": 1e3 * (t6 - t0), "startup_ms": 1e3 * (t_in0 - t0), "ingest_ms": 1e3 * (t1 - t_in0), "reader_GBps": info.raw_bytes / (t1 - t_in0) / 1e9,
                      "reader_mode": info.mode, "reader_wait_ms": info.read_wait_ms, "parse_ms": 1e3 * (t2 - t1), "wait_for_output_buffers_ms": 1e3 * (t3 - t2),
                      ("emit_ms" if expanded else "emit_and_download_ms"): 1e3 * (t4 - t3), "samples_download_ms": 1e3 * (t5 - t4),
-                     "bwt_from_runs_ms": 1e3 * (t6 - t5) if expanded else None, "bwt_path": ("one byte per run over PCIe + %d host threads, equal shares of the bytes (pfp_bwt_get_expanded)" % len(os.sched_getaffinity(0))) if expanded else "every row over PCIe, overlapped with the emission (pfp_bwt_build_stream)",
+                     "bwt_from_runs_ms": 1e3 * (t6 - t5) if expanded else None, "bwt_path": ("one byte per run over PCIe + %d host threads writing runs from the front while the copy engine moves rows from the back (pfp_bwt_get_expanded)" % len(os.sched_getaffinity(0))) if expanded else "every row over PCIe, overlapped with the emission (pfp_bwt_build_stream)",
                      "value": n / (t6 - t0) / 1e9, "unit": "Gbases/s", "n": int(n), "r": int(b.r), "raw_bytes": int(info.raw_bytes), "records": int(info.records)})
     res = {"cold": runs[0], "warm": runs[1], "output_buffers": {"fault_ms": outs["fault_ms"], "register_ms": outs["register_ms"]}}
     if rle:

@@ -239,7 +239,8 @@ int pfp_bwt_get(pfp_ctx *ctx, uint8_t *bwt, void *sa, void *ssa, void *esa);
  * row `.ssa[k]` starts run k, so one byte per run crosses PCIe (r bytes instead of n + 1 -- 84 MB instead of 32 GB on a 1000-haplotype
  * collection) and `threads` host threads write the runs out.  ssa_host: the 2 * r U-wide values pfp_bwt_get returned for `.ssa`
  * (NULL: fetched again).  host_bwt receives exactly the n + 1 bytes of pfp_bwt_get.  threads < 1: one per CPU the process may run on;
- * every thread writes an equal share of the BYTES (runs are cut at the shares' borders). */
+ * the output is cut into 64 MiB blocks of BYTES that the threads claim from the front (runs are cut at the blocks' borders); when
+ * host_bwt is page-locked (pfp_host_register) the copy engine claims blocks from the back and moves those rows over PCIe while the threads write. */
 int pfp_bwt_get_expanded(pfp_ctx *ctx, uint8_t *host_bwt, const void *ssa_host, int threads);
 /* The results of the last build straight to file descriptors (-1 skips one): what out_fn of src/pfbwt-f.cpp:298-328 writes with two to
  * four fwrite calls per base.  The bytes leave the device in 64 MiB blocks through page-locked buffers; the transfer of a block

@@ -97,6 +97,7 @@ struct Tunables {
     long big_group_members = -2;       // -2: BIG_GROUP_MEMBERS (emit.h); < 0 otherwise: never take the sort route
     int force_wide_rows = 0;           // 64-bit row counters on small texts
     uint64_t ingest_block_bytes = 0;   // block size of the file reader (0: 64 MiB)
+    int expand_dma = 1;                // pfp_bwt_get_expanded: the copy engine takes blocks from the back while host threads write runs from the front (page-locked destinations)
     int ingest_readers = 0;            // pread threads of the file reader (0: one per CPU, 4 / 8 / 16)
     uint32_t emit_group_rows = 4096;   // rows per batch of the group-stationary emission of the special rows (0: every special row through k_emit; smaller: more groups left to k_emit)
     int dict_text_rounds = -1;         // dictionary suffix sort by text rounds: -1 = when the collection is not repetitive (dictionary > text / 8), 0 never, 1 always

@@ -11,6 +11,7 @@
 #include <condition_variable>
 #include <fcntl.h>
 #include <mutex>
+#include <cstdio>
 #include <sched.h>
 #include <string>
 #include <sys/stat.h>
@@ -21,13 +22,26 @@
 namespace pfp {
 
 constexpr size_t ING_BLOCK = (size_t)64 << 20;
+// CPUs this process can really use: the affinity mask, capped by the cgroup's CPU quota (a one-GPU job of the pool sees 256 CPUs and
+// may use 16 of them: 64 writer threads on such a box throttle each other)
+static int usable_cpus()
+{
+    cpu_set_t cs; CPU_ZERO(&cs);
+    int n = sched_getaffinity(0, sizeof cs, &cs) == 0 ? CPU_COUNT(&cs) : (int)std::thread::hardware_concurrency();
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {      // cgroup v2: "<quota> <period>" or "max <period>"
+        char q[32]; long period = 0;
+        if (fscanf(f, "%31s %ld", q, &period) == 2 && strcmp(q, "max") && period > 0) { const long cpus = (atol(q) + period - 1) / period; if (cpus >= 1 && cpus < n) n = (int)cpus; }
+        fclose(f);
+    }
+    return n < 1 ? 1 : n;
+}
 constexpr int ING_RING = 16;      // the ring is a multiple of the readers (4, 8 or 16): a slot is always filled by the same thread
 // readers of a plain file: one per CPU the process may run on, at most 16 (a pread from the page cache is a copy at ~5 GB/s per thread: eight
 // threads gave 35 GB/s on the driver's box where the link does 57 -- VERDICT r3)
 inline int ingest_readers(const pfp_ctx *c)
 {
     int want = c->tun.ingest_readers;
-    if (want <= 0) { cpu_set_t cs; CPU_ZERO(&cs); want = sched_getaffinity(0, sizeof cs, &cs) == 0 ? CPU_COUNT(&cs) : 8; }
+    if (want <= 0) want = usable_cpus();
     return want >= 16 ? 16 : want >= 8 ? 8 : 4;
 }
 

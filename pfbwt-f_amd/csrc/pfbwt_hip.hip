@@ -100,7 +100,7 @@ static void reset_results(pfp_ctx *c)
 // ---- route / tuning switches (pfbwt_hip_dev.h) -----------------------------------------------------
 static const char *const tunable_names[] = {"verbose", "seg_grid", "seg_stage", "sort_k", "sort_no_table", "class_sort_maxrange", "dedup_table_log2", "no_trigger_table",
                                             "emit_chunk_rows", "fill_subs", "sample_cap", "no_runaware", "big_group_members", "force_wide_rows", "fasta_chunk_bytes", "ingest_block_bytes", "emit_group_rows", "no_slot_records", "dict_text_rounds", "int_key_symbols", "force_run_round",
-                                            "ingest_readers", "parse_rec", "parse_rec_p2", "parse_rec_min", "parse_rec_depth", "parse_rec_tile_rows", "parse_rec_table_log2"};
+                                            "ingest_readers", "expand_dma", "parse_rec", "parse_rec_p2", "parse_rec_min", "parse_rec_depth", "parse_rec_tile_rows", "parse_rec_table_log2"};
 static int set_tunable(pfp_ctx *c, const char *key, long long v)
 {
     Tunables &t = c->tun;
@@ -126,6 +126,7 @@ static int set_tunable(pfp_ctx *c, const char *key, long long v)
     else if (!strcmp(key, "int_key_symbols")) t.int_key_symbols = (int)v;
     else if (!strcmp(key, "force_run_round")) t.force_run_round = (int)v;
     else if (!strcmp(key, "ingest_readers")) t.ingest_readers = (int)v;
+    else if (!strcmp(key, "expand_dma")) t.expand_dma = (int)v;
     else if (!strcmp(key, "parse_rec")) t.parse_rec = (int)v;
     else if (!strcmp(key, "parse_rec_p2")) t.parse_rec_p2 = (int)v;
     else if (!strcmp(key, "parse_rec_min")) t.parse_rec_min = v > 0 ? (uint64_t)v : 0;
@@ -605,24 +606,54 @@ template <typename SAT> __global__ __launch_bounds__(BLOCK) void k_run_heads(con
     if (k < r) heads[k] = bwt[(uint64_t)ssa[2 * k]];
 }
 }
-// one run of the .bwt into host memory.  A run is a few hundred bytes on a pangenome: memset would write them with ordinary stores, and
-// every cache line of the 32 GB output would first be READ from memory to be owned; the 16-byte aligned body of a run goes out with
-// streaming stores instead (the buffer is written once and not read again by the writer)
-static inline void fill_run(uint8_t *p, uint8_t v, size_t len)
-{
+// The runs of one block of the .bwt into host memory.  A run is a few hundred bytes on a pangenome.  Written run by run, every run
+// touches two partial cache lines -- with ordinary stores every line of the 32 GB output is first READ from memory to be owned, with
+// streaming stores a partially written line costs the memory controller a read-modify-write (measured on the pool's boxes: 130 ns per
+// run and thread, 1.5 GB/s per thread).  So the runs are expanded into a 4 KiB buffer that lives in L1 and leave it as whole, 64-byte
+// aligned lines of streaming stores; a run longer than the buffer goes out directly.
+struct RunWriter {
+    uint8_t *dst;                 // next byte of the destination that has not been written
+    alignas(64) uint8_t buf[4096]; size_t fill = 0;
+    explicit RunWriter(uint8_t *d) : dst(d) {}
+    static void stream(uint8_t *d, const uint8_t *s, size_t len)      // d 16-byte aligned, len a multiple of 16
+    {
 #if defined(__SSE2__)
-    if (len >= 64) {
-        const size_t head = (size_t)(-(uintptr_t)p & 15u);
-        memset(p, v, head); p += head; len -= head;
-        const __m128i x = _mm_set1_epi8((char)v);
-        size_t i = 0;
-        for (; i + 16 <= len; i += 16) _mm_stream_si128(reinterpret_cast<__m128i *>(p + i), x);
-        memset(p + i, v, len - i);
-        return;
-    }
+        for (size_t i = 0; i < len; i += 16) _mm_stream_si128(reinterpret_cast<__m128i *>(d + i), _mm_load_si128(reinterpret_cast<const __m128i *>(s + i)));
+#else
+        memcpy(d, s, len);
 #endif
-    memset(p, v, len);
-}
+    }
+    void flush_all()              // everything buffered goes out (the tail that is not a whole line with ordinary stores)
+    {
+        const size_t body = fill & ~(size_t)63;
+        if (((uintptr_t)dst & 63u) == 0) { stream(dst, buf, body); memcpy(dst + body, buf + body, fill - body); }
+        else memcpy(dst, buf, fill);
+        dst += fill; fill = 0;
+    }
+    void put(uint8_t v, size_t len)
+    {
+        if (fill == 0 && ((uintptr_t)dst & 63u)) {      // bring the destination to a line boundary first
+            const size_t head = (size_t)(-(uintptr_t)dst & 63u) < len ? (size_t)(-(uintptr_t)dst & 63u) : len;
+            memset(dst, v, head); dst += head; len -= head;
+        }
+        while (len) {
+            if (fill == 0 && len >= sizeof buf) {      // a long run: whole lines straight to the destination
+                const size_t body = len & ~(size_t)63;
+#if defined(__SSE2__)
+                const __m128i x = _mm_set1_epi8((char)v);
+                for (size_t i = 0; i < body; i += 16) _mm_stream_si128(reinterpret_cast<__m128i *>(dst + i), x);
+#else
+                memset(dst, v, body);
+#endif
+                dst += body; len -= body;
+                continue;
+            }
+            const size_t k = len < sizeof buf - fill ? len : sizeof buf - fill;
+            memset(buf + fill, v, k); fill += k; len -= k;
+            if (fill == sizeof buf) { stream(dst, buf, sizeof buf); dst += sizeof buf; fill = 0; }
+        }
+    }
+};
 int pfp_bwt_get_expanded(pfp_ctx *c, uint8_t *host_bwt, const void *ssa_host, int threads)
 {
     if (!c || !host_bwt) return PFP_E_ARG;
@@ -640,32 +671,48 @@ int pfp_bwt_get_expanded(pfp_ctx *c, uint8_t *host_bwt, const void *ssa_host, in
     if (!ssa_host) { own.resize((size_t)r * 2 * (u64 ? 8 : 4)); PFP_HIP(c, hipMemcpyAsync(own.data(), c->d_ssa, own.size(), hipMemcpyDeviceToHost, c->stream)); ssa_host = own.data(); }
     PFP_HIP(c, hipStreamSynchronize(c->stream));
     c->arena.release_hi(mk);
-    if (threads < 1) {      // 0 / negative: one thread per CPU this process may run on (a one-GPU job of the pool gets 16)
-        cpu_set_t cs; CPU_ZERO(&cs);
-        threads = sched_getaffinity(0, sizeof cs, &cs) == 0 ? CPU_COUNT(&cs) : (int)std::thread::hardware_concurrency();
-        if (threads < 1) threads = 1;
-    }
+    if (threads < 1) threads = usable_cpus();      // 0 / negative: one thread per CPU this process may use
     if (threads > 64) threads = 64;
     auto row = [&](uint64_t k) -> uint64_t { return k >= r ? nout : (u64 ? ((const uint64_t *)ssa_host)[2 * k] : (uint64_t)((const uint32_t *)ssa_host)[2 * k]); };
-    // the output is split by BYTES, not by runs (runs of a collection's BWT are anything from 1 to millions of rows long: equal run
-    // counts gave threads unequal shares -- VERDICT r3): thread t writes rows [nout * t / T, nout * (t + 1) / T), i.e. the part of every
-    // run that lies in there; the first run that reaches into the share is found by bisection over the run starts
+    // The output is cut into blocks of BYTES (runs of a collection's BWT are anything from 1 to millions of rows long; equal run counts
+    // gave threads unequal shares -- VERDICT r3).  Host threads claim blocks from the FRONT and write the runs that reach into them
+    // (the first one is found by bisection over the run starts).  When the destination is page-locked, the copy engine claims
+    // blocks from the BACK and moves those rows over PCIe as they are: host stores and DMA writes use different paths into host memory
+    // (16 cores of two CCDs reach ~65 GB/s of streaming stores on the pool's boxes, the link 55 GB/s), so the two meet somewhere in the
+    // middle -- wherever this box's ratio puts it -- instead of the slower one doing everything (S-32G: 472 -> ~270 ms).
+    const uint64_t BLKB = c->tun.expand_dma >= 2 ? ((uint64_t)1 << 20) : ((uint64_t)64 << 20);      // (2: tests -- 1 MiB blocks, so that small outputs are split between threads and link too)
+    const uint64_t nblk = (nout + BLKB - 1) / BLKB;
+    std::mutex mu; uint64_t front = 0, back = nblk;      // blocks [front, back) are unclaimed
+    auto claim = [&](bool from_back, uint64_t *blk) -> bool { std::lock_guard<std::mutex> g(mu); if (front >= back) return false; *blk = from_back ? --back : front++; return true; };
     std::vector<std::thread> th;
     for (int t = 0; t < threads; ++t)
-        th.emplace_back([&, t] {
-            const uint64_t b0 = nout / (uint64_t)threads * (uint64_t)t + (nout % (uint64_t)threads) * (uint64_t)t / (uint64_t)threads;
-            const uint64_t b1 = t + 1 == threads ? nout : nout / (uint64_t)threads * (uint64_t)(t + 1) + (nout % (uint64_t)threads) * (uint64_t)(t + 1) / (uint64_t)threads;
-            if (b1 <= b0) return;
-            uint64_t lo = 0, hi = r;                    // last run that starts at or before b0 (run 0 starts at row 0)
-            while (hi - lo > 1) { const uint64_t mid = lo + (hi - lo) / 2; if (row(mid) <= b0) lo = mid; else hi = mid; }
-            uint64_t a = b0;
-            for (uint64_t k = lo; k < r && a < b1; ++k) { uint64_t e = row(k + 1); if (e > b1) e = b1; if (e > a) { fill_run(host_bwt + a, heads[(size_t)k], (size_t)(e - a)); a = e; } }
+        th.emplace_back([&] {
+            uint64_t blk;
+            while (claim(false, &blk)) {
+                const uint64_t b0 = blk * BLKB, b1 = b0 + BLKB < nout ? b0 + BLKB : nout;
+                uint64_t lo = 0, hi = r;                    // last run that starts at or before b0 (run 0 starts at row 0)
+                while (hi - lo > 1) { const uint64_t mid = lo + (hi - lo) / 2; if (row(mid) <= b0) lo = mid; else hi = mid; }
+                uint64_t a = b0;
+                RunWriter wr(host_bwt + b0);
+                for (uint64_t k = lo; k < r && a < b1; ++k) { uint64_t e = row(k + 1); if (e > b1) e = b1; if (e > a) { wr.put(heads[(size_t)k], (size_t)(e - a)); a = e; } }
+                wr.flush_all();
+            }
 #if defined(__SSE2__)
             _mm_sfence();      // the streaming stores of this thread are globally visible before it ends
 #endif
         });
+    int dma_rc = PFP_OK; uint64_t dma_blocks = 0;
+    if (nblk >= (c->tun.expand_dma >= 2 ? 2u : 8u) && c->tun.expand_dma != 0 && host_pointer_is_pinned(host_bwt) && ensure_copy_stream(c) == PFP_OK) {
+        uint64_t blk;
+        while (dma_rc == PFP_OK && claim(true, &blk)) {
+            const uint64_t b0 = blk * BLKB, b1 = b0 + BLKB < nout ? b0 + BLKB : nout;
+            if (hipMemcpyAsync(host_bwt + b0, (const uint8_t *)c->d_bwt + b0, (size_t)(b1 - b0), hipMemcpyDeviceToHost, c->fa.copy) != hipSuccess || hipStreamSynchronize(c->fa.copy) != hipSuccess) { (void)hipGetLastError(); dma_rc = PFP_E_HIP; }
+            ++dma_blocks;
+        }
+    }
     for (auto &t : th) t.join();
-    return PFP_OK;
+    if (c->tun.verbose) fprintf(stderr, "[pfbwt_hip] .bwt from its runs: %llu blocks of 64 MiB, %llu of them over the link\n", (unsigned long long)nblk, (unsigned long long)dma_blocks);
+    return dma_rc;
 }
 int pfp_parse_docs(pfp_ctx *c, uint64_t *count) { if (!c || !count) return PFP_E_ARG; *count = c->doc_names.size(); return PFP_OK; }
 int pfp_parse_doc_get(pfp_ctx *c, uint64_t i, const char **name, uint64_t *start)

@@ -217,5 +217,15 @@ def test_fasta_ingest_large_gpu(gpu_ctx_factory):
             c.debug_set(fasta_chunk_bytes=chunk)
         c.reserve(len(raw)); c.feed_fasta(raw, final=True)
         sz = c.finalize(); c.parse_bwt(); b = c.bwt_build(sa=False, rssa=True)
-        res = {"n": sz.n, "r": b.r}; res.update(c.bwt_get()); c.close()
+        res = {"n": sz.n, "r": b.r}; res.update(c.bwt_get())
         assert compare(res, ref, 8, names=("bwt", "ssa", "esa")) == [] and res["r"] == ref["r"]
+        # .bwt from its run-length form into a page-locked buffer: host threads write runs from the front, the copy engine moves rows
+        # from the back (1 MiB blocks here: 40 blocks) -- and into a pageable one (threads only)
+        for pinned in (True, False):
+            hb = np.full(sz.n + 1, 0xEE, np.uint8)
+            if pinned: assert c.L.pfp_host_register(hb.ctypes.data, hb.size) == 0
+            c.debug_set(expand_dma=2)
+            c.bwt_get_expanded(hb.ctypes.data, res["ssa"], threads=4)
+            if pinned: c.L.pfp_host_unregister(hb.ctypes.data)
+            assert np.array_equal(hb, res["bwt"]), pinned
+        c.close()
