@@ -453,6 +453,12 @@ __global__ __launch_bounds__(BLOCK) void k_dedup_insert(const uint8_t *Y, Spans 
 {
     __shared__ uint32_t tile[DD_TILE_BYTES / 4 + 20];
     __shared__ unsigned long long wlo[BLOCK / WAVE], whi[BLOCK / WAVE];
+    __shared__ uint32_t abandoned;
+    // a table that is being abandoned (a non-repetitive text fills the first, small table after an eighth of its phrases): the workgroups
+    // that have not started yet return at once instead of hashing their phrases for nothing (S-3G: 19 of 38 ms)
+    if (threadIdx.x == 0) abandoned = *(volatile uint32_t *)t.overflow;
+    __syncthreads();
+    if (abandoned) return;
     const uint64_t j = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     const bool live = j < m;
     tpos_t ys = 0; uint32_t len = 0;

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Full-size cross-check of the routes that round 3 added against the routes they replace (validated at full size in round 2):
-a bench workload is built with the default switches and again with the old routes forced -- row-wise emission of the special rows
+a bench workload is built with the default switches (round 4: recursive suffix sort of the parse, rows fed by view) and again with the old routes forced -- the parse sorted by prefix doubling (parse_rec = 0), rows copied in, row-wise emission of the special rows
 (emit_group_rows = 0), two-gather slot fields (no_slot_records = 1), rank-based dictionary sort (dict_text_rounds = 0), two parse
 symbols in the initial key, run round always, emission windows of 2^30 rows -- and the position-weighted device checksums (pfp_debug_checksum) of every output
 (.bwt, .sa if the workload has one, .ssa, .esa) and r must be equal.  Nothing leaves the device; no oracle is involved: small
@@ -21,7 +21,7 @@ U = 8 if u64 else 4
 h_all = torch.empty((H, Lb), dtype=torch.uint8, pin_memory=True)
 bench.synth_seqs(Lb, H, seed, nruns, out=h_all.numpy())
 d_all = h_all.to("cuda"); del h_all
-OLD = dict(emit_group_rows=0, no_slot_records=1, dict_text_rounds=0, int_key_symbols=2, force_run_round=1, emit_chunk_rows=1 << 30)
+OLD = dict(emit_group_rows=0, no_slot_records=1, dict_text_rounds=0, int_key_symbols=2, force_run_round=1, emit_chunk_rows=1 << 30, parse_rec=0)      # parse_rec=0 (round 4): the parse suffix-sorted by prefix doubling, as in rounds 1-3
 
 
 def build(switches):
@@ -30,7 +30,8 @@ def build(switches):
     lib = ctx.L
     lib.pfp_debug_checksum.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64 * 2)]
     t0 = time.time()
-    ctx.feed_device_batch(d_all.data_ptr(), d_all.shape[0], d_all.shape[1], d_all.stride(0))
+    if switches: ctx.feed_device_batch(d_all.data_ptr(), d_all.shape[0], d_all.shape[1], d_all.stride(0))      # the old routes: rows copied in
+    else: ctx.feed_device_view(d_all.data_ptr(), d_all.shape[0], d_all.shape[1], d_all.stride(0))               # default: rows read in place (round 4)
     sz = ctx.finalize(); ctx.parse_bwt(); b = ctx.bwt_build(sa=want_sa, rssa=want_rssa)
     torch.cuda.synchronize(); dt = time.time() - t0
     pb, psa, ps, pe = ctx.bwt_device_ptrs()
