@@ -402,7 +402,10 @@ struct DedupTable {
     uint32_t *slotof;                                             // per phrase: its entry
     uint32_t *dslot; uint64_t *dhash; uint32_t *nd; uint32_t limit;   // the entries in use (appended by whoever created them) and their hashes
     uint32_t *overflow;                                           // != 0: more distinct phrases than `limit` (or a probe sequence too long): retry with a larger table
+    uint32_t *abandon;                                            // the same news on a cache line of its own: read by every workgroup when it starts (`overflow` shares its line with the
+                                                                  // counters the insertions bump -- 1.3 M workgroup starts reading THAT line cost 8 ms on S-32G)
 };
+__device__ __forceinline__ void ht_give_up(const DedupTable &t, uint32_t code) { *t.overflow = code; *t.abandon = 1u; }
 // phrase j (hash h, bytes Y[ys..ys+len)) enters the table or finds its representative there
 __device__ __forceinline__ void dedup_find_or_insert(const uint8_t *Y, const Spans &sp, const DedupTable &t, uint32_t j, tpos_t ys, uint32_t len, uint64_t h)
 {
@@ -416,7 +419,7 @@ __device__ __forceinline__ void dedup_find_or_insert(const uint8_t *Y, const Spa
             cur = atomicCAS(&t.ent[slot].tab, (unsigned long long)HT_EMPTY, (unsigned long long)((filt << 32) | j));
             if (cur == HT_EMPTY) {                               // this phrase is the representative of a new entry
                 const uint32_t k = atomicAdd(t.nd, 1u);
-                if (k >= t.limit) { *t.overflow = 1; return; }
+                if (k >= t.limit) { ht_give_up(t, 1u); return; }
                 t.dslot[k] = (uint32_t)slot; t.dhash[k] = h; t.ent[slot].kidx = k;
                 t.slotof[j] = k; atomicAdd(&t.ent[slot].cnt, 1u);
                 return;
@@ -427,7 +430,7 @@ __device__ __forceinline__ void dedup_find_or_insert(const uint8_t *Y, const Spa
             if (rlen == len && str_equal(Y + ys, Y + rs, len)) { t.slotof[j] = entry_ref(t.ent, slot); atomicAdd(&t.ent[slot].cnt, 1u); return; }
         }
     }
-    *t.overflow = 2;
+    ht_give_up(t, 2u);
 }
 // One thread per phrase; phrases longer than LONG_PHRASE are only listed (a workgroup each, below).  The 256 phrases of a
 // workgroup are neighbours in the text (~26 KB at p = 100): their bytes are brought into LDS by coalesced 16-byte loads
@@ -456,7 +459,7 @@ __global__ __launch_bounds__(BLOCK) void k_dedup_insert(const uint8_t *Y, Spans 
     __shared__ uint32_t abandoned;
     // a table that is being abandoned (a non-repetitive text fills the first, small table after an eighth of its phrases): the workgroups
     // that have not started yet return at once instead of hashing their phrases for nothing (S-3G: 19 of 38 ms)
-    if (threadIdx.x == 0) abandoned = *(volatile uint32_t *)t.overflow;
+    if (threadIdx.x == 0) abandoned = *(volatile uint32_t *)t.abandon;
     __syncthreads();
     if (abandoned) return;
     const uint64_t j = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -507,7 +510,7 @@ __global__ __launch_bounds__(BLOCK) void k_dedup_insert(const uint8_t *Y, Spans 
             cur = atomicCAS(&t.ent[slot].tab, (unsigned long long)HT_EMPTY, (unsigned long long)((filt << 32) | (uint32_t)j));
             if (cur == HT_EMPTY) {
                 const uint32_t k = atomicAdd(t.nd, 1u);
-                if (k >= t.limit) { *t.overflow = 1; return; }
+                if (k >= t.limit) { ht_give_up(t, 1u); return; }
                 t.ent[slot].rinfo = ((unsigned long long)ys << 16) | len;
                 t.dslot[k] = (uint32_t)slot; t.dhash[k] = h; t.ent[slot].kidx = k;
                 t.slotof[j] = k; atomicAdd(&t.ent[slot].cnt, 1u);
@@ -545,7 +548,7 @@ __global__ __launch_bounds__(BLOCK) void k_dedup_insert(const uint8_t *Y, Spans 
             }
         }
     }
-    *t.overflow = 2;
+    ht_give_up(t, 2u);
 }
 // ---- long phrases (e.g. a 10 Mbp run of N is ONE phrase: wang_hash(0) % 100 != 0): one workgroup
 // per phrase hashes and compares it cooperatively; thread 0 walks the probe sequence
@@ -584,7 +587,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dedup_insert_long(const uint8_t 
                     cur = atomicCAS(&t.ent[slot].tab, (unsigned long long)HT_EMPTY, (unsigned long long)((filt << 32) | j));
                     if (cur == HT_EMPTY) {
                         const uint32_t k = atomicAdd(t.nd, 1u);
-                        if (k >= t.limit) *t.overflow = 1;
+                        if (k >= t.limit) ht_give_up(t, 1u);
                         else { t.dslot[k] = (uint32_t)slot; t.dhash[k] = h; t.ent[slot].kidx = k; t.slotof[j] = k; atomicAdd(&t.ent[slot].cnt, 1u); }
                         st = 1;
                     }
@@ -617,7 +620,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dedup_insert_long(const uint8_t 
         slot = (slot + 1) & t.mask;
         __syncthreads();
     }
-    if (threadIdx.x == 0) *t.overflow = 2;
+    if (threadIdx.x == 0) ht_give_up(t, 2u);
 }
 // ids = position of an entry's hash among the sorted hashes of the entries in use (deterministic whatever thread created
 // the entry): rep[id] = its representative phrase, occw[id] = its occurrences; the entry then holds the id

@@ -777,6 +777,7 @@ static int dedup_strings(pfp_ctx *c, const uint8_t *Y, Spans sp, uint64_t m, uin
     const uint64_t maxlong = total_bytes / LONG_PHRASE + 2;
     PFP_ALLOC_HI(c, longlist, uint32_t, maxlong);
     PFP_ALLOC_HI(c, d_u32, uint32_t, 8);
+    uint32_t *d_abandon; PFP_ALLOC_HI(c, d_abandon, uint32_t, 64);      // a 256-byte block of its own
     PFP_ALLOC_HI(c, slotof, uint32_t, m);
     const unsigned gm = nblocks(m, BLOCK);
     const int force_small = c->tun.dedup_table_log2;      // tests: a first table that overflows
@@ -796,7 +797,8 @@ static int dedup_strings(pfp_ctx *c, const uint8_t *Y, Spans sp, uint64_t m, uin
         if (limit >= 0x7FFFFFFFULL || T > 0x80000000ULL) return PFP_E_TOO_LARGE;      // dense entry indices and slots share 31 bits of slotof[]
         PFP_ALLOC_HI(c, t.ent, DedupEntry, T);
         PFP_ALLOC_HI(c, t.dslot, uint32_t, limit); PFP_ALLOC_HI(c, t.dhash, uint64_t, limit);
-        t.mask = T - 1; t.slotof = slotof; t.nd = d_u32; t.limit = (uint32_t)limit; t.overflow = d_u32 + 1;
+        t.mask = T - 1; t.slotof = slotof; t.nd = d_u32; t.limit = (uint32_t)limit; t.overflow = d_u32 + 1; t.abandon = d_abandon;
+        PFP_HIP(c, hipMemsetAsync(d_abandon, 0, 4, c->stream));
         PFP_HIP(c, hipMemsetAsync(t.ent, 0xFF, T * sizeof(DedupEntry), c->stream));
         PFP_HIP(c, hipMemsetAsync(d_u32, 0, 32, c->stream));
         PFP_LAUNCH(c, K_PHRASE_HASH, 2 * total_bytes + m * 24, k_dedup_insert, gm, Y, sp, m, c->hash_seed, t, longlist, d_u32 + 2, last_out);
