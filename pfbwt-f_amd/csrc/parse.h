@@ -227,26 +227,34 @@ template <bool VIEW> __global__ __launch_bounds__(TS_THREADS) void k_trigger_sca
     for (uint32_t i = threadIdx.x; i < tabwords; i += TS_THREADS) stab[i] = tab[i];
     const int lane = threadIdx.x & 63;
     const uint64_t tile0 = (uint64_t)blockIdx.x * tiles_per_wg;
-    // software pipeline: the 16 bytes of tile k + 1 are requested before tile k is processed (one workgroup per CU runs
-    // its waves in step -- nothing else would hide the load latency)
-    uint4 qn = make_uint4(0, 0, 0, 0);
-    uint64_t vrow = 0, vo = 0;                                     // VIEW: row and offset in it of the current tile's first base (uniform)
-    if (VIEW) { const uint64_t p0 = tile0 * TS_THREADS * 16; vrow = p0 / rv.rowlen; vo = p0 - vrow * rv.rowlen; }
+    // software pipeline: the 16 bytes of the tiles k + 1 .. k + 3 are on their way while tile k is processed.  One workgroup per CU (the
+    // table fills the LDS) means 16 waves of loads per CU: with ONE tile ahead the scan that also WRITES the text (row view) took 7.0 ms per
+    // 8 Gbase, with three 5.7 (the read-only scan stays at 5.0: tools/view_bench.py).  Three NAMED registers: a rotated array made the
+    // compiler wait for every load where it was issued -- no gain at any depth.
+    uint64_t prow = 0, po = 0;                                     // VIEW: row and offset in it of the next tile to be requested (uniform)
+    if (VIEW) { const uint64_t p0 = tile0 * TS_THREADS * 16; prow = p0 / rv.rowlen; po = p0 - prow * rv.rowlen; }
     // (a tile that lies inside one row -- all but one tile in two thousand on S-32G -- is a uniform test and one address per thread)
     auto view_tile = [&](uint64_t row, uint64_t o) -> uint4 {
         if (row < rv.count && o + (uint64_t)TS_THREADS * 16 <= rv.len) { uint4 q; __builtin_memcpy(&q, rv.src + row * rv.stride + o + 16u * threadIdx.x, 16); return q; }
         return view_load16(rv, row, o + 16u * threadIdx.x);
     };
-    if ((tile0 * TS_THREADS + threadIdx.x) * 16 < n) qn = VIEW ? view_tile(vrow, vo) : *reinterpret_cast<const uint4 *>(X + (tile0 * TS_THREADS + threadIdx.x) * 16);
+    uint32_t requested = 0;                                        // tiles of this workgroup requested so far (in order)
+    auto request = [&]() -> uint4 {
+        uint4 r = make_uint4(0, 0, 0, 0);
+        const uint64_t b = ((tile0 + requested) * TS_THREADS + threadIdx.x) * 16;
+        if (requested < tiles_per_wg && b < n) r = VIEW ? view_tile(prow, po) : *reinterpret_cast<const uint4 *>(X + b);
+        if (VIEW) { po += (uint64_t)TS_THREADS * 16; while (po >= rv.rowlen) { po -= rv.rowlen; ++prow; } }
+        ++requested;
+        return r;
+    };
+    uint4 qa = request(), qb = request(), qc = request();
     for (uint32_t tl = 0; tl < tiles_per_wg; ++tl) {
         const uint64_t first = (tile0 + tl) * TS_THREADS;          // in units of 16 bases
         if (first >= nthreads_total) break;                        // uniform
         const uint64_t t = first + threadIdx.x;
         const uint64_t base = t * 16;
-        const uint4 q = qn;
-        if (VIEW) { vo += (uint64_t)TS_THREADS * 16; while (vo >= rv.rowlen) { vo -= rv.rowlen; ++vrow; } }      // (now of the NEXT tile)
-        if (tl + 1 < tiles_per_wg && base + (uint64_t)TS_THREADS * 16 < n) qn = VIEW ? view_tile(vrow, vo) : *reinterpret_cast<const uint4 *>(X + base + (uint64_t)TS_THREADS * 16);
-        else qn = make_uint4(0, 0, 0, 0);
+        const uint4 q = qa;
+        qa = qb; qb = qc; qc = request();
         uint4 nq; uint32_t bad = 0;
         const uint32_t mine = pack16(q, ntoa != 0, &bad, &nq);
         if (base < n) {
