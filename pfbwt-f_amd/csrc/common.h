@@ -110,6 +110,8 @@ struct Tunables {
     uint64_t parse_rec_min = 1u << 21; // shortest parse that takes it (below: launch latencies, not data, bound either route)
     int parse_rec_depth = 1;           // levels (the names of one level are as long as a second level's dictionary on the collections measured)
     uint32_t parse_rec_tile_rows = 0;  // rows per assembly batch (0: a full LDS tile; smaller: reaches the large-class route on small inputs)
+    int dict_rec = -1;                 // suffix sort of the dictionary through a level-2 parse of the dictionary (dictrec.h): -1 = when the collection is repetitive, 0 never, 1 whenever the route can run
+    int dict_rec_p2 = 16;              // its modulus (windows of four bytes)
     int parse_rec_table_log2 = 0;      // log2 of the level-2 phrase table (tests: a table that overflows -> doubling route)
 };
 

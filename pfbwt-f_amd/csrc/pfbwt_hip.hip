@@ -7,6 +7,7 @@
 #include "fasta.h"
 #include "sufsort.h"
 #include "recsort.h"
+#include "dictrec.h"
 #include "emit.h"
 #include "markers.h"
 #include <map>
@@ -100,7 +101,7 @@ static void reset_results(pfp_ctx *c)
 // ---- route / tuning switches (pfbwt_hip_dev.h) -----------------------------------------------------
 static const char *const tunable_names[] = {"verbose", "seg_grid", "seg_stage", "sort_k", "sort_no_table", "class_sort_maxrange", "dedup_table_log2", "no_trigger_table",
                                             "emit_chunk_rows", "fill_subs", "sample_cap", "no_runaware", "big_group_members", "force_wide_rows", "fasta_chunk_bytes", "ingest_block_bytes", "emit_group_rows", "no_slot_records", "dict_text_rounds", "int_key_symbols", "force_run_round",
-                                            "ingest_readers", "expand_dma", "parse_rec", "parse_rec_p2", "parse_rec_min", "parse_rec_depth", "parse_rec_tile_rows", "parse_rec_table_log2"};
+                                            "ingest_readers", "expand_dma", "parse_rec", "parse_rec_p2", "parse_rec_min", "parse_rec_depth", "parse_rec_tile_rows", "parse_rec_table_log2", "dict_rec", "dict_rec_p2"};
 static int set_tunable(pfp_ctx *c, const char *key, long long v)
 {
     Tunables &t = c->tun;
@@ -133,6 +134,8 @@ static int set_tunable(pfp_ctx *c, const char *key, long long v)
     else if (!strcmp(key, "parse_rec_depth")) t.parse_rec_depth = (int)v;
     else if (!strcmp(key, "parse_rec_tile_rows")) t.parse_rec_tile_rows = v > 0 ? (uint32_t)v : 0u;
     else if (!strcmp(key, "parse_rec_table_log2")) t.parse_rec_table_log2 = (int)v;
+    else if (!strcmp(key, "dict_rec")) t.dict_rec = (int)v;
+    else if (!strcmp(key, "dict_rec_p2")) t.dict_rec_p2 = (int)v;
     else return PFP_E_ARG;
     return PFP_OK;
 }
@@ -747,6 +750,14 @@ static int sort_dict_suffixes(pfp_ctx *c)
     // emission takes the class heads per SLOT (d_srank), the word ranks come from the word-start flags that travel with the
     // suffixes (d_sflag).  A repetitive collection (pangenome: dictionary << text, variant words share long prefixes) keeps the
     // rank-based rounds, whose covered prefix doubles / quadruples; so does a dictionary on which the text rounds are given up.
+    // A repetitive collection's dictionary is repetitive itself: sorted through its own level-2 parse (dictrec.h); outputs as of the text rounds
+    if (c->tun.dict_rec > 0 || (c->tun.dict_rec < 0 && c->n != 0 && N <= c->n / 8 && N >= ((uint64_t)1 << 22))) {
+        PFP_ALLOC_LO(c, c->d_sflag, uint8_t, N);
+        int taken = 0;
+        PFP_TRY(dict_sort_pfp(c, c->d_gsa, c->d_srank, c->d_sflag, &taken));
+        if (taken) { c->d_grank = nullptr; c->arena.release_hi(mk); c->gsa_valid = true; return PFP_OK; }
+        c->d_sflag = nullptr; c->arena.release_lo(lo_state);
+    }
     const int want = c->tun.dict_text_rounds;
     bool text_mode = want > 0 || (want < 0 && c->n != 0 && N > c->n / 8);
     if (text_mode) {

@@ -259,9 +259,9 @@ template <int NB> __device__ __forceinline__ void rs_same_digit_lanes(uint32_t d
 // 35 bits = 4 passes (8-bit digits and the class's first row as high part: 6 passes, 13.1 ms) -- and stored: SA[1 + row] = text
 // position (row 0 is the final 0).  A class with more rows than a tile is appended to `bigc` (global sort route).
 constexpr int RA_DB = 9, RA_RADIX = 1 << RA_DB;
-template <bool RANK> __global__ __launch_bounds__(BLOCK) void k_rs_assemble(const uint4 *srec, const uint32_t *chead /*nc + 1*/, const uint32_t *crow /*nc + 1*/, uint32_t nc,
+template <bool RANK, bool KEYOUT> __global__ __launch_bounds__(BLOCK) void k_rs_assemble(const uint4 *srec, const uint32_t *chead /*nc + 1*/, const uint32_t *crow /*nc + 1*/, uint32_t nc,
                                                                             const uint32_t *ikey, const uint32_t *ipos, int keybits, uint32_t tile_rows, uint32_t *SA, uint32_t *rank,
-                                                                            uint32_t *bigc, uint32_t *nbig)
+                                                                            uint32_t *bigc, uint32_t *nbig, uint32_t *okey /*KEYOUT (dictrec.h): the key of every row, in row order*/)
 {
     constexpr int ITEMS = RS_ITEMS, TILE = RS_TILE;
     constexpr uint32_t STEP = TILE / 2;
@@ -361,6 +361,11 @@ template <bool RANK> __global__ __launch_bounds__(BLOCK) void k_rs_assemble(cons
             }
             __syncthreads();
         }
+        if (KEYOUT) {
+            const uint64_t km = keybits >= 32 ? 0xFFFFFFFFULL : ((1ULL << keybits) - 1ULL);
+            for (uint32_t i = threadIdx.x; i < n; i += BLOCK) okey[1u + r0 + i] = (uint32_t)(skeys[i] & km);
+            __syncthreads();
+        }
         // the keys are not needed any more: their LDS holds the text positions, indexed by row before the sort
         uint32_t *sx = reinterpret_cast<uint32_t *>(skeys);
 #pragma unroll
@@ -397,7 +402,7 @@ __global__ __launch_bounds__(BLOCK) void k_rs_big_rows(const uint32_t *bigc, con
     keys[q] = ((uint64_t)b << 32) | ikey[e];
     vals[q] = ipos[e] + rec.z;
 }
-template <bool RANK> __global__ __launch_bounds__(BLOCK) void k_rs_big_store(const uint64_t *keys, const uint32_t *vals, uint64_t nbr, const uint32_t *bigc, const uint32_t *bigoff, const uint32_t *crow, uint32_t *SA, uint32_t *rank)
+template <bool RANK, bool KEYOUT> __global__ __launch_bounds__(BLOCK) void k_rs_big_store(const uint64_t *keys, const uint32_t *vals, uint64_t nbr, const uint32_t *bigc, const uint32_t *bigoff, const uint32_t *crow, uint32_t *SA, uint32_t *rank, uint32_t *okey)
 {
     const uint64_t q = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (q >= nbr) return;
@@ -406,6 +411,7 @@ template <bool RANK> __global__ __launch_bounds__(BLOCK) void k_rs_big_store(con
     const uint32_t x = vals[q];
     SA[1u + row] = x;
     if (RANK) rank[x] = 1u + row;
+    if (KEYOUT) okey[1u + row] = (uint32_t)keys[q];
 }
 __global__ __launch_bounds__(BLOCK) void k_rs_first_row(uint32_t *SA, uint32_t *rank, uint64_t N)
 {
@@ -555,10 +561,10 @@ inline int suffix_sort_pfp(pfp_ctx *c, const uint32_t *dS, uint64_t N, uint64_t 
     uint32_t *bigc; PFP_ALLOC_HI(c, bigc, uint32_t, nc + 1);
     const unsigned ga = nblocks(N - 1, RS_TILE / 2);
     // algorithmic bytes per row: list entry 8 in, text position 4 out (+ 4 rank); per slot 16
-    if (rank) PFP_LAUNCH(c, K_REC_ASSEMBLE, (N - 1) * 16 + nv * 16, (k_rs_assemble<true>), ga, (const uint4 *)srec, (const uint32_t *)chead, (const uint32_t *)crow, (uint32_t)nc, (const uint32_t *)ikey, (const uint32_t *)ipos,
-                         keybits, tile_rows, SA, rank, bigc, d_cnt + 1);
-    else PFP_LAUNCH(c, K_REC_ASSEMBLE, (N - 1) * 12 + nv * 16, (k_rs_assemble<false>), ga, (const uint4 *)srec, (const uint32_t *)chead, (const uint32_t *)crow, (uint32_t)nc, (const uint32_t *)ikey, (const uint32_t *)ipos,
-                    keybits, tile_rows, SA, rank, bigc, d_cnt + 1);
+    if (rank) PFP_LAUNCH(c, K_REC_ASSEMBLE, (N - 1) * 16 + nv * 16, (k_rs_assemble<true, false>), ga, (const uint4 *)srec, (const uint32_t *)chead, (const uint32_t *)crow, (uint32_t)nc, (const uint32_t *)ikey, (const uint32_t *)ipos,
+                         keybits, tile_rows, SA, rank, bigc, d_cnt + 1, (uint32_t *)nullptr);
+    else PFP_LAUNCH(c, K_REC_ASSEMBLE, (N - 1) * 12 + nv * 16, (k_rs_assemble<false, false>), ga, (const uint4 *)srec, (const uint32_t *)chead, (const uint32_t *)crow, (uint32_t)nc, (const uint32_t *)ikey, (const uint32_t *)ipos,
+                    keybits, tile_rows, SA, rank, bigc, d_cnt + 1, (uint32_t *)nullptr);
     PFP_LAUNCH(c, K_MISC, 8, k_rs_first_row, 1, SA, rank, N);
     uint32_t nb32 = 0; PFP_TRY(d2h_u32(c, d_cnt + 1, &nb32));
     if (nb32) {      // classes with more rows than a tile
@@ -576,8 +582,8 @@ inline int suffix_sort_pfp(pfp_ctx *c, const uint32_t *dS, uint64_t N, uint64_t 
         BitRange br[2] = {{0, keybits}, {32, 32 + bits_for(nb - 1)}};
         uint64_t *sk; uint32_t *sv;
         PFP_TRY(radix_sort_pairs<uint64_t>(c, bk0, bv0, bk1, bv1, nbr, br, 2, &sk, &sv));
-        if (rank) PFP_LAUNCH(c, K_REC_PARSE, nbr * 24, (k_rs_big_store<true>), nblocks(nbr, BLOCK), (const uint64_t *)sk, (const uint32_t *)sv, nbr, (const uint32_t *)bigc, (const uint32_t *)bigoff, (const uint32_t *)crow, SA, rank);
-        else PFP_LAUNCH(c, K_REC_PARSE, nbr * 20, (k_rs_big_store<false>), nblocks(nbr, BLOCK), (const uint64_t *)sk, (const uint32_t *)sv, nbr, (const uint32_t *)bigc, (const uint32_t *)bigoff, (const uint32_t *)crow, SA, rank);
+        if (rank) PFP_LAUNCH(c, K_REC_PARSE, nbr * 24, (k_rs_big_store<true, false>), nblocks(nbr, BLOCK), (const uint64_t *)sk, (const uint32_t *)sv, nbr, (const uint32_t *)bigc, (const uint32_t *)bigoff, (const uint32_t *)crow, SA, rank, (uint32_t *)nullptr);
+        else PFP_LAUNCH(c, K_REC_PARSE, nbr * 20, (k_rs_big_store<false, false>), nblocks(nbr, BLOCK), (const uint64_t *)sk, (const uint32_t *)sv, nbr, (const uint32_t *)bigc, (const uint32_t *)bigoff, (const uint32_t *)crow, SA, rank, (uint32_t *)nullptr);
     }
     PFP_HIP(c, hipStreamSynchronize(c->stream));
     if (verbose) fprintf(stderr, "[pfbwt_hip]   assembled: %llu slots, %llu classes (%.1f ms)\n", (unsigned long long)nv, (unsigned long long)nc, tm.ms());
