@@ -80,6 +80,9 @@ ENVS = [
     {"PFP_EMIT_GROUP_ROWS": "40", "PFP_EMIT_CHUNK_ROWS": "20000", "PFP_FORCE_WIDE_ROWS": "1"},   # batches of at most 40 rows: most groups are left to the row-wise kernel, the rest goes through LDS
     {"PFP_PARSE_REC": "1"},                                                                      # suffix sort of the parse through its own level-2 prefix-free parse (recsort.h), the route S-32G takes by itself
     {"PFP_PARSE_REC": "1", "PFP_PARSE_REC_P2": "3", "PFP_PARSE_REC_TILE_ROWS": "40", "PFP_PARSE_REC_DEPTH": "2", "PFP_FORCE_WIDE_ROWS": "1"},   # two levels, assembly batches of 40 rows, larger classes through the global sort
+    {"PFP_DICT_REC": "1"},                                                                       # suffix sort of the dictionary through its own level-2 parse (dictrec.h), the route S-32G takes by itself
+    {"PFP_DICT_REC": "1", "PFP_DICT_REC_P2": "5", "PFP_PARSE_REC_TILE_ROWS": "40", "PFP_PARSE_REC": "1", "PFP_EMIT_CHUNK_ROWS": "50000"},      # short level-2 phrases, small assembly batches, both recursive sorts
+    {"PFP_DICT_REC": "0", "PFP_PARSE_REC": "0"},                                                 # the routes of rounds 1-3
 ]
 
 

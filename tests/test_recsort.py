@@ -88,6 +88,27 @@ print("pipeline ok")
 '''
 
 
+DICT_ENVS = [{"PFP_DICT_REC": "1"}, {"PFP_DICT_REC": "1", "PFP_DICT_REC_P2": "3", "PFP_PARSE_REC_TILE_ROWS": "30"}, {"PFP_DICT_REC": "1", "PFP_DICT_REC_P2": "64", "PFP_PARSE_REC": "1"},
+             {"PFP_DICT_REC": "1", "PFP_PARSE_REC_TABLE_LOG2": "4"}]      # (the last: the phrase table overflows -> the old dictionary sorter)
+
+
+@pytest.mark.parametrize("env", DICT_ENVS, ids=lambda e: ",".join("%s=%s" % (k.replace("PFP_", ""), v) for k, v in e.items()))
+def test_pipeline_with_recursive_dictionary_sort_emu(env):
+    """whole build with the dictionary suffix-sorted through its own level-2 parse (dictrec.h: D2 by the dictionary sorter, P2 by the integer sorter,
+    tie classes, assembly): every array == oracle == the reference's file digests; other moduli, small assembly batches, a table that overflows"""
+    e = dict(os.environ); e.update(env); e["PFP_TEST_HOOKS"] = "1"; e["PFP_EMU_POISON"] = "1"
+    pr = subprocess.run([sys.executable, "-c", PIPE_CODE, ROOT, "emu", "edge", "w4p7", "mult_chroms_fa"], env=e, capture_output=True, text=True, timeout=1500)
+    assert pr.returncode == 0 and "pipeline ok" in pr.stdout, pr.stdout[-1500:] + pr.stderr[-3000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", DICT_ENVS, ids=lambda e: ",".join("%s=%s" % (k.replace("PFP_", ""), v) for k, v in e.items()))
+def test_pipeline_with_recursive_dictionary_sort_gpu(env):
+    e = dict(os.environ); e.update(env); e["PFP_TEST_HOOKS"] = "1"
+    pr = subprocess.run([sys.executable, "-c", PIPE_CODE, ROOT, "gpu", "edge", "mult_chroms_fa", "w4p7", "single_chrom", "mult_chroms", "panel8"], env=e, capture_output=True, text=True, timeout=1500)
+    assert pr.returncode == 0 and "pipeline ok" in pr.stdout, pr.stdout[-1500:] + pr.stderr[-3000:]
+
+
 @pytest.mark.parametrize("env", ENVS[:1] + ENVS[3:4], ids=IDS)
 def test_pipeline_with_recursive_parse_sort_emu(env):
     """whole build (parse -> parse BWT through the recursive sort -> BWT + SA + samples) == oracle == the reference's file digests"""
