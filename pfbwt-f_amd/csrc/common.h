@@ -112,6 +112,10 @@ struct Tunables {
     uint32_t parse_rec_tile_rows = 0;  // rows per assembly batch (0: a full LDS tile; smaller: reaches the large-class route on small inputs)
     int dict_rec = -1;                 // suffix sort of the dictionary through a level-2 parse of the dictionary (dictrec.h): -1 = when the collection is repetitive, 0 never, 1 whenever the route can run
     int dict_rec_p2 = 16;              // its modulus (windows of four bytes)
+    int dedup_variant = 1;             // k_dedup_insert<COOP> (parse.h): 1 = the representatives read by the wave together, 0 = by every lane for itself (rounds 2-3)
+    int64_t dedup_period = 0;          // k_dedup_insert, order of the workgroups (parse.h, DedupOrder): workgroups per sequence; 0 = text workgroups / sequences fed, -1 = text order
+    int64_t dedup_chunk = 0;           // workgroups per column (0 = about 32)
+    int dedup_phases = 0;              // != 0: the stages of k_dedup_insert timed inside the kernel and printed (experiments)
     int parse_rec_table_log2 = 0;      // log2 of the level-2 phrase table (tests: a table that overflows -> doubling route)
 };
 
@@ -126,7 +130,7 @@ struct pfp_ctx {
     uint64_t err_pos = 0; int err_ch = 0;
     // --- text staging (device): tb = 16 guard bytes (tb[15] = Dollar) + X + w Dollars + slack
     pfp::VmRegion text;          // address range of tb; committed as the text grows (never re-allocated, never copied)
-    uint8_t *tb = nullptr; size_t tb_cap = 0; uint64_t n = 0; uint64_t text_hint = 0;
+    uint8_t *tb = nullptr; size_t tb_cap = 0; uint64_t n = 0; uint64_t text_hint = 0; uint64_t nseq = 0 /* sequences fed (a hint for the order in which the de-duplication visits the text) */;
     struct RowViewPending { const uint8_t *src = nullptr; uint64_t count = 0, len = 0, stride = 0; } view;      // pfp_parse_feed_device_view: the text is still the caller's rows (read in place by the trigger scan of pfp_parse_finalize)
     uint64_t left_ctx = 0;       // bytes of left context fed in front of this shard's text (pfp_parse_feed_left_context)
     uint64_t tb_n = 0;           // bytes of tb that hold the text of the current parse (0: none -- merged or loaded state)

@@ -460,103 +460,241 @@ struct LdsWords {
         return ((uint64_t)hi << 32) | lo;
     }
 };
-__global__ __launch_bounds__(BLOCK) void k_dedup_insert(const uint8_t *Y, Spans sp, uint64_t m, uint64_t seed, DedupTable t, uint32_t *longlist, uint32_t *nlong, uint8_t *last /*nullable: last[j] = Y[ye[j] - w], pfparser.hpp:599*/)
+// The order in which the workgroups visit the text (round 4).  A collection of similar sequences is a matrix: sequence h, locus c.  In text order the
+// workgroups that run at the same time cover ~27 MB of text, one whole sequence: the representative a phrase is compared with (the same locus of the FIRST
+// sequence, mostly) was last touched a sequence ago and comes from the MALL or HBM -- that read is 24 of the kernel's 42 ms on S-32G (stage by stage,
+// DESIGN.md section 4).  Hardware workgroup b runs on XCD b mod 8.  With `period` = workgroups per sequence (an estimate: text workgroups / sequences fed),
+// XCD x visits the loci c = x, x + 8, ... (columns of `chunk` workgroups) and, inside a column, sequence after sequence: the representatives of a column
+// (~1 MB) stay in that XCD's 4 MB L2 while all `rows` sequences pass.  Only the ORDER changes -- any estimate gives the same table; a bad one just does
+// not help.  period == 0: text order.  Grid = 8 * ceil(period / (8 * chunk)) * chunk * rows workgroups; those that fall outside the matrix return at once.
+struct DedupOrder { uint32_t period, chunk, rows; };
+// COOP (round 4): the representatives' bytes are read by the wave together (see below); false = every lane reads its own representative (rounds 2-3).
+// phase (nullable, experiments): wall-clock ticks (10 ns) that thread 0 of a workgroup saw between the kernel's stages, summed into 64 x 8 counters.
+template <bool COOP>
+__global__ __launch_bounds__(BLOCK) void k_dedup_insert(const uint8_t *Y, Spans sp, uint64_t m, uint64_t seed, DedupTable t, uint32_t *longlist, uint32_t *nlong, uint8_t *last /*nullable: last[j] = Y[ye[j] - w], pfparser.hpp:599*/,
+                                                        unsigned long long *phase, DedupOrder ord)
 {
-    __shared__ uint32_t tile[DD_TILE_BYTES / 4 + 20];
-    __shared__ unsigned long long wlo[BLOCK / WAVE], whi[BLOCK / WAVE];
-    __shared__ uint32_t abandoned;
-    // a table that is being abandoned (a non-repetitive text fills the first, small table after an eighth of its phrases): the workgroups
-    // that have not started yet return at once instead of hashing their phrases for nothing (S-3G: 19 of 38 ms)
-    if (threadIdx.x == 0) abandoned = *(volatile uint32_t *)t.abandon;
-    __syncthreads();
-    if (abandoned) return;
-    const uint64_t j = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    constexpr uint32_t TILE_BYTES = DD_TILE_BYTES, NT = BLOCK;
+    constexpr uint32_t CHUNK = 128u;       // bytes of the representative in flight per round trip (256: no gain, r04dv)
+    __shared__ uint32_t tile[TILE_BYTES / 4 + 20];
+    unsigned long long tk[6] = {0, 0, 0, 0, 0, 0};
+    if (phase) tk[0] = wall_clock64();
+    uint64_t B = blockIdx.x;
+    if (ord.period) {      // (see DedupOrder)
+        const uint32_t x = blockIdx.x & 7u, tt = blockIdx.x >> 3, cell = ord.chunk * ord.rows;
+        const uint32_t k = tt / cell, r = tt - k * cell, hrow = r / ord.chunk, i = r - hrow * ord.chunk;
+        const uint64_t col = (uint64_t)(k * 8u + x) * ord.chunk + i;
+        if (col >= ord.period) return;
+        B = (uint64_t)hrow * ord.period + col;
+        if (B * NT >= m) return;
+    }
+    const uint64_t j = B * NT + threadIdx.x;
     const bool live = j < m;
     tpos_t ys = 0; uint32_t len = 0;
-    if (live) phrase_span(sp, j, &ys, &len);
+    unsigned long long lo, hi;
+    bool tiled;
+    uint64_t base;
+    {
+        __shared__ unsigned long long wlo[BLOCK / WAVE], whi[BLOCK / WAVE];
+        __shared__ uint32_t abandoned;
+        // a table that is being abandoned (a non-repetitive text fills the first, small table after an eighth of its phrases): the workgroups
+        // that have not started yet return at once instead of hashing their phrases for nothing (S-3G: 19 of 38 ms)
+        if (threadIdx.x == 0) abandoned = *(volatile uint32_t *)t.abandon;
+        __syncthreads();
+        if (abandoned) return;
+        if (phase) tk[1] = wall_clock64();
+        if (live) phrase_span(sp, j, &ys, &len);
+        const bool lng0 = live && len > LONG_PHRASE;
+        if (lng0) longlist[atomicAdd(nlong, 1u)] = (uint32_t)j;
+        // window of the workgroup's (short) phrases
+        lo = (live && !lng0) ? (unsigned long long)ys : ~0ULL; hi = (live && !lng0) ? (unsigned long long)ys + len : 0ULL;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { const unsigned long long a = __shfl_xor(lo, d), b = __shfl_xor(hi, d); lo = a < lo ? a : lo; hi = b > hi ? b : hi; }
+        if ((threadIdx.x & 63) == 0) { wlo[threadIdx.x >> 6] = lo; whi[threadIdx.x >> 6] = hi; }
+        __syncthreads();
+        lo = wlo[0]; hi = whi[0];
+#pragma unroll
+        for (int v = 1; v < BLOCK / WAVE; ++v) { lo = wlo[v] < lo ? wlo[v] : lo; hi = whi[v] > hi ? whi[v] : hi; }
+        if (hi == 0) return;                                     // nothing but long phrases (or nothing at all)
+    }
     const bool lng = live && len > LONG_PHRASE;
-    if (lng) longlist[atomicAdd(nlong, 1u)] = (uint32_t)j;
-    // window of the workgroup's (short) phrases
-    unsigned long long lo = (live && !lng) ? (unsigned long long)ys : ~0ULL, hi = (live && !lng) ? (unsigned long long)ys + len : 0ULL;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { const unsigned long long a = __shfl_xor(lo, d), b = __shfl_xor(hi, d); lo = a < lo ? a : lo; hi = b > hi ? b : hi; }
-    if ((threadIdx.x & 63) == 0) { wlo[threadIdx.x >> 6] = lo; whi[threadIdx.x >> 6] = hi; }
-    __syncthreads();
-    lo = wlo[0]; hi = whi[0];
-#pragma unroll
-    for (int v = 1; v < BLOCK / WAVE; ++v) { lo = wlo[v] < lo ? wlo[v] : lo; hi = whi[v] > hi ? whi[v] : hi; }
-    if (hi == 0) return;                                     // nothing but long phrases (or nothing at all)
-    const uint64_t base = lo & ~15ULL;                       // Y + base is 16-byte aligned when Y is: not assumed -- the loads below are byte-exact
-    const bool tiled = hi - base <= DD_TILE_BYTES;
+    if (phase) tk[2] = wall_clock64();
+    base = lo & ~15ULL;                                       // Y + base is 16-byte aligned when Y is: not assumed -- the loads below are byte-exact
+    tiled = hi - base <= TILE_BYTES;
     if (tiled) {
         const uint32_t nb = (uint32_t)(hi - base);
         // the text buffer is padded in front of Y[0] and behind its end, so whole 16-byte pieces may be read
-        for (uint32_t o = threadIdx.x * 16u; o < nb + 8u; o += BLOCK * 16u) {
+        for (uint32_t o = threadIdx.x * 16u; o < nb + 8u; o += NT * 16u) {
             uint4 v; __builtin_memcpy(&v, Y + base + o, 16);
             tile[o / 4] = v.x; tile[o / 4 + 1] = v.y; tile[o / 4 + 2] = v.z; tile[o / 4 + 3] = v.w;
         }
     }
     __syncthreads();
-    if (!live) return;
+    if (phase) tk[3] = wall_clock64();
+    const bool act = live && !lng;
     // the character in front of the phrase's closing window, while the phrase is at hand (in LDS, normally): a kernel of its own
     // read one sector per phrase for this byte
-    if (last && (lng || !tiled)) last[j] = Y[ys + len - 1u - (uint32_t)sp.w];
-    if (lng) return;
-    if (!tiled) { dedup_find_or_insert(Y, sp, t, (uint32_t)j, ys, len, str_hash(Y + ys, len, seed)); return; }
-    const uint32_t off = (uint32_t)(ys - base);
-    if (last) { const uint32_t o = off + len - 1u - (uint32_t)sp.w; last[j] = (uint8_t)(tile[o >> 2] >> (8u * (o & 3u))); }
-    LdsWords hw(tile, off);
-    const uint64_t h = hash_words(len, seed, [&hw]() { return hw.next(); });
-    const uint64_t filt = h >> 32;
-    uint64_t slot = h & t.mask;
-    for (uint32_t probe = 0; probe < HT_MAX_PROBES; ++probe, slot = (slot + 1) & t.mask) {
-        unsigned long long cur = t.ent[slot].tab;
-        unsigned long long ri = t.ent[slot].rinfo;                    // requested together with the entry: the representative's bytes are one dependent load away, not three
-        if ((probe & 7u) == 7u && *t.overflow) return;          // the table is being abandoned (it may be full: no EMPTY entry would end the walk)
-        if (cur == HT_EMPTY) {
-            if (*t.overflow) return;
-            cur = atomicCAS(&t.ent[slot].tab, (unsigned long long)HT_EMPTY, (unsigned long long)((filt << 32) | (uint32_t)j));
+    if (live && last && (lng || !tiled)) last[j] = Y[ys + len - 1u - (uint32_t)sp.w];
+    if (!tiled) { if (act) dedup_find_or_insert(Y, sp, t, (uint32_t)j, ys, len, str_hash(Y + ys, len, seed)); return; }
+    const bool actm = act;
+    const uint32_t off = actm ? (uint32_t)(ys - base) : 0u;
+    if (actm && last) { const uint32_t o = off + len - 1u - (uint32_t)sp.w; last[j] = (uint8_t)(tile[o >> 2] >> (8u * (o & 3u))); }
+    uint64_t h = 0;
+    if (actm) { LdsWords hw(tile, off); h = hash_words(len, seed, [&hw]() { return hw.next(); }); }
+    if (phase) tk[4] = wall_clock64();
+    // the table: my phrase finds its entry or becomes one
+    auto lookup = [&]() __attribute__((always_inline)) -> void {
+        const uint64_t filt = h >> 32;
+        uint64_t slot = h & t.mask;
+        for (uint32_t probe = 0; probe < HT_MAX_PROBES; ++probe, slot = (slot + 1) & t.mask) {
+            unsigned long long cur = t.ent[slot].tab;
+            unsigned long long ri = t.ent[slot].rinfo;                    // requested together with the entry: the representative's bytes are one dependent load away, not three
+            if ((probe & 7u) == 7u && *t.overflow) return;          // the table is being abandoned (it may be full: no EMPTY entry would end the walk)
             if (cur == HT_EMPTY) {
-                const uint32_t k = atomicAdd(t.nd, 1u);
-                if (k >= t.limit) { ht_give_up(t, 1u); return; }
-                t.ent[slot].rinfo = ((unsigned long long)ys << 16) | len;
-                t.dslot[k] = (uint32_t)slot; t.dhash[k] = h; t.ent[slot].kidx = k;
-                t.slotof[j] = k; atomicAdd(&t.ent[slot].cnt, 1u);
-                return;
+                if (*t.overflow) return;
+                cur = atomicCAS(&t.ent[slot].tab, (unsigned long long)HT_EMPTY, (unsigned long long)((filt << 32) | (uint32_t)j));
+                if (cur == HT_EMPTY) {
+                    const uint32_t k = atomicAdd(t.nd, 1u);
+                    if (k >= t.limit) { ht_give_up(t, 1u); return; }
+                    t.ent[slot].rinfo = ((unsigned long long)ys << 16) | len;
+                    t.dslot[k] = (uint32_t)slot; t.dhash[k] = h; t.ent[slot].kidx = k;
+                    t.slotof[j] = k; atomicAdd(&t.ent[slot].cnt, 1u);
+                    return;
+                }
+                ri = HT_NOINFO;
             }
-            ri = HT_NOINFO;
-        }
-        if ((cur >> 32) == filt) {
-            tpos_t rs; uint32_t rlen;
-            if (ri != HT_NOINFO) { rs = (tpos_t)(ri >> 16); rlen = (uint32_t)(ri & 0xFFFFu); }
-            else phrase_span(sp, (uint32_t)cur, &rs, &rlen);
-            if (rlen == len) {
-                // no early exit (an entry whose filter bits agree is the same phrase all but never), and the representative's
-                // bytes are requested 128 at a time: a wave is as slow as the longest of its 64 phrases (~470 bytes at
-                // p = 100), which was 15 dependent round trips when 32 bytes were in flight
-                const uint8_t *r = Y + rs;
-                uint64_t diff = 0;
-                LdsWords cw(tile, off);
-                for (uint32_t c0 = 0; c0 < len; c0 += 128u) {
-                    uint64_t a[16];
+            if ((cur >> 32) == filt) {
+                tpos_t rs; uint32_t rlen;
+                if (ri != HT_NOINFO) { rs = (tpos_t)(ri >> 16); rlen = (uint32_t)(ri & 0xFFFFu); }
+                else phrase_span(sp, (uint32_t)cur, &rs, &rlen);
+                if (rlen == len) {
+                    // no early exit (an entry whose filter bits agree is the same phrase all but never), and the representative's
+                    // bytes are requested CHUNK at a time: a wave is as slow as the longest of its 64 phrases (~470 bytes at
+                    // p = 100), which was 15 dependent round trips when 32 bytes were in flight
+                    const uint8_t *r = Y + rs;
+                    uint64_t diff = 0;
+                    LdsWords cw(tile, off);
+                    for (uint32_t c0 = 0; c0 < len; c0 += CHUNK) {
+                        uint64_t a[CHUNK / 8];
 #pragma unroll
-                    for (int q = 0; q < 16; q += 2) {      // 16 bytes per request: every lane reads another line, and the requests, not the bytes, are what the memory pipeline counts (callers keep 15 readable bytes behind every string)
-                        const uint32_t i = c0 + 8u * (uint32_t)q;
-                        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                        if (i < len) __builtin_memcpy(&v, r + i, 16);
-                        a[q] = ((uint64_t)v.y << 32) | v.x; a[q + 1] = ((uint64_t)v.w << 32) | v.z;
+                        for (int q = 0; q < (int)(CHUNK / 8); q += 2) {      // 16 bytes per request: every lane reads another line, and the requests, not the bytes, are what the memory pipeline counts (callers keep 15 readable bytes behind every string)
+                            const uint32_t i = c0 + 8u * (uint32_t)q;
+                            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                            if (i < len) __builtin_memcpy(&v, r + i, 16);
+                            a[q] = ((uint64_t)v.y << 32) | v.x; a[q + 1] = ((uint64_t)v.w << 32) | v.z;
+                        }
+#pragma unroll
+                        for (int q = 0; q < (int)(CHUNK / 8); ++q) {
+                            const uint32_t i = c0 + 8u * (uint32_t)q;
+                            if (i < len) { uint64_t x = a[q] ^ cw.next(); if (len - i < 8) x &= (1ULL << (8 * (len - i))) - 1ULL; diff |= x; }
+                        }
                     }
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        const uint32_t i = c0 + 8u * (uint32_t)q;
-                        if (i < len) { uint64_t x = a[q] ^ cw.next(); if (len - i < 8) x &= (1ULL << (8 * (len - i))) - 1ULL; diff |= x; }
+                    if (!diff) { t.slotof[j] = entry_ref(t.ent, slot); atomicAdd(&t.ent[slot].cnt, 1u); return; }
+                }
+            }
+        }
+        ht_give_up(t, 2u);
+    };
+    if constexpr (!COOP) { if (actm) lookup(); }
+    else {
+        // the representatives' bytes are read by the wave TOGETHER.  A lane that reads the 7 x 16 bytes of its own representative touches a cache
+        // line of its own with every request (64 lines per load instruction); here the 8 lanes of a group read 128 contiguous bytes of ONE representative
+        // (1-2 lines), eight representatives per instruction, and compare them with the phrase's bytes in LDS; a ballot brings the verdict back to the
+        // phrase's own lane.  Every lane walks its probe sequence as before; the wave meets for the comparison whenever some lane has a candidate.
+        const uint32_t lane = threadIdx.x & 63u, grp = lane >> 3, sub = lane & 7u;
+        const uint64_t filt = h >> 32;
+        uint64_t slot = h & t.mask;
+        uint32_t probe = 0;
+        bool active = actm;
+        while (__any(active ? 1 : 0)) {
+            bool cand = false; tpos_t rs = 0; uint32_t kx = HT_NOIDX;
+            if (active) {
+                unsigned long long cur = t.ent[slot].tab;
+                unsigned long long ri = t.ent[slot].rinfo;
+                kx = t.ent[slot].kidx;                                   // (the same 32-byte sector: no further round trip when the phrase turns out to be this entry's)
+                bool fin = false;
+                if ((probe & 7u) == 7u && *t.overflow) fin = true;       // the table is being abandoned (it may be full: no EMPTY entry would end the walk)
+                else if (cur == HT_EMPTY) {
+                    if (*t.overflow) fin = true;
+                    else {
+                        cur = atomicCAS(&t.ent[slot].tab, (unsigned long long)HT_EMPTY, (unsigned long long)((filt << 32) | (uint32_t)j));
+                        if (cur == HT_EMPTY) {
+                            const uint32_t k = atomicAdd(t.nd, 1u);
+                            if (k >= t.limit) ht_give_up(t, 1u);
+                            else {
+                                t.ent[slot].rinfo = ((unsigned long long)ys << 16) | len;
+                                t.dslot[k] = (uint32_t)slot; t.dhash[k] = h; t.ent[slot].kidx = k;
+                                t.slotof[j] = k; atomicAdd(&t.ent[slot].cnt, 1u);
+                            }
+                            fin = true;
+                        }
+                        ri = HT_NOINFO; kx = HT_NOIDX;
                     }
                 }
-                if (!diff) { t.slotof[j] = entry_ref(t.ent, slot); atomicAdd(&t.ent[slot].cnt, 1u); return; }
+                if (fin) active = false;
+                else if ((cur >> 32) == filt) {
+                    uint32_t rlen;
+                    if (ri != HT_NOINFO) { rs = (tpos_t)(ri >> 16); rlen = (uint32_t)(ri & 0xFFFFu); }
+                    else phrase_span(sp, (uint32_t)cur, &rs, &rlen);
+                    cand = rlen == len;
+                }
+            }
+            uint32_t bad = 0;
+            const uint32_t clen = cand ? len : 0u;
+            uint32_t maxlen = clen;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(maxlen, d); maxlen = o > maxlen ? o : maxlen; }
+            for (uint32_t c0 = 0; c0 < maxlen; c0 += 128u) {
+                const uint32_t o = c0 + sub * 16u;
+                uint4 a[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const int p = r * 8 + (int)grp;
+                    const uint32_t plen = __shfl(clen, p);
+                    const unsigned long long prs = __shfl((unsigned long long)rs, p);
+                    a[r] = make_uint4(0u, 0u, 0u, 0u);
+                    if (o < plen) __builtin_memcpy(&a[r], Y + prs + o, 16);      // (callers keep 15 readable bytes behind every string)
+                }
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const int p = r * 8 + (int)grp;
+                    const uint32_t plen = __shfl(clen, p), poff = __shfl(off, p);
+                    bool d = false;
+                    if (o < plen) {
+                        const uint32_t bo = poff + o, wi = bo >> 2, sh = (bo & 3u) * 8u;
+                        const uint32_t w0 = tile[wi], w1 = tile[wi + 1], w2 = tile[wi + 2], w3 = tile[wi + 3], w4 = tile[wi + 4];
+                        uint32_t d0 = (uint32_t)((((uint64_t)w1 << 32) | w0) >> sh) ^ a[r].x, d1 = (uint32_t)((((uint64_t)w2 << 32) | w1) >> sh) ^ a[r].y;
+                        uint32_t d2 = (uint32_t)((((uint64_t)w3 << 32) | w2) >> sh) ^ a[r].z, d3 = (uint32_t)((((uint64_t)w4 << 32) | w3) >> sh) ^ a[r].w;
+                        const uint32_t nv = plen - o;                              // bytes of this piece that belong to the phrase (>= 1)
+                        if (nv < 16u) {
+                            if (nv <= 12u) d3 = 0; else d3 &= (1u << (8u * (nv - 12u))) - 1u;
+                            if (nv <= 8u) d2 = 0; else if (nv < 12u) d2 &= (1u << (8u * (nv - 8u))) - 1u;
+                            if (nv <= 4u) d1 = 0; else if (nv < 8u) d1 &= (1u << (8u * (nv - 4u))) - 1u;
+                            if (nv < 4u) d0 &= (1u << (8u * nv)) - 1u;
+                        }
+                        d = (d0 | d1 | d2 | d3) != 0u;
+                    }
+                    const unsigned long long bm = __ballot(d ? 1 : 0);
+                    if ((int)grp == r) bad |= (uint32_t)((bm >> (8u * sub)) & 0xFFull);
+                }
+            }
+            if (cand && !bad) {
+                t.slotof[j] = kx != HT_NOIDX ? kx : (HT_BYSLOT | (uint32_t)slot);
+                atomicAdd(&t.ent[slot].cnt, 1u);
+                active = false;
+            }
+            if (active) {
+                ++probe; slot = (slot + 1) & t.mask;
+                if (probe >= HT_MAX_PROBES) { ht_give_up(t, 2u); active = false; }
             }
         }
     }
-    ht_give_up(t, 2u);
+    if (phase && threadIdx.x == 0) {
+        tk[5] = wall_clock64();
+        unsigned long long *ph = phase + (blockIdx.x & 63u) * 8u;
+        for (int k = 0; k < 5; ++k) atomicAdd(&ph[k], tk[k + 1] - tk[k]);
+        atomicAdd(&ph[5], 1ULL);
+    }
 }
 // ---- long phrases (e.g. a 10 Mbp run of N is ONE phrase: wang_hash(0) % 100 != 0): one workgroup
 // per phrase hashes and compares it cooperatively; thread 0 walks the probe sequence

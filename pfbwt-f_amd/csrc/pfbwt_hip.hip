@@ -88,7 +88,7 @@ static int ensure_text(pfp_ctx *c, uint64_t need_n)
 
 static void reset_results(pfp_ctx *c)
 {
-    c->stage = 0; c->n = 0; c->tb_n = 0; c->left_ctx = 0; c->view.src = nullptr; c->m = c->dwords = c->dsize = 0; c->nrows = 0; c->nout = c->runs = c->esa_pairs = 0;
+    c->stage = 0; c->n = 0; c->nseq = 0; c->tb_n = 0; c->left_ctx = 0; c->view.src = nullptr; c->m = c->dwords = c->dsize = 0; c->nrows = 0; c->nout = c->runs = c->esa_pairs = 0;
     c->gsa_valid = false; c->d_wrank = nullptr; c->d_bwt = nullptr; c->d_sa = c->d_ssa = c->d_esa = nullptr;
     c->d_bwlast = nullptr; c->d_ilist = nullptr; c->d_bwsai = nullptr; c->d_bwl_il = nullptr;
     c->d_ma = nullptr; c->ma_words = 0; c->ma_lo_mark = (size_t)-1;
@@ -101,7 +101,7 @@ static void reset_results(pfp_ctx *c)
 // ---- route / tuning switches (pfbwt_hip_dev.h) -----------------------------------------------------
 static const char *const tunable_names[] = {"verbose", "seg_grid", "seg_stage", "sort_k", "sort_no_table", "class_sort_maxrange", "dedup_table_log2", "no_trigger_table",
                                             "emit_chunk_rows", "fill_subs", "sample_cap", "no_runaware", "big_group_members", "force_wide_rows", "fasta_chunk_bytes", "ingest_block_bytes", "emit_group_rows", "no_slot_records", "dict_text_rounds", "int_key_symbols", "force_run_round",
-                                            "ingest_readers", "expand_dma", "parse_rec", "parse_rec_p2", "parse_rec_min", "parse_rec_depth", "parse_rec_tile_rows", "parse_rec_table_log2", "dict_rec", "dict_rec_p2"};
+                                            "ingest_readers", "expand_dma", "parse_rec", "parse_rec_p2", "parse_rec_min", "parse_rec_depth", "parse_rec_tile_rows", "parse_rec_table_log2", "dict_rec", "dict_rec_p2", "dedup_variant", "dedup_phases", "dedup_period", "dedup_chunk"};
 static int set_tunable(pfp_ctx *c, const char *key, long long v)
 {
     Tunables &t = c->tun;
@@ -136,6 +136,10 @@ static int set_tunable(pfp_ctx *c, const char *key, long long v)
     else if (!strcmp(key, "parse_rec_table_log2")) t.parse_rec_table_log2 = (int)v;
     else if (!strcmp(key, "dict_rec")) t.dict_rec = (int)v;
     else if (!strcmp(key, "dict_rec_p2")) t.dict_rec_p2 = (int)v;
+    else if (!strcmp(key, "dedup_variant")) t.dedup_variant = (int)v;
+    else if (!strcmp(key, "dedup_phases")) t.dedup_phases = (int)v;
+    else if (!strcmp(key, "dedup_period")) t.dedup_period = (int64_t)v;
+    else if (!strcmp(key, "dedup_chunk")) t.dedup_chunk = (int64_t)v;
     else return PFP_E_ARG;
     return PFP_OK;
 }
@@ -305,6 +309,7 @@ static int feed_common(pfp_ctx *c, const void *src, uint64_t len, int end_of_seq
     else if (len) PFP_HIP(c, hipMemcpyAsync(c->tb + 16 + c->n, src, (size_t)len, kind, c->stream));
     c->n += len;
     if (end_of_seq) {   // the w 'A's of pfparser.hpp:335-337
+        ++c->nseq;
         PFP_HIP(c, hipMemsetAsync(c->tb + 16 + c->n, 'A', (size_t)c->w, c->stream));
         c->n += (uint64_t)c->w;
     }
@@ -323,8 +328,9 @@ int pfp_parse_reopen(pfp_ctx *c)
     if (c->stage == 0) return PFP_OK;
     if (!c->tb || !c->tb_n || c->tb_n != c->n) return PFP_E_STATE;   // a context filled by pfp_merge_shards / pfp_bwt_load holds no text
     PFP_HIP(c, hipStreamSynchronize(c->stream));
-    const uint64_t n = c->n;
+    const uint64_t n = c->n, nseq = c->nseq;
     reset_results(c);
+    c->nseq = nseq;
     c->n = c->tb_n = n;                                         // the (normalised) text is still in place; more can be appended
     return PFP_OK;
 }
@@ -372,7 +378,7 @@ int pfp_parse_feed_device_view(pfp_ctx *c, const void *d_bases, uint64_t count, 
     if (count * blocks_per_row >= 0x7FFFFFFFULL) return PFP_E_TOO_LARGE;
     PFP_TRY(ensure_text(c, add + (uint64_t)c->w));
     c->view.src = (const uint8_t *)d_bases; c->view.count = count; c->view.len = len; c->view.stride = stride;
-    c->n = add; c->tb_n = c->n;
+    c->n = add; c->tb_n = c->n; c->nseq = count;
     return PFP_OK;
 }
 int pfp_parse_feed(pfp_ctx *c, const uint8_t *bases, uint64_t len, int end_of_seq) { if (c) PFP_TRY(flush_view(c)); return feed_common(c, bases, len, end_of_seq, hipMemcpyHostToDevice); }
@@ -392,7 +398,7 @@ int pfp_parse_feed_device_batch(pfp_ctx *c, const void *d_bases, uint64_t count,
     const uint64_t blocks_per_row = ((len + 15) / 16 + BLOCK - 1) / BLOCK;
     if (count * blocks_per_row >= 0x7FFFFFFFULL) return PFP_E_TOO_LARGE;      // grid limit (2^31 workgroups = 8 Tbase)
     PFP_LAUNCH(c, K_MISC, 2 * count * len, k_feed_batch, count * blocks_per_row, (const uint8_t *)d_bases, count, len, stride, c->w, dst);
-    c->n += add; c->tb_n = c->n;
+    c->n += add; c->tb_n = c->n; c->nseq += count;
     return PFP_OK;
 }
 
@@ -416,7 +422,7 @@ int pfp_parse_feed_batch(pfp_ctx *c, const uint8_t *bases, uint64_t count, uint6
     for (uint64_t k = 0; k < count; ++k) PFP_HIP(c, hipMemcpyAsync(dst + k * pitch, bases + k * stride, (size_t)len, hipMemcpyHostToDevice, c->stream));
     PFP_LAUNCH(c, K_MISC, count * (uint64_t)c->w, k_pad_rows, nblocks(count * (uint64_t)c->w, BLOCK), dst, count, len, pitch, c->w);
     PFP_HIP(c, hipStreamSynchronize(c->stream));      // the caller may reuse its buffer
-    c->n += add; c->tb_n = c->n;
+    c->n += add; c->tb_n = c->n; c->nseq += count;
     return PFP_OK;
 }
 
@@ -812,7 +818,37 @@ static int dedup_strings(pfp_ctx *c, const uint8_t *Y, Spans sp, uint64_t m, uin
         PFP_HIP(c, hipMemsetAsync(d_abandon, 0, 4, c->stream));
         PFP_HIP(c, hipMemsetAsync(t.ent, 0xFF, T * sizeof(DedupEntry), c->stream));
         PFP_HIP(c, hipMemsetAsync(d_u32, 0, 32, c->stream));
-        PFP_LAUNCH(c, K_PHRASE_HASH, 2 * total_bytes + m * 24, k_dedup_insert, gm, Y, sp, m, c->hash_seed, t, longlist, d_u32 + 2, last_out);
+        unsigned long long *d_phase = nullptr;
+        if (c->tun.dedup_phases) { PFP_ALLOC_HI(c, d_phase, unsigned long long, 512); PFP_HIP(c, hipMemsetAsync(d_phase, 0, 4096, c->stream)); }
+        // the order of the workgroups (parse.h, DedupOrder): columns of loci per XCD when the text is a collection of similar sequences
+        const uint64_t nb = gm;
+        DedupOrder ord = {0u, 0u, 0u};
+        uint64_t grid = nb;
+        {
+            const uint64_t nseq = c->nseq + c->fa.records;
+            uint64_t period = c->tun.dedup_period > 0 ? (uint64_t)c->tun.dedup_period : (c->tun.dedup_period == 0 && !sp.ys32 && nseq >= 8 ? (nb + nseq / 2) / nseq : 0);
+            if (c->tun.dedup_period == 0 && period < 64) period = 0;      // sequences of less than ~1.6 Mbase: nothing to gain
+            if (period && period < nb) {
+                uint64_t chunk = c->tun.dedup_chunk > 0 ? (uint64_t)c->tun.dedup_chunk : 0;
+                if (!chunk) { const uint64_t q0 = (period + 128) / 256 ? (period + 128) / 256 : 1; chunk = (period + 8 * q0 - 1) / (8 * q0); }
+                if (chunk > period) chunk = period;
+                const uint64_t q = (period + 8 * chunk - 1) / (8 * chunk), rows = (nb + period - 1) / period;
+                const uint64_t g = 8 * q * chunk * rows;
+                if (g < 0x7FFFFFFFULL && chunk * rows < 0xFFFFFFFFULL) { ord.period = (uint32_t)period; ord.chunk = (uint32_t)chunk; ord.rows = (uint32_t)rows; grid = g; }
+            }
+            if (c->tun.verbose && ord.period) fprintf(stderr, "[pfbwt_hip] text de-duplication: %llu workgroups visited as %u sequences x %u loci, columns of %u per XCD (grid %llu)\n", (unsigned long long)nb, ord.rows, ord.period, ord.chunk, (unsigned long long)grid);
+        }
+        if (c->tun.dedup_variant == 0) PFP_LAUNCH(c, K_PHRASE_HASH, 2 * total_bytes + m * 24, k_dedup_insert<false>, grid, Y, sp, m, c->hash_seed, t, longlist, d_u32 + 2, last_out, d_phase, ord);
+        else PFP_LAUNCH(c, K_PHRASE_HASH, 2 * total_bytes + m * 24, k_dedup_insert<true>, grid, Y, sp, m, c->hash_seed, t, longlist, d_u32 + 2, last_out, d_phase, ord);
+        if (d_phase) {
+            unsigned long long hp[512], tot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            PFP_HIP(c, hipMemcpyAsync(hp, d_phase, 4096, hipMemcpyDeviceToHost, c->stream));
+            PFP_HIP(c, hipStreamSynchronize(c->stream));
+            for (int q = 0; q < 64; ++q) for (int k = 0; k < 8; ++k) tot[k] += hp[q * 8 + k];
+            const double nwg = tot[5] ? (double)tot[5] : 1.0;
+            fprintf(stderr, "[pfbwt_hip] k_dedup_insert (variant %d), thread 0 of %llu workgroups, mean us per stage: abandon flag %.2f, spans + window bounds %.2f, window into LDS %.2f, hash %.2f, table + compare %.2f\n",
+                    c->tun.dedup_variant, tot[5], tot[0] / nwg / 100.0, tot[1] / nwg / 100.0, tot[2] / nwg / 100.0, tot[3] / nwg / 100.0, tot[4] / nwg / 100.0);
+        }
         uint32_t h3[3];
         PFP_HIP(c, hipMemcpyAsync(h3, d_u32, 12, hipMemcpyDeviceToHost, c->stream));
         PFP_HIP(c, hipStreamSynchronize(c->stream));

@@ -202,6 +202,7 @@ static inline int __clz(int x) { return x ? __builtin_clz((unsigned)x) : 32; }
 static inline int __clzll(long long x) { return x ? __builtin_clzll((unsigned long long)x) : 64; }
 static inline int __ffs(int x) { return __builtin_ffs(x); }
 static inline int __ffsll(long long x) { return __builtin_ffsll(x); }
+static inline unsigned long long wall_clock64() { return 0ULL; }
 static inline unsigned long long __umul64hi(unsigned long long a, unsigned long long b) { return (unsigned long long)(((unsigned __int128)a * b) >> 64); }
 static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((uint64_t)a * b) >> 32); }
 

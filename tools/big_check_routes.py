@@ -21,7 +21,7 @@ U = 8 if u64 else 4
 h_all = torch.empty((H, Lb), dtype=torch.uint8, pin_memory=True)
 bench.synth_seqs(Lb, H, seed, nruns, out=h_all.numpy())
 d_all = h_all.to("cuda"); del h_all
-OLD = dict(emit_group_rows=0, no_slot_records=1, dict_text_rounds=0, int_key_symbols=2, force_run_round=1, emit_chunk_rows=1 << 30, parse_rec=0, dict_rec=0)      # parse_rec=0, dict_rec=0 (round 4): parse and dictionary suffix-sorted by prefix doubling, as in rounds 1-3
+OLD = dict(emit_group_rows=0, no_slot_records=1, dict_text_rounds=0, int_key_symbols=2, force_run_round=1, emit_chunk_rows=1 << 30, parse_rec=0, dict_rec=0, dedup_variant=0, dedup_period=-1)      # parse_rec=0, dict_rec=0 (round 4): parse and dictionary suffix-sorted by prefix doubling, as in rounds 1-3
 
 
 def build(switches):
