@@ -29,6 +29,11 @@ int pfp_stage_ms(pfp_ctx *ctx, double out[3]);
  *   no_slot_records (per-slot fields by two gathers: the route of dictionaries with words of 64 Mbase and more),
  *   dict_text_rounds (-1 auto | 0 rank-based dictionary sort only | 1 text rounds forced), int_key_symbols (2 | 3: parse symbols in the initial sort key),
  *   force_run_round (the run round of the dictionary sort even without a long run).
+ *   round 4: parse_rec (-1 auto | 0 never | 1 always: suffix sort of the parse through its level-2 prefix-free parse, csrc/recsort.h), parse_rec_p2, parse_rec_min,
+ *   parse_rec_depth, parse_rec_tile_rows, parse_rec_table_log2; dict_rec (-1 | 0 | 1: the same for the dictionary, csrc/dictrec.h), dict_rec_p2;
+ *   dedup_variant (1: representatives read by the wave together | 0: by every lane), dedup_period (workgroups per sequence for the per-XCD column order of
+ *   k_dedup_insert: 0 = estimated from the sequences fed, -1 = text order), dedup_chunk (workgroups per column), dedup_phases (!= 0: stage times from inside the kernel on stderr);
+ *   ingest_readers, expand_dma.
  * Returns PFP_E_ARG for an unknown key.  In a process started with PFP_TEST_HOOKS=1 pfp_create presets a new context from the
  * environment variables PFP_<KEY IN UPPER CASE>; without PFP_TEST_HOOKS=1 the environment is ignored (PFP_VERBOSE excepted,
  * which only prints). */
