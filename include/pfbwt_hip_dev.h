@@ -31,7 +31,7 @@ int pfp_stage_ms(pfp_ctx *ctx, double out[3]);
  *   force_run_round (the run round of the dictionary sort even without a long run).
  *   round 4: parse_rec (-1 auto | 0 never | 1 always: suffix sort of the parse through its level-2 prefix-free parse, csrc/recsort.h), parse_rec_p2, parse_rec_min,
  *   parse_rec_depth, parse_rec_tile_rows, parse_rec_table_log2; dict_rec (-1 | 0 | 1: the same for the dictionary, csrc/dictrec.h), dict_rec_p2;
- *   dedup_variant (1: representatives read by the wave together | 0: by every lane), dedup_period (workgroups per sequence for the per-XCD column order of
+ *   dedup_variant (1: representatives read by the wave together | 0: by every lane | -1 default: 1 for a collection of >= 8 sequences while its first table lasts), dedup_period (workgroups per sequence for the per-XCD column order of
  *   k_dedup_insert: 0 = estimated from the sequences fed, -1 = text order), dedup_chunk (workgroups per column), dedup_phases (!= 0: stage times from inside the kernel on stderr);
  *   ingest_readers, expand_dma.
  * Returns PFP_E_ARG for an unknown key.  In a process started with PFP_TEST_HOOKS=1 pfp_create presets a new context from the

@@ -112,7 +112,7 @@ struct Tunables {
     uint32_t parse_rec_tile_rows = 0;  // rows per assembly batch (0: a full LDS tile; smaller: reaches the large-class route on small inputs)
     int dict_rec = -1;                 // suffix sort of the dictionary through a level-2 parse of the dictionary (dictrec.h): -1 = when the collection is repetitive, 0 never, 1 whenever the route can run
     int dict_rec_p2 = 16;              // its modulus (windows of four bytes)
-    int dedup_variant = 1;             // k_dedup_insert<COOP> (parse.h): 1 = the representatives read by the wave together, 0 = by every lane for itself (rounds 2-3)
+    int dedup_variant = -1;            // k_dedup_insert<COOP> (parse.h): 1 = the representatives read by the wave together, 0 = by every lane for itself (rounds 2-3), -1 = 1 for a collection while its first table lasts
     int64_t dedup_period = 0;          // k_dedup_insert, order of the workgroups (parse.h, DedupOrder): workgroups per sequence; 0 = text workgroups / sequences fed, -1 = text order
     int64_t dedup_chunk = 0;           // workgroups per column (0 = about 32)
     int dedup_phases = 0;              // != 0: the stages of k_dedup_insert timed inside the kernel and printed (experiments)

@@ -469,6 +469,8 @@ struct LdsWords {
 // not help.  period == 0: text order.  Grid = 8 * ceil(period / (8 * chunk)) * chunk * rows workgroups; those that fall outside the matrix return at once.
 struct DedupOrder { uint32_t period, chunk, rows; };
 // COOP (round 4): the representatives' bytes are read by the wave together (see below); false = every lane reads its own representative (rounds 2-3).
+// The host takes COOP for a collection (>= 8 sequences fed) while its first, small table lasts: on a text of DISTINCT phrases the cooperative kernel is 2.4 x slower
+// (S-3G: 80 against 34 ms; none of its parts explains it when switched off one by one -- r04ag_s3g_exp.log -- so the cause is open).
 // phase (nullable, experiments): wall-clock ticks (10 ns) that thread 0 of a workgroup saw between the kernel's stages, summed into 64 x 8 counters.
 template <bool COOP>
 __global__ __launch_bounds__(BLOCK) void k_dedup_insert(const uint8_t *Y, Spans sp, uint64_t m, uint64_t seed, DedupTable t, uint32_t *longlist, uint32_t *nlong, uint8_t *last /*nullable: last[j] = Y[ye[j] - w], pfparser.hpp:599*/,
@@ -607,7 +609,7 @@ __global__ __launch_bounds__(BLOCK) void k_dedup_insert(const uint8_t *Y, Spans 
         uint32_t probe = 0;
         bool active = actm;
         while (__any(active ? 1 : 0)) {
-            bool cand = false; tpos_t rs = 0; uint32_t kx = HT_NOIDX;
+            bool cand = false, won = false; tpos_t rs = 0; uint32_t kx = HT_NOIDX;
             if (active) {
                 unsigned long long cur = t.ent[slot].tab;
                 unsigned long long ri = t.ent[slot].rinfo;
@@ -618,16 +620,7 @@ __global__ __launch_bounds__(BLOCK) void k_dedup_insert(const uint8_t *Y, Spans 
                     if (*t.overflow) fin = true;
                     else {
                         cur = atomicCAS(&t.ent[slot].tab, (unsigned long long)HT_EMPTY, (unsigned long long)((filt << 32) | (uint32_t)j));
-                        if (cur == HT_EMPTY) {
-                            const uint32_t k = atomicAdd(t.nd, 1u);
-                            if (k >= t.limit) ht_give_up(t, 1u);
-                            else {
-                                t.ent[slot].rinfo = ((unsigned long long)ys << 16) | len;
-                                t.dslot[k] = (uint32_t)slot; t.dhash[k] = h; t.ent[slot].kidx = k;
-                                t.slotof[j] = k; atomicAdd(&t.ent[slot].cnt, 1u);
-                            }
-                            fin = true;
-                        }
+                        if (cur == HT_EMPTY) { won = true; fin = true; }
                         ri = HT_NOINFO; kx = HT_NOIDX;
                     }
                 }
@@ -637,6 +630,24 @@ __global__ __launch_bounds__(BLOCK) void k_dedup_insert(const uint8_t *Y, Spans 
                     if (ri != HT_NOINFO) { rs = (tpos_t)(ri >> 16); rlen = (uint32_t)(ri & 0xFFFFu); }
                     else phrase_span(sp, (uint32_t)cur, &rs, &rlen);
                     cand = rlen == len;
+                }
+            }
+            // the wave's new entries take their dense indices with ONE update of the counter (a text of distinct phrases -- S-3G -- is bound by exactly
+            // that counter when every lane bumps it by itself: 31 M atomics on one address)
+            const unsigned long long wm = __ballot(won ? 1 : 0);
+            if (wm) {
+                const int leader = __ffsll((long long)wm) - 1;
+                uint32_t kbase = 0;
+                if ((int)lane == leader) kbase = atomicAdd(t.nd, (uint32_t)__popcll(wm));
+                kbase = __shfl(kbase, leader);
+                if (won) {
+                    const uint32_t k = kbase + (uint32_t)__popcll(wm & ((1ULL << lane) - 1ULL));
+                    if (k >= t.limit) ht_give_up(t, 1u);
+                    else {
+                        t.ent[slot].rinfo = ((unsigned long long)ys << 16) | len;
+                        t.dslot[k] = (uint32_t)slot; t.dhash[k] = h; t.ent[slot].kidx = k;
+                        t.slotof[j] = k; atomicAdd(&t.ent[slot].cnt, 1u);
+                    }
                 }
             }
             uint32_t bad = 0;

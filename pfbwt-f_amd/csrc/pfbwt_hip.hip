@@ -838,7 +838,9 @@ static int dedup_strings(pfp_ctx *c, const uint8_t *Y, Spans sp, uint64_t m, uin
             }
             if (c->tun.verbose && ord.period) fprintf(stderr, "[pfbwt_hip] text de-duplication: %llu workgroups visited as %u sequences x %u loci, columns of %u per XCD (grid %llu)\n", (unsigned long long)nb, ord.rows, ord.period, ord.chunk, (unsigned long long)grid);
         }
-        if (c->tun.dedup_variant == 0) PFP_LAUNCH(c, K_PHRASE_HASH, 2 * total_bytes + m * 24, k_dedup_insert<false>, grid, Y, sp, m, c->hash_seed, t, longlist, d_u32 + 2, last_out, d_phase, ord);
+        // variant: 1 = cooperative, 0 = per lane, -1 (default) = cooperative for a collection (>= 8 sequences fed) as long as its first table lasts (parse.h)
+        const bool coop = c->tun.dedup_variant > 0 || (c->tun.dedup_variant < 0 && attempt == 0 && !sp.ys32 && c->nseq + c->fa.records >= 8);
+        if (!coop) PFP_LAUNCH(c, K_PHRASE_HASH, 2 * total_bytes + m * 24, k_dedup_insert<false>, grid, Y, sp, m, c->hash_seed, t, longlist, d_u32 + 2, last_out, d_phase, ord);
         else PFP_LAUNCH(c, K_PHRASE_HASH, 2 * total_bytes + m * 24, k_dedup_insert<true>, grid, Y, sp, m, c->hash_seed, t, longlist, d_u32 + 2, last_out, d_phase, ord);
         if (d_phase) {
             unsigned long long hp[512], tot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -846,8 +848,8 @@ static int dedup_strings(pfp_ctx *c, const uint8_t *Y, Spans sp, uint64_t m, uin
             PFP_HIP(c, hipStreamSynchronize(c->stream));
             for (int q = 0; q < 64; ++q) for (int k = 0; k < 8; ++k) tot[k] += hp[q * 8 + k];
             const double nwg = tot[5] ? (double)tot[5] : 1.0;
-            fprintf(stderr, "[pfbwt_hip] k_dedup_insert (variant %d), thread 0 of %llu workgroups, mean us per stage: abandon flag %.2f, spans + window bounds %.2f, window into LDS %.2f, hash %.2f, table + compare %.2f\n",
-                    c->tun.dedup_variant, tot[5], tot[0] / nwg / 100.0, tot[1] / nwg / 100.0, tot[2] / nwg / 100.0, tot[3] / nwg / 100.0, tot[4] / nwg / 100.0);
+            fprintf(stderr, "[pfbwt_hip] k_dedup_insert (%s), thread 0 of %llu workgroups, mean us per stage: abandon flag %.2f, spans + window bounds %.2f, window into LDS %.2f, hash %.2f, table + compare %.2f\n",
+                    coop ? "cooperative" : "per lane", tot[5], tot[0] / nwg / 100.0, tot[1] / nwg / 100.0, tot[2] / nwg / 100.0, tot[3] / nwg / 100.0, tot[4] / nwg / 100.0);
         }
         uint32_t h3[3];
         PFP_HIP(c, hipMemcpyAsync(h3, d_u32, 12, hipMemcpyDeviceToHost, c->stream));

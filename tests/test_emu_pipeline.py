@@ -233,7 +233,7 @@ print("variant ok")
                                  {"PFP_BIG_GROUP_MEMBERS": "2", "PFP_EMIT_CHUNK_ROWS": "5000", "PFP_CLASS_SORT_MIN": "1", "PFP_CLASS_SORT_MAXRANGE": "150"},
                                  {"PFP_CLASS_SORT_MIN": "1", "PFP_SORT_K": "1", "PFP_CLASS_SORT_MAXRANGE": "150"}, {"PFP_CLASS_SORT_MIN": "1", "PFP_SORT_NO_TABLE": "1"},
                                  {"PFP_DICT_REC": "1", "PFP_BIG_GROUP_MEMBERS": "2"}, {"PFP_DICT_REC": "1", "PFP_DICT_REC_P2": "5", "PFP_PARSE_REC_TILE_ROWS": "20", "PFP_PARSE_REC": "1", "PFP_EMIT_GROUP_ROWS": "12"},
-                                 {"PFP_DEDUP_VARIANT": "0", "PFP_DEDUP_PERIOD": "-1"}, {"PFP_DEDUP_PERIOD": "2", "PFP_DEDUP_CHUNK": "1"}, {"PFP_DEDUP_PERIOD": "3", "PFP_DEDUP_TABLE_LOG2": "5", "PFP_DEDUP_VARIANT": "0"}])
+                                 {"PFP_DEDUP_VARIANT": "0", "PFP_DEDUP_PERIOD": "-1"}, {"PFP_DEDUP_VARIANT": "1", "PFP_DEDUP_PERIOD": "2", "PFP_DEDUP_CHUNK": "1"}, {"PFP_DEDUP_PERIOD": "3", "PFP_DEDUP_TABLE_LOG2": "5", "PFP_DEDUP_VARIANT": "0"}])
 def test_emu_wide_rows_and_chunked_emission(emu_factory, env):
     """The code paths taken by texts of 2^32 bases and more (64-bit row counters, emission in windows of rows, run
     samples in two passes), the sort route for groups of equal suffixes with many members and the LDS class sort of the

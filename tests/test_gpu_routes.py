@@ -83,8 +83,9 @@ ENVS = [
     {"PFP_DICT_REC": "1"},                                                                       # suffix sort of the dictionary through its own level-2 parse (dictrec.h), the route S-32G takes by itself
     {"PFP_DICT_REC": "1", "PFP_DICT_REC_P2": "5", "PFP_PARSE_REC_TILE_ROWS": "40", "PFP_PARSE_REC": "1", "PFP_EMIT_CHUNK_ROWS": "50000"},      # short level-2 phrases, small assembly batches, both recursive sorts
     {"PFP_DICT_REC": "0", "PFP_PARSE_REC": "0", "PFP_DEDUP_VARIANT": "0", "PFP_DEDUP_PERIOD": "-1"},   # the routes of rounds 1-3 (every lane reads its own representative, workgroups in text order)
-    {"PFP_DEDUP_PERIOD": "3", "PFP_DEDUP_CHUNK": "2"},                                            # text de-duplication: workgroups visit the text as a matrix of 3 loci per sequence, columns of 2 per XCD
+    {"PFP_DEDUP_VARIANT": "1", "PFP_DEDUP_PERIOD": "3", "PFP_DEDUP_CHUNK": "2"},                                            # text de-duplication: workgroups visit the text as a matrix of 3 loci per sequence, columns of 2 per XCD
     {"PFP_DEDUP_PERIOD": "1", "PFP_DEDUP_TABLE_LOG2": "5", "PFP_DEDUP_VARIANT": "0"},             # one locus per sequence; a first table that overflows
+    {"PFP_DEDUP_VARIANT": "1", "PFP_DEDUP_TABLE_LOG2": "5"},                                      # the cooperative kernel on both tables (new entries of a wave counted together)
 ]
 
 

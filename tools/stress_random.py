@@ -14,7 +14,7 @@ ENVS = [{}, {"PFP_CLASS_SORT_MAXRANGE": "40"}, {"PFP_SORT_NO_TABLE": "1", "PFP_F
         {"PFP_PARSE_REC": "1", "PFP_PARSE_REC_P2": "3", "PFP_PARSE_REC_TILE_ROWS": "30", "PFP_PARSE_REC_DEPTH": "2", "PFP_EMIT_CHUNK_ROWS": "5000"},
         {"PFP_DICT_REC": "1"},                                                                       # round 4: the dictionary suffix-sorted through its own level-2 parse (dictrec.h), whatever its size
         {"PFP_DICT_REC": "1", "PFP_DICT_REC_P2": "5", "PFP_PARSE_REC_TILE_ROWS": "20", "PFP_PARSE_REC": "1"},
-        {"PFP_DEDUP_VARIANT": "0", "PFP_DEDUP_PERIOD": "-1"}, {"PFP_DEDUP_PERIOD": "3", "PFP_DEDUP_CHUNK": "2"}]   # short level-2 phrases, assembly batches of 20 rows (larger classes through the global sort), both recursive sorts   # two levels, assembly batches of 30 rows (larger classes through the global sort)
+        {"PFP_DEDUP_VARIANT": "0", "PFP_DEDUP_PERIOD": "-1"}, {"PFP_DEDUP_VARIANT": "1", "PFP_DEDUP_PERIOD": "3", "PFP_DEDUP_CHUNK": "2"}]   # short level-2 phrases, assembly batches of 20 rows (larger classes through the global sort), both recursive sorts   # two levels, assembly batches of 30 rows (larger classes through the global sort)
 ap = argparse.ArgumentParser()
 ap.add_argument("--seeds", type=int, nargs=2, default=[1000, 1010]); ap.add_argument("--count", type=int, default=25)
 ap.add_argument("--emu", action="store_true"); ap.add_argument("--envs", action="store_true"); ap.add_argument("--child", action="store_true")
