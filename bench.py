@@ -44,6 +44,9 @@ WORKLOADS = {
     "S-chr22": (50_818_468, 1, 22, (10_000_000, 10_000_000, 35_000_000, 1_000_000), 10, 100, False),
     "S-50M": (5_000_000, 10, 12345, (0, 0, 0, 0), 10, 100, False),
     "S-5M": (5_000_000, 1, 22, (1_000_000, 500_000, 3_000_000, 50_000), 10, 100, False),
+    # small collections (measurements of the text de-duplication: 8.6 % / 3 % of their phrases are distinct, 0.5 % of S-32G's)
+    "S-20x32M": (32_000_000, 20, 1000, (0, 0, 0, 0), 10, 100, True),
+    "S-100x32M": (32_000_000, 100, 1000, (0, 0, 0, 0), 10, 100, True),
     # the north-star shape: 1000 haplotypes x 32 Mbase = 32 Gbase on ONE GPU, -r (BWT + run-length sampled SA, a full
     # .sa of 32 G x 8 B does not fit), pfbwt-f64 path.
     "S-32G": (32_000_000, 1000, 1000, (0, 0, 0, 0), 10, 100, True),
@@ -52,7 +55,7 @@ WORKLOADS = {
     # configs[2] stand-in: one GRCh38-sized sequence (3.1 Gbase, 35 Mbp of N in two runs), -s -r, pfbwt-f64 path
     "S-3G": (3_100_000_000, 1, 38, (500_000_000, 30_000_000, 2_000_000_000, 5_000_000), 10, 100, True),
 }
-OUTPUTS = {"S-32G": (False, True), "S-50G": (False, True), "S-3G": (True, True)}      # (-s, -r); default: -s only
+OUTPUTS = {"S-32G": (False, True), "S-50G": (False, True), "S-3G": (True, True), "S-20x32M": (False, True), "S-100x32M": (False, True)}      # (-s, -r); default: -s only
 CPU_SAMPLE_HAPLOTYPES = 10        # large collections: the CPU baseline / oracle parity run covers the first 10 haplotypes
 CPU_SAMPLE_BASES = 100_000_000    # one huge sequence: its first 100 Mbase (~20 s of CPU work)
 
