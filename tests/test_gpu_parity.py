@@ -201,6 +201,9 @@ def test_medium_panel_default_routes_vs_oracle(gpu_ctx_factory):
     c = gpu_ctx_factory(w=10, p=100, u64=True, sai=True)
     for sa, names in ((False, ("bwt", "ssa", "esa")), (True, ("bwt", "sa", "ssa", "esa"))):
         c.reset()
+        # first build: every switch at its default (220 sequences: the wave-cooperative de-duplication kernel by itself); second build: the text visited as
+        # 220 sequences x 39 loci, one set of locus columns per XCD -- the order S-32G takes by itself (its sequences are long enough), here next to the oracle
+        if sa: c.debug_set(dedup_period=39)
         for s in seqs:
             c.feed(s, True)
         sz = c.finalize(); c.parse_bwt(); c.bwt_build(sa=sa, rssa=True)
