@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""One-off: hit rate of the "follow the previous match" path of the text de-duplication on a synthetic panel (run with PFP_VERBOSE=1;
-forced first-launch size with PFP_TEST_HOOKS=1 PFP_DEDUP_FOLLOW=<phrases>).  usage: python tools/follow_check.py H L [u64]"""
+"""One-off (round 4): parse of a synthetic panel of H sequences x L bases with PFP_VERBOSE=1 -- with profiles/r04fw_follow_path.patch applied it prints the hit rate
+of the "follow the previous match" path of the text de-duplication (PFP_TEST_HOOKS=1 PFP_DEDUP_FOLLOW=<phrases of the first launch>; the path was measured slower and is not
+in the tree); without the patch: sizes of the parse and, for collections, the order in which the de-duplication visits the text.
+usage: python tools/follow_check.py H L [u64]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "pfbwt-f_amd", "python"))
