@@ -171,14 +171,15 @@ __global__ __launch_bounds__(BLOCK) void k_dr_p2_class(const uint32_t *SA2, cons
     if (s < n2) rc[SA2[s]] = headslot[s];
 }
 // list entry (a phrase occurrence, grouped by distinct phrase): key = tie class of the sampled suffix at the next phrase of its word (0 behind
-// a word's last phrase: nothing follows), position = first byte of the occurrence
+// a word's last phrase: nothing follows), position = first byte of the occurrence (| bit 31 when that byte starts a word)
 __global__ __launch_bounds__(BLOCK) void k_dr_list_payload(const uint8_t *D, const uint32_t *inv, const uint32_t *ps, const uint32_t *pe, const uint32_t *wordid, const uint32_t *rc, uint64_t k, uint32_t *ikey, uint32_t *ipos)
 {
     const uint64_t e = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (e >= k) return;
     const uint32_t j = inv[e], en = pe[j];
     ikey[e] = D[en] == EndOfWord ? 0u : rc[j + 1u + wordid[en]];
-    ipos[e] = ps[j];
+    const uint32_t x = ps[j];      // bit 31: the occurrence starts a dictionary word (row `x` itself then gets sflag = 1 from the assembly; positions stay below 2^31)
+    ipos[e] = x | ((D[x] > EndOfWord && (x == 0 || D[x - 1] == EndOfWord)) ? 0x80000000u : 0u);
 }
 // per slot of SA(D2): rows it stands for, whole-phrase flag.  Offset o of phrase W (L bytes): a closing phrase owns every offset up to its
 // separator (the word's EndOfWord), any other phrase the offsets whose suffix is longer than the window
@@ -229,14 +230,6 @@ __global__ __launch_bounds__(BLOCK) void k_dr_final_heads(const uint32_t *okey, 
     const bool hd = r <= 1 || cstart[r] || okey[r] != okey[r - 1];
     headslot[r] = hd ? (uint32_t)r : 0u;
 }
-__global__ __launch_bounds__(BLOCK) void k_dr_flags(const uint8_t *D, const uint32_t *gsa, uint64_t N, uint8_t *sflag)
-{
-    const uint64_t r = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (r >= N) return;
-    const uint32_t x = gsa[r];
-    sflag[r] = (D[x] > EndOfWord && (x == 0 || D[x - 1] == EndOfWord)) ? (uint8_t)1 : (uint8_t)0;
-}
-
 // *taken = 0: nothing was written (the dictionary does not shrink, a phrase is too long, ...): the caller sorts with sufsort.h
 inline int dict_sort_pfp(pfp_ctx *c, uint32_t *gsa, uint32_t *srank, uint8_t *sflag, int *taken)
 {
@@ -370,7 +363,7 @@ inline int dict_sort_pfp(pfp_ctx *c, uint32_t *gsa, uint32_t *srank, uint8_t *sf
     PFP_HIP(c, hipMemsetAsync(cstart, 0, (N + 1) * 4, c->stream));
     const unsigned ga = nblocks(N - 1, RS_TILE / 2);
     PFP_LAUNCH(c, K_REC_ASSEMBLE, (N - 1) * 16 + nv * 16, (k_rs_assemble<false, true>), ga, (const uint4 *)srec, (const uint32_t *)chead, (const uint32_t *)crow, (uint32_t)nc, (const uint32_t *)ikey, (const uint32_t *)ipos,
-               keybits, tile_rows, gsa, (uint32_t *)nullptr, bigc, d_cnt + 1, okey);
+               keybits, tile_rows, gsa, (uint32_t *)nullptr, bigc, d_cnt + 1, okey, sflag);
     PFP_LAUNCH(c, K_MISC, 8, k_rs_first_row, 1, gsa, (uint32_t *)nullptr, N);
     uint32_t nb32 = 0; PFP_TRY(d2h_u32(c, d_cnt + 1, &nb32));
     if (nb32) {
@@ -384,18 +377,18 @@ inline int dict_sort_pfp(pfp_ctx *c, uint32_t *gsa, uint32_t *srank, uint8_t *sf
         uint64_t *bk0, *bk1; uint32_t *bv0, *bv1;
         PFP_ALLOC_HI(c, bk0, uint64_t, nbr); PFP_ALLOC_HI(c, bk1, uint64_t, nbr); PFP_ALLOC_HI(c, bv0, uint32_t, nbr); PFP_ALLOC_HI(c, bv1, uint32_t, nbr);
         PFP_LAUNCH(c, K_REC_PARSE, nbr * 40, k_rs_big_rows, nblocks(nbr, BLOCK), (const uint32_t *)bigc, (const uint32_t *)bigoff, (uint32_t)nb, nbr, (const uint32_t *)crow, (const uint32_t *)chead, (const uint4 *)srec,
-                   (const uint32_t *)ikey, (const uint32_t *)ipos, bk0, bv0);
+                   (const uint32_t *)ikey, (const uint32_t *)ipos, bk0, bv0, 1);
         BitRange br[2] = {{0, keybits}, {32, 32 + bits_for(nb - 1)}};
         uint64_t *sk; uint32_t *sv;
         PFP_TRY(radix_sort_pairs<uint64_t>(c, bk0, bv0, bk1, bv1, nbr, br, 2, &sk, &sv));
         PFP_LAUNCH(c, K_REC_PARSE, nbr * 24, (k_rs_big_store<false, true>), nblocks(nbr, BLOCK), (const uint64_t *)sk, (const uint32_t *)sv, nbr, (const uint32_t *)bigc, (const uint32_t *)bigoff, (const uint32_t *)crow, gsa,
-                   (uint32_t *)nullptr, okey);
+                   (uint32_t *)nullptr, okey, sflag);
     }
     // ---- classes of identical dictionary suffixes, word-start flags
     PFP_LAUNCH(c, K_REC_PARSE, nc * 8, k_dr_mark_class_rows, nblocks(nc, BLOCK), (const uint32_t *)crow, nc, cstart);
     PFP_LAUNCH(c, K_REC_PARSE, N * 12, k_dr_final_heads, nblocks(N, BLOCK), (const uint32_t *)okey, (const uint32_t *)cstart, N, srank);
     PFP_TRY((device_scan<uint32_t, 1>(c, srank, srank, N, nullptr)));
-    PFP_LAUNCH(c, K_REC_PARSE, N * 7, k_dr_flags, nblocks(N, BLOCK), D, (const uint32_t *)gsa, N, sflag);
+    PFP_HIP(c, hipMemsetAsync(sflag, 0, 1, c->stream));      // row 0 is the final EndOfDict; every other row's flag came out of the assembly (k_rs_assemble / k_rs_big_store)
     PFP_HIP(c, hipStreamSynchronize(c->stream));
     if (verbose) fprintf(stderr, "[pfbwt_hip]   dictionary assembled: %llu slots, %llu D2 classes (%.1f ms)\n", (unsigned long long)nv, (unsigned long long)nc, tm.ms());
     c->arena.release_hi(mk);

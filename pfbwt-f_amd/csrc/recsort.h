@@ -261,7 +261,8 @@ template <int NB> __device__ __forceinline__ void rs_same_digit_lanes(uint32_t d
 constexpr int RA_DB = 9, RA_RADIX = 1 << RA_DB;
 template <bool RANK, bool KEYOUT> __global__ __launch_bounds__(BLOCK) void k_rs_assemble(const uint4 *srec, const uint32_t *chead /*nc + 1*/, const uint32_t *crow /*nc + 1*/, uint32_t nc,
                                                                             const uint32_t *ikey, const uint32_t *ipos, int keybits, uint32_t tile_rows, uint32_t *SA, uint32_t *rank,
-                                                                            uint32_t *bigc, uint32_t *nbig, uint32_t *okey /*KEYOUT (dictrec.h): the key of every row, in row order*/)
+                                                                            uint32_t *bigc, uint32_t *nbig, uint32_t *okey /*KEYOUT (dictrec.h): the key of every row, in row order*/,
+                                                                            uint8_t *oflag /*KEYOUT: bit 31 of a list position marks the start of a dictionary word; oflag[row] = the row is that position itself (sflag)*/)
 {
     constexpr int ITEMS = RS_ITEMS, TILE = RS_TILE;
     constexpr uint32_t STEP = TILE / 2;
@@ -305,7 +306,7 @@ template <bool RANK, bool KEYOUT> __global__ __launch_bounds__(BLOCK) void k_rs_
                 while (lo < hi) { const uint32_t mid = lo + ((hi - lo + 1) >> 1); if (srow[mid] <= i) lo = mid; else hi = mid - 1; }
                 const uint4 rec = srec[v0 + lo];
                 const uint32_t e = rec.y + (i - (rec.x - r0));
-                xi[it] = ipos[e] + rec.z;
+                xi[it] = KEYOUT ? (rec.z ? (ipos[e] & 0x7FFFFFFFu) + rec.z : ipos[e]) : ipos[e] + rec.z;
                 skeys[i] = ((uint64_t)(rec.w - ci) << keybits) | ikey[e];
                 sidx[i] = (uint16_t)i;
             }
@@ -372,7 +373,8 @@ template <bool RANK, bool KEYOUT> __global__ __launch_bounds__(BLOCK) void k_rs_
         for (int it = 0; it < ITEMS; ++it) { const uint32_t i = threadIdx.x + (uint32_t)it * BLOCK; if (i < n) sx[i] = xi[it]; }
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < n; i += BLOCK) {
-            const uint32_t x = sx[sidx[i]];
+            uint32_t x = sx[sidx[i]];
+            if (KEYOUT) { oflag[1u + r0 + i] = (uint8_t)(x >> 31); x &= 0x7FFFFFFFu; }
             SA[1u + r0 + i] = x;
             if (RANK) rank[x] = 1u + r0 + i;
         }
@@ -388,7 +390,7 @@ __global__ __launch_bounds__(BLOCK) void k_rs_big_sizes(const uint32_t *bigc, ui
     else if (b == nb) sizes[b] = 0u;
 }
 __global__ __launch_bounds__(BLOCK) void k_rs_big_rows(const uint32_t *bigc, const uint32_t *bigoff /*nb + 1*/, uint32_t nb, uint64_t nbr, const uint32_t *crow, const uint32_t *chead, const uint4 *srec,
-                                                       const uint32_t *ikey, const uint32_t *ipos, uint64_t *keys, uint32_t *vals)
+                                                       const uint32_t *ikey, const uint32_t *ipos, uint64_t *keys, uint32_t *vals, int flagged /*dictrec.h: bit 31 of a list position is a flag (see k_rs_assemble)*/)
 {
     const uint64_t q = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (q >= nbr) return;
@@ -400,15 +402,16 @@ __global__ __launch_bounds__(BLOCK) void k_rs_big_rows(const uint32_t *bigc, con
     const uint4 rec = srec[vl];
     const uint32_t e = rec.y + (row - rec.x);
     keys[q] = ((uint64_t)b << 32) | ikey[e];
-    vals[q] = ipos[e] + rec.z;
+    vals[q] = flagged ? (rec.z ? (ipos[e] & 0x7FFFFFFFu) + rec.z : ipos[e]) : ipos[e] + rec.z;
 }
-template <bool RANK, bool KEYOUT> __global__ __launch_bounds__(BLOCK) void k_rs_big_store(const uint64_t *keys, const uint32_t *vals, uint64_t nbr, const uint32_t *bigc, const uint32_t *bigoff, const uint32_t *crow, uint32_t *SA, uint32_t *rank, uint32_t *okey)
+template <bool RANK, bool KEYOUT> __global__ __launch_bounds__(BLOCK) void k_rs_big_store(const uint64_t *keys, const uint32_t *vals, uint64_t nbr, const uint32_t *bigc, const uint32_t *bigoff, const uint32_t *crow, uint32_t *SA, uint32_t *rank, uint32_t *okey, uint8_t *oflag)
 {
     const uint64_t q = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (q >= nbr) return;
     const uint32_t b = (uint32_t)(keys[q] >> 32);
     const uint32_t row = crow[bigc[b]] + (uint32_t)(q - bigoff[b]);
-    const uint32_t x = vals[q];
+    uint32_t x = vals[q];
+    if (KEYOUT) { oflag[1u + row] = (uint8_t)(x >> 31); x &= 0x7FFFFFFFu; }
     SA[1u + row] = x;
     if (RANK) rank[x] = 1u + row;
     if (KEYOUT) okey[1u + row] = (uint32_t)keys[q];
@@ -562,9 +565,9 @@ inline int suffix_sort_pfp(pfp_ctx *c, const uint32_t *dS, uint64_t N, uint64_t 
     const unsigned ga = nblocks(N - 1, RS_TILE / 2);
     // algorithmic bytes per row: list entry 8 in, text position 4 out (+ 4 rank); per slot 16
     if (rank) PFP_LAUNCH(c, K_REC_ASSEMBLE, (N - 1) * 16 + nv * 16, (k_rs_assemble<true, false>), ga, (const uint4 *)srec, (const uint32_t *)chead, (const uint32_t *)crow, (uint32_t)nc, (const uint32_t *)ikey, (const uint32_t *)ipos,
-                         keybits, tile_rows, SA, rank, bigc, d_cnt + 1, (uint32_t *)nullptr);
+                         keybits, tile_rows, SA, rank, bigc, d_cnt + 1, (uint32_t *)nullptr, (uint8_t *)nullptr);
     else PFP_LAUNCH(c, K_REC_ASSEMBLE, (N - 1) * 12 + nv * 16, (k_rs_assemble<false, false>), ga, (const uint4 *)srec, (const uint32_t *)chead, (const uint32_t *)crow, (uint32_t)nc, (const uint32_t *)ikey, (const uint32_t *)ipos,
-                    keybits, tile_rows, SA, rank, bigc, d_cnt + 1, (uint32_t *)nullptr);
+                    keybits, tile_rows, SA, rank, bigc, d_cnt + 1, (uint32_t *)nullptr, (uint8_t *)nullptr);
     PFP_LAUNCH(c, K_MISC, 8, k_rs_first_row, 1, SA, rank, N);
     uint32_t nb32 = 0; PFP_TRY(d2h_u32(c, d_cnt + 1, &nb32));
     if (nb32) {      // classes with more rows than a tile
@@ -578,12 +581,12 @@ inline int suffix_sort_pfp(pfp_ctx *c, const uint32_t *dS, uint64_t N, uint64_t 
         uint64_t *bk0, *bk1; uint32_t *bv0, *bv1;
         PFP_ALLOC_HI(c, bk0, uint64_t, nbr); PFP_ALLOC_HI(c, bk1, uint64_t, nbr); PFP_ALLOC_HI(c, bv0, uint32_t, nbr); PFP_ALLOC_HI(c, bv1, uint32_t, nbr);
         PFP_LAUNCH(c, K_REC_PARSE, nbr * 40, k_rs_big_rows, nblocks(nbr, BLOCK), (const uint32_t *)bigc, (const uint32_t *)bigoff, (uint32_t)nb, nbr, (const uint32_t *)crow, (const uint32_t *)chead, (const uint4 *)srec,
-                   (const uint32_t *)ikey, (const uint32_t *)ipos, bk0, bv0);
+                   (const uint32_t *)ikey, (const uint32_t *)ipos, bk0, bv0, 0);
         BitRange br[2] = {{0, keybits}, {32, 32 + bits_for(nb - 1)}};
         uint64_t *sk; uint32_t *sv;
         PFP_TRY(radix_sort_pairs<uint64_t>(c, bk0, bv0, bk1, bv1, nbr, br, 2, &sk, &sv));
-        if (rank) PFP_LAUNCH(c, K_REC_PARSE, nbr * 24, (k_rs_big_store<true, false>), nblocks(nbr, BLOCK), (const uint64_t *)sk, (const uint32_t *)sv, nbr, (const uint32_t *)bigc, (const uint32_t *)bigoff, (const uint32_t *)crow, SA, rank, (uint32_t *)nullptr);
-        else PFP_LAUNCH(c, K_REC_PARSE, nbr * 20, (k_rs_big_store<false, false>), nblocks(nbr, BLOCK), (const uint64_t *)sk, (const uint32_t *)sv, nbr, (const uint32_t *)bigc, (const uint32_t *)bigoff, (const uint32_t *)crow, SA, rank, (uint32_t *)nullptr);
+        if (rank) PFP_LAUNCH(c, K_REC_PARSE, nbr * 24, (k_rs_big_store<true, false>), nblocks(nbr, BLOCK), (const uint64_t *)sk, (const uint32_t *)sv, nbr, (const uint32_t *)bigc, (const uint32_t *)bigoff, (const uint32_t *)crow, SA, rank, (uint32_t *)nullptr, (uint8_t *)nullptr);
+        else PFP_LAUNCH(c, K_REC_PARSE, nbr * 20, (k_rs_big_store<false, false>), nblocks(nbr, BLOCK), (const uint64_t *)sk, (const uint32_t *)sv, nbr, (const uint32_t *)bigc, (const uint32_t *)bigoff, (const uint32_t *)crow, SA, rank, (uint32_t *)nullptr, (uint8_t *)nullptr);
     }
     PFP_HIP(c, hipStreamSynchronize(c->stream));
     if (verbose) fprintf(stderr, "[pfbwt_hip]   assembled: %llu slots, %llu classes (%.1f ms)\n", (unsigned long long)nv, (unsigned long long)nc, tm.ms());
