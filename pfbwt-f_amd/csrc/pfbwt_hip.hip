@@ -534,6 +534,7 @@ static int fa_finish_stream(pfp_ctx *c)
     }
     uint32_t fl = 0;
     if (f.d_tot) { PFP_HIP(c, hipMemcpyAsync(&fl, f.d_tot + 4, 4, hipMemcpyDeviceToHost, c->stream)); PFP_HIP(c, hipStreamSynchronize(c->stream)); PFP_HIP(c, hipMemsetAsync(f.d_tot + 4, 0, 8, c->stream)); }
+    c->nseq += f.records;      // (the hint the text de-duplication orders its workgroups by)
     f.started = false; f.state = FA_L; f.records = 0;
     if (fl & 1u) { c->err_ch = '+'; return PFP_E_ARG; }                             // a FASTQ quality section: not handled on the device
     return PFP_OK;
