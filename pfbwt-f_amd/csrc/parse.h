@@ -468,6 +468,36 @@ struct LdsWords {
 // (~1 MB) stay in that XCD's 4 MB L2 while all `rows` sequences pass.  Only the ORDER changes -- any estimate gives the same table; a bad one just does
 // not help.  period == 0: text order.  Grid = 8 * ceil(period / (8 * chunk)) * chunk * rows workgroups; those that fall outside the matrix return at once.
 struct DedupOrder { uint32_t period, chunk, rows; };
+// hardware workgroup b -> the workgroup of the text (or of any array laid out like the text) it works on; false: none (it lies outside the matrix)
+__device__ __forceinline__ bool dedup_order_block(const DedupOrder &ord, uint32_t b, uint64_t nblk, uint64_t *B)
+{
+    *B = b;
+    if (!ord.period) return true;
+    const uint32_t x = b & 7u, tt = b >> 3, cell = ord.chunk * ord.rows;
+    const uint32_t k = tt / cell, r = tt - k * cell, hrow = r / ord.chunk, i = r - hrow * ord.chunk;
+    const uint64_t col = (uint64_t)(k * 8u + x) * ord.chunk + i;
+    if (col >= ord.period) return false;
+    *B = (uint64_t)hrow * ord.period + col;
+    return *B < nblk;
+}
+// host: the order for nb workgroups of a text fed as nseq sequences; *grid = workgroups to launch.  period_req / chunk_req: the dedup_period / dedup_chunk switches
+// (period 0 = nb / nseq when that is at least min_period workgroups, < 0 = text order).
+inline DedupOrder make_dedup_order(uint64_t nb, uint64_t nseq, int64_t period_req, int64_t chunk_req, uint64_t min_period, uint64_t *grid)
+{
+    DedupOrder ord = {0u, 0u, 0u};
+    *grid = nb;
+    uint64_t period = period_req > 0 ? (uint64_t)period_req : (period_req == 0 && nseq >= 8 ? (nb + nseq / 2) / nseq : 0);
+    if (period_req == 0 && period < min_period) period = 0;
+    if (period && period < nb) {
+        uint64_t chunk = chunk_req > 0 ? (uint64_t)chunk_req : 0;
+        if (!chunk) { const uint64_t q0 = (period + 128) / 256 ? (period + 128) / 256 : 1; chunk = (period + 8 * q0 - 1) / (8 * q0); }
+        if (chunk > period) chunk = period;
+        const uint64_t q = (period + 8 * chunk - 1) / (8 * chunk), rows = (nb + period - 1) / period;
+        const uint64_t g = 8 * q * chunk * rows;
+        if (g < 0x7FFFFFFFULL && chunk * rows < 0xFFFFFFFFULL) { ord.period = (uint32_t)period; ord.chunk = (uint32_t)chunk; ord.rows = (uint32_t)rows; *grid = g; }
+    }
+    return ord;
+}
 // COOP (round 4): the representatives' bytes are read by the wave together (see below); false = every lane reads its own representative (rounds 2-3).
 // The host takes COOP for a collection (>= 8 sequences fed) while its first, small table lasts: on a text of DISTINCT phrases the cooperative kernel is 2.4 x slower
 // (S-3G: 80 against 34 ms; none of its parts explains it when switched off one by one -- r04ag_s3g_exp.log -- so the cause is open).
@@ -481,15 +511,8 @@ __global__ __launch_bounds__(BLOCK) void k_dedup_insert(const uint8_t *Y, Spans 
     __shared__ uint32_t tile[TILE_BYTES / 4 + 20];
     unsigned long long tk[6] = {0, 0, 0, 0, 0, 0};
     if (phase) tk[0] = wall_clock64();
-    uint64_t B = blockIdx.x;
-    if (ord.period) {      // (see DedupOrder)
-        const uint32_t x = blockIdx.x & 7u, tt = blockIdx.x >> 3, cell = ord.chunk * ord.rows;
-        const uint32_t k = tt / cell, r = tt - k * cell, hrow = r / ord.chunk, i = r - hrow * ord.chunk;
-        const uint64_t col = (uint64_t)(k * 8u + x) * ord.chunk + i;
-        if (col >= ord.period) return;
-        B = (uint64_t)hrow * ord.period + col;
-        if (B * NT >= m) return;
-    }
+    uint64_t B;
+    if (!dedup_order_block(ord, blockIdx.x, (m + NT - 1) / NT, &B)) return;      // (see DedupOrder)
     const uint64_t j = B * NT + threadIdx.x;
     const bool live = j < m;
     tpos_t ys = 0; uint32_t len = 0;

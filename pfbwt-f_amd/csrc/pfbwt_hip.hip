@@ -823,22 +823,9 @@ static int dedup_strings(pfp_ctx *c, const uint8_t *Y, Spans sp, uint64_t m, uin
         if (c->tun.dedup_phases) { PFP_ALLOC_HI(c, d_phase, unsigned long long, 512); PFP_HIP(c, hipMemsetAsync(d_phase, 0, 4096, c->stream)); }
         // the order of the workgroups (parse.h, DedupOrder): columns of loci per XCD when the text is a collection of similar sequences
         const uint64_t nb = gm;
-        DedupOrder ord = {0u, 0u, 0u};
         uint64_t grid = nb;
-        {
-            const uint64_t nseq = c->nseq + c->fa.records;
-            uint64_t period = c->tun.dedup_period > 0 ? (uint64_t)c->tun.dedup_period : (c->tun.dedup_period == 0 && !sp.ys32 && nseq >= 8 ? (nb + nseq / 2) / nseq : 0);
-            if (c->tun.dedup_period == 0 && period < 64) period = 0;      // sequences of less than ~1.6 Mbase: nothing to gain
-            if (period && period < nb) {
-                uint64_t chunk = c->tun.dedup_chunk > 0 ? (uint64_t)c->tun.dedup_chunk : 0;
-                if (!chunk) { const uint64_t q0 = (period + 128) / 256 ? (period + 128) / 256 : 1; chunk = (period + 8 * q0 - 1) / (8 * q0); }
-                if (chunk > period) chunk = period;
-                const uint64_t q = (period + 8 * chunk - 1) / (8 * chunk), rows = (nb + period - 1) / period;
-                const uint64_t g = 8 * q * chunk * rows;
-                if (g < 0x7FFFFFFFULL && chunk * rows < 0xFFFFFFFFULL) { ord.period = (uint32_t)period; ord.chunk = (uint32_t)chunk; ord.rows = (uint32_t)rows; grid = g; }
-            }
-            if (c->tun.verbose && ord.period) fprintf(stderr, "[pfbwt_hip] text de-duplication: %llu workgroups visited as %u sequences x %u loci, columns of %u per XCD (grid %llu)\n", (unsigned long long)nb, ord.rows, ord.period, ord.chunk, (unsigned long long)grid);
-        }
+        const DedupOrder ord = make_dedup_order(nb, sp.ys32 ? 0 : c->nseq + c->fa.records, c->tun.dedup_period, c->tun.dedup_chunk, 64 /* sequences of less than ~1.6 Mbase: nothing to gain */, &grid);
+        if (c->tun.verbose && ord.period) fprintf(stderr, "[pfbwt_hip] text de-duplication: %llu workgroups visited as %u sequences x %u loci, columns of %u per XCD (grid %llu)\n", (unsigned long long)nb, ord.rows, ord.period, ord.chunk, (unsigned long long)grid);
         // variant: 1 = cooperative, 0 = per lane, -1 (default) = cooperative for a collection (>= 8 sequences fed) as long as its first table lasts (parse.h)
         const bool coop = c->tun.dedup_variant > 0 || (c->tun.dedup_variant < 0 && attempt == 0 && !sp.ys32 && c->nseq + c->fa.records >= 8);
         if (!coop) PFP_LAUNCH(c, K_PHRASE_HASH, 2 * total_bytes + m * 24, k_dedup_insert<false>, grid, Y, sp, m, c->hash_seed, t, longlist, d_u32 + 2, last_out, d_phase, ord);
