@@ -89,8 +89,8 @@ static int sharded_phase_exchange(pfp_sharded *s, int r, const ShardMeta *meta, 
     if (s->sendcap[(size_t)r] < maxb) {      // the collective sends maxb bytes from every rank
         uint8_t *nb = nullptr;
         if (hipMalloc((void **)&nb, maxb) != hipSuccess) { (void)hipGetLastError(); return PFP_E_NOMEM; }
-        PFP_HIP(c, hipMemcpy(nb, s->sendbuf[(size_t)r], (size_t)meta[r].bytes, hipMemcpyDeviceToDevice));
-        PFP_HIP(c, hipFree(s->sendbuf[(size_t)r])); s->sendbuf[(size_t)r] = nb; s->sendcap[(size_t)r] = maxb;
+        if (hipMemcpy(nb, s->sendbuf[(size_t)r], (size_t)meta[r].bytes, hipMemcpyDeviceToDevice) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(nb); return PFP_E_HIP; }
+        (void)hipFree(s->sendbuf[(size_t)r]); s->sendbuf[(size_t)r] = nb; s->sendcap[(size_t)r] = maxb;
     }
     if (s->recvcap[(size_t)r] < maxb * (size_t)N) {
         if (s->recvbuf[(size_t)r]) PFP_HIP(c, hipFree(s->recvbuf[(size_t)r]));
@@ -108,7 +108,11 @@ static int sharded_phase_gather(pfp_sharded *s, int r, const ShardMeta *meta, si
 #ifndef PFBWT_EMU_HIP_RUNTIME_H
     if (s->distinct) {
         const ncclResult_t e = s->p_all_gather(s->sendbuf[(size_t)r], s->recvbuf[(size_t)r], maxb, ncclUint8, s->comm[(size_t)r], c->stream);
-        if (e != ncclSuccess) { snprintf(s->err, sizeof s->err, "ncclAllGather: %s", s->p_errstr ? s->p_errstr(e) : "error"); return PFP_E_HIP; }
+        if (e != ncclSuccess) {      // several ranks may fail at once: one writer of the shared message
+            static std::mutex err_mu; std::lock_guard<std::mutex> g(err_mu);
+            if (!s->err[0]) snprintf(s->err, sizeof s->err, "rank %d: ncclAllGather: %s", r, s->p_errstr ? s->p_errstr(e) : "error");
+            return PFP_E_HIP;
+        }
         PFP_HIP(c, hipStreamSynchronize(c->stream));
         return PFP_OK;
     }
@@ -178,7 +182,10 @@ pfp_sharded *pfp_sharded_create(int w, uint64_t p, unsigned flags, int ndev, con
                 s->p_destroy = (decltype(s->p_destroy))dlsym(s->rccl, "ncclCommDestroy");
                 s->p_errstr = (decltype(s->p_errstr))dlsym(s->rccl, "ncclGetErrorString");
             }
-            if (!s->rccl || !s->p_init_all || !s->p_all_gather || !s->p_destroy) { fprintf(stderr, "[pfbwt_hip] pfp_sharded_create: librccl.so not available (%s)\n", dlerror() ? dlerror() : "symbols missing"); st = PFP_E_HIP; }
+            if (!s->rccl || !s->p_init_all || !s->p_all_gather || !s->p_destroy) {
+                const char *why = dlerror();      // one call: dlerror() clears the message it returns
+                fprintf(stderr, "[pfbwt_hip] pfp_sharded_create: librccl.so not available (%s)\n", why ? why : "symbols missing"); st = PFP_E_HIP;
+            }
             else {
                 s->comm.assign((size_t)ndev, nullptr);
                 const ncclResult_t e = s->p_init_all(s->comm.data(), ndev, s->dev.data());
@@ -221,6 +228,7 @@ int pfp_sharded_build(pfp_sharded *s, int want_sa, int want_rssa, pfp_parse_size
 {
     using namespace pfp;
     if (!s) return PFP_E_ARG;
+    s->err[0] = 0;      // the message belongs to this build, not to an earlier one that failed
     const int N = s->ndev;
     std::vector<ShardMeta> meta((size_t)N);
     std::vector<int> rc((size_t)N, PFP_OK);
