@@ -1029,6 +1029,21 @@ template <typename EBT> __global__ __launch_bounds__(BLOCK) void k_slice_bounds(
 // a thread bisects that list for its first row and walks on from there.  The rows of special slots get the placeholder
 // s_pc too and are overwritten by k_emit afterwards (same stream).  bwt points at row a.w0 and (bwt - a.w0) is 16-byte
 // aligned (host).
+// The 16-byte row stores of k_fill (32 GB per build on S-32G; nothing in the kernel reads them back).  PFP_FILL_NT=1 gives them the
+// streaming (non-temporal) policy; measured against the plain store on one box: profiles/r04nt_*.
+#ifndef PFP_FILL_NT
+#define PFP_FILL_NT 0
+#endif
+__device__ __forceinline__ void fill_store16(uint8_t *dst, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3)
+{
+#if PFP_FILL_NT && !defined(PFBWT_EMU_HIP_RUNTIME_H)
+    typedef uint32_t fill_v4u __attribute__((ext_vector_type(4)));
+    fill_v4u v = {x0, x1, x2, x3};
+    __builtin_nontemporal_store(v, reinterpret_cast<fill_v4u *>(dst));
+#else
+    *reinterpret_cast<uint4 *>(dst) = make_uint4(x0, x1, x2, x3);
+#endif
+}
 constexpr int FILL_PER_THREAD = 16, FILL_SUB = BLOCK * FILL_PER_THREAD;      // 4096 rows = 2 emission tiles
 constexpr int FILL_GROUPS = 4;                                                // groups of FILL_SUB rows that share one slot list (a super-tile)
 constexpr uint32_t FILL_MAX_SUBS = 8;                                         // super-tiles per workgroup, at most
@@ -1108,7 +1123,7 @@ template <typename EBT> __global__ __launch_bounds__(BLOCK) void k_fill(EmitArgs
             }
         }
         uint8_t *dst = bwt + (ra - a.w0);                     // may point in front of the buffer when ra < w0: only rows in [lo, hi) are stored
-        if (lo == ra && hi == ra + FILL_PER_THREAD) *reinterpret_cast<uint4 *>(dst) = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+        if (lo == ra && hi == ra + FILL_PER_THREAD) fill_store16(dst, wd[0], wd[1], wd[2], wd[3]);
         else for (uint64_t o = lo; o < hi; ++o) { const int j = (int)(o - ra); dst[j] = (uint8_t)(wd[j >> 2] >> (8 * (j & 3))); }
     };
     for (uint32_t ss = 0; ss < subs_per_wg; ++ss) {
