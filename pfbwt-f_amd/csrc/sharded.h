@@ -234,6 +234,8 @@ int pfp_sharded_build(pfp_sharded *s, int want_sa, int want_rssa, pfp_parse_size
     std::vector<int> rc((size_t)N, PFP_OK);
     std::vector<pfp_parse_sizes> ps((size_t)N);
     size_t maxb = 0;
+    // Known limit: a rank whose ncclAllGather call itself fails (phase 2) leaves the others waiting inside the collective -- the
+    // barriers only cover failures in front of it (parse, pack, allocation); a watchdog with ncclCommAbort is not built.
     // the phases of one rank; between them every rank waits for all the others (the packs must be complete before they are
     // read, the receive buffers allocated before a collective writes to them) and learns whether one of them failed -- a rank
     // that cannot parse its shard must not leave the others waiting inside the all-gather
